@@ -1,0 +1,17 @@
+"""pytest configuration: marker registration + import paths.
+
+``-m "not gpu"`` : oracle vs golden vectors, host logic, C-ABI symbol checks, gloo DDP tests.
+``-m gpu``       : parity tests proper (HIP engine through the C-ABI vs the oracle / golden).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "disentangling-vae_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")

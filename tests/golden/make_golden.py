@@ -1,0 +1,183 @@
+"""Generate golden vectors by running the REAL reference (read-only at /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference is imported unmodified with the two import shims of SURVEY.md section 8c
+(stub ``imageio``; ``numpy.product = numpy.prod``).  Noise is recorded by wrapping
+``torch.randn_like`` / ``torch.randperm`` so that the oracle and the HIP engine can
+replay the same eps / permutations.  Outputs are small ``.npz`` files committed next to
+this script; nothing from the reference's sources is copied.
+"""
+import os
+import sys
+import types
+import logging
+from collections import defaultdict, OrderedDict
+
+import numpy as np
+import torch
+
+REF = os.environ.get("DVAE_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+HP = dict(rec_dist="bernoulli", reg_anneal=10000, betaH_B=4, betaB_initC=0, betaB_finC=25,
+          betaB_G=1000, factor_G=6.4, latent_dim=10, lr_disc=1e-4, btcvae_A=1, btcvae_B=6.4,
+          btcvae_G=1)
+
+
+def import_reference():
+    sys.modules.setdefault("imageio", types.ModuleType("imageio"))
+    if not hasattr(np, "product"):
+        np.product = np.prod
+    sys.path.insert(0, REF)
+    import disvae  # noqa
+    from disvae.models import losses, vae, discriminator
+    from disvae.utils import math as dmath
+    from disvae import training
+    return disvae, losses, vae, discriminator, dmath, training
+
+
+class NoiseRecorder:
+    """Wrap torch.randn_like / torch.randperm, keep what the reference drew."""
+
+    def __enter__(self):
+        self.randn, self.perm = [], []
+        self._rl, self._rp = torch.randn_like, torch.randperm
+
+        def randn_like(t, *a, **k):
+            out = self._rl(t, *a, **k)
+            self.randn.append(out.detach().clone())
+            return out
+
+        def randperm(n, *a, **k):
+            out = self._rp(n, *a, **k)
+            self.perm.append(out.detach().clone())
+            return out
+
+        torch.randn_like, torch.randperm = randn_like, randperm
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like, torch.randperm = self._rl, self._rp
+
+
+def tensor_digest(t, n_samples=24):
+    """sum, abs-sum, and a few deterministic sample entries of a tensor."""
+    f = t.detach().double().flatten()
+    idx = torch.linspace(0, f.numel() - 1, min(n_samples, f.numel())).long()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item()], f[idx].numpy()])
+
+
+def kats(losses, dmath):
+    """RNG-free known-answer vectors."""
+    out = {}
+    i = torch.arange(12, dtype=torch.float32).view(4, 3)
+    mu, logvar, eps = torch.sin(i), 0.5 * torch.cos(i), torch.cos(2 * i + 1)
+    z = mu + torch.exp(0.5 * logvar) * eps
+    for mss in (True, False):
+        r = losses._get_log_pz_qz_prodzi_qzCx(z, (mu, logvar), 100, is_mss=mss)
+        for nm, v in zip(["log_pz", "log_qz", "log_prod_qzi", "log_q_zCx"], r):
+            out["kat_%s_mss%d" % (nm, mss)] = v.numpy()
+    out["kat_kl"] = losses._kl_normal_loss(mu, logvar).numpy()
+    x = (torch.arange(32).view(2, 1, 4, 4) % 5).float() / 4
+    r = torch.sigmoid(torch.sin(torch.arange(32).float())).view(2, 1, 4, 4)
+    for d in ["bernoulli", "gaussian", "laplace"]:
+        out["kat_rec_" + d] = losses._reconstruction_loss(x, r, distribution=d).numpy()
+    lf = losses.BtcvaeLoss(100, alpha=1, beta=6.4, gamma=1, steps_anneal=10000)
+    st = defaultdict(list)
+    loss = lf(x, r, (mu[:2], logvar[:2]), True, st, latent_sample=z[:2])
+    out["kat_btcvae_loss"] = loss.numpy()
+    for k in ["mi_loss", "tc_loss", "dw_kl_loss", "kl_loss"]:
+        out["kat_btcvae_" + k] = np.float32(st[k][0])
+    out["kat_anneal_a"] = np.float64(losses.linear_annealing(0, 1, 1, 10000))
+    out["kat_anneal_b"] = np.float64(losses.linear_annealing(0, 25, 5000, 100000))
+    for (b, n) in [(4, 100), (8, 737280), (64, 202599)]:
+        out["kat_logiw_%d_%d" % (b, n)] = dmath.log_importance_weight_matrix(b, n).numpy()
+    return out
+
+
+def run_case(ref, loss_name, img_size, batch, n_steps, seed, n_data, lr, rec_dist="bernoulli"):
+    """Run the reference Trainer._train_iteration n_steps times; record everything."""
+    disvae, losses, vae, discriminator, dmath, training = ref
+    torch.manual_seed(seed)
+    model = vae.init_specific_model("Burgess", img_size, 10)
+    init_state = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    kw = dict(HP)
+    kw["rec_dist"] = rec_dist
+    loss_f = losses.get_loss_f(loss_name, n_data=n_data, device=torch.device("cpu"), **kw)
+    init_dstate = None
+    if loss_name == "factor":
+        init_dstate = OrderedDict((k, v.detach().clone()) for k, v in loss_f.discriminator.state_dict().items())
+    logging.disable(logging.CRITICAL)
+    tr = training.Trainer(model, opt, loss_f, device=torch.device("cpu"), save_dir="/tmp",
+                          is_progress_bar=False)
+    model.train()
+    gen = torch.Generator().manual_seed(seed + 1)
+    out = {}
+    out["seed"] = np.int64(seed)
+    out["n_data"] = np.int64(n_data)
+    out["lr"] = np.float64(lr)
+    for k, v in init_state.items():
+        out["init_digest/" + k] = tensor_digest(v)
+    if init_dstate is not None:
+        for k, v in init_dstate.items():
+            out["dinit_digest/" + k] = tensor_digest(v)
+    for step in range(n_steps):
+        data = torch.rand((batch,) + tuple(img_size), generator=gen)
+        storer = defaultdict(list)
+        with NoiseRecorder() as rec:
+            loss_val = tr._train_iteration(data, storer)
+        out["step%d/loss" % step] = np.float64(loss_val)
+        for k, v in storer.items():
+            out["step%d/storer/%s" % (step, k)] = np.float64(v[0])
+        for j, e in enumerate(rec.randn):
+            out["step%d/randn%d" % (step, j)] = e.numpy()
+        if rec.perm:
+            out["step%d/perms" % step] = torch.stack(rec.perm).numpy()
+        for k, p in model.named_parameters():
+            out["step%d/grad_digest/%s" % (step, k)] = tensor_digest(p.grad)
+            out["step%d/param_digest/%s" % (step, k)] = tensor_digest(p)
+        if loss_name == "factor":
+            for k, p in loss_f.discriminator.named_parameters():
+                out["step%d/dgrad_digest/%s" % (step, k)] = tensor_digest(p.grad)
+                out["step%d/dparam_digest/%s" % (step, k)] = tensor_digest(p)
+    # full small tensors for the last forward (eval-mode forward on the last batch)
+    model.eval()
+    with torch.no_grad():
+        recon, (mu, logvar), z = model(data)
+    out["eval/mu"] = mu.numpy()
+    out["eval/logvar"] = logvar.numpy()
+    out["eval/recon_digest"] = tensor_digest(recon, 64)
+    return out
+
+
+def main():
+    ref = import_reference()
+    _, losses, vae, discriminator, dmath, training = ref
+    np.savez_compressed(os.path.join(HERE, "kats.npz"), **kats(losses, dmath))
+    cases = [
+        # name,           loss,     img_size,    B, steps, seed, n_data,  lr
+        ("vae_mnist",      "VAE",    (1, 32, 32), 8, 2, 1234, 60000, 5e-4),
+        ("betaB_mnist",    "betaB",  (1, 32, 32), 8, 2, 1234, 60000, 5e-4),
+        ("btcvae_dsprites", "btcvae", (1, 64, 64), 8, 3, 1234, 737280, 5e-4),
+        ("btcvae_celeba",  "btcvae", (3, 64, 64), 6, 2, 1234, 202599, 5e-4),
+        ("betaH_celeba",   "betaH",  (3, 64, 64), 4, 2, 1234, 202599, 5e-4),
+        ("factor_dsprites", "factor", (1, 64, 64), 8, 2, 1234, 737280, 1e-4),
+        ("factor_celeba",  "factor", (3, 64, 64), 8, 2, 1234, 202599, 1e-4),
+    ]
+    for name, loss, img, b, steps, seed, n_data, lr in cases:
+        out = run_case(ref, loss, img, b, steps, seed, n_data, lr)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "loss", [out["step%d/loss" % s] for s in range(steps)])
+    # reconstruction-distribution variants (one step each)
+    for dist in ["gaussian", "laplace"]:
+        out = run_case(ref, "betaH", (1, 32, 32), 4, 1, 7, 60000, 5e-4, rec_dist=dist)
+        np.savez_compressed(os.path.join(HERE, "betaH_mnist_%s.npz" % dist), **out)
+        print(dist, out["step0/loss"])
+
+
+if __name__ == "__main__":
+    main()
