@@ -1,0 +1,189 @@
+"""Benchmark of the hot path: Trainer._train_iteration-equivalent steps (forward + loss +
+backward + Adam [+ RCCL all-reduce]) of the native HIP engine on synthetic 64x64x3 batches.
+
+    python bench.py --gpus N --steps K --warmup W           (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric / configs[3]): btcvae_celeba -- Burgess VAE, 64x64x3,
+btcvae loss (alpha 1, beta 6.4, gamma 1, n_data 202599, reg_anneal 10000), Adam lr 5e-4,
+B = 1024 images per GPU (weak scaling: global batch = 1024 x N, the B x B estimator runs over
+the GLOBAL batch).  `--loss factor` times the two-optimizer FactorVAE step instead
+(configs[4]: tensor of 2048 = 1024 + 1024 per GPU).
+
+One JSON line on rank 0:  value = images/s of the whole job (inputs resident in HBM),
+`roofline` = algorithmic FLOPs of the dominant kernel / its HIP-event-timed duration vs the
+157.3 TFLOP/s fp32 MFMA peak, `cpu_baseline` = the CPU oracle (port of the reference Trainer,
+torch CPU) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "disentangling-vae_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HP = dict(rec_dist="bernoulli", reg_anneal=10000, betaH_B=4, betaB_initC=0, betaB_finC=25, betaB_G=1000,
+          factor_G=6.4, latent_dim=10, btcvae_A=1, btcvae_B=6.4, btcvae_G=1)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_image_train(C):
+    """6 * MACs_fwd - 2 * MACs_conv1 (64x64xC)."""
+    conv = [524288 * C, 4194304, 1048576, 262144]
+    fc = 131072 + 65536 + 5120 + 2560 + 65536 + 131072
+    macs = 2 * sum(conv) + fc
+    return 6 * macs - 2 * conv[0]
+
+
+def dominant_kernel_roofline(B, device):
+    """HIP-event timing of the dominant kernel of the step (conv2 forward shape: the
+    32->32 channel, 32x32 -> 16x16 'down' MFMA kernel k_down32<16>, also used by the
+    convT2 dgrad) on the stream the engine launches on (torch's current stream)."""
+    from disvae_amd import _lib
+    from disvae_amd._lib import call, ptr
+    x = torch.rand(B, 32, 32, 32, device=device)
+    w = torch.rand(32, 32, 4, 4, device=device) - 0.5
+    b = torch.zeros(32, device=device)
+    y = torch.empty(B, 16, 16, 32, device=device)
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        call("dvae_conv4s2_fwd", ptr(x), _lib.NHWC, ptr(w), ptr(b), ptr(y), _lib.NHWC, B, 32, 32, 32, 32, _lib.ACT_RELU, s)
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        call("dvae_conv4s2_fwd", ptr(x), _lib.NHWC, ptr(w), ptr(b), ptr(y), _lib.NHWC, B, 32, 32, 32, 32, _lib.ACT_RELU, s)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * 4194304 * B              # algorithmic: 2 x MACs/img x images per launch
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_down32<16> (conv2 fwd / convT2 dgrad)", "achieved": round(achieved, 2),
+            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            "us_per_launch": round(ms * 1e3, 2), "traffic": None}
+
+
+def cpu_baseline(loss, img, B, iters=6, warm=2):
+    """CPU oracle (port of the reference Trainer iteration) on this box's host cores."""
+    from oracle import disvae_oracle as O
+    n = os.cpu_count() or 1
+    torch.set_num_threads(n)
+    torch.manual_seed(1234)
+    hp = dict(HP, n_data=202599, lr_disc=1e-5)
+    tr = O.OracleTrainer(loss, hp, img, 10, lr=5e-4 if loss != "factor" else 1e-4, lr_disc=1e-5,
+                         steps_anneal=HP["reg_anneal"])
+    data = torch.rand((B,) + tuple(img))
+    ts = []
+    for i in range(warm + iters):
+        t0 = time.perf_counter()
+        tr.train_iteration(data)
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[warm:])
+    med = ts[len(ts) // 2]
+    return {"value": round(B / med, 1), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (torch-CPU restatement of reference Trainer._train_iteration), %s 64x64x%d B=%d, "
+                      "median of %d iterations after %d warm-ups, %.0f ms/iter" % (loss, img[0], B, iters, warm, med * 1e3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--loss", default="btcvae", choices=["btcvae", "factor", "VAE", "betaH", "betaB"])
+    ap.add_argument("--batch", type=int, default=None, help="tensor handed to _train_iteration PER GPU")
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus > 1" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from disvae_amd.models.vae import init_specific_model
+    from disvae_amd.models.losses import get_loss_f
+    from disvae_amd.training import Trainer
+    from disvae_amd import parallel
+
+    img = (args.channels, 64, 64)
+    B = args.batch or (2048 if args.loss == "factor" else 1024)
+    lr = 1e-4 if args.loss == "factor" else 5e-4
+    torch.manual_seed(1234)
+    model = init_specific_model("Burgess", img, 10)
+    optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+    loss_f = get_loss_f(args.loss, n_data=202599, device=device, lr_disc=1e-5, **HP)
+    import logging
+    trainer = Trainer(model, optimizer, loss_f, device=device, logger=logging.getLogger("bench"),
+                      save_dir="/tmp/dvae_bench_%d" % rank, is_progress_bar=False)
+    model.train()
+    if world > 1:
+        parallel.init_process_group_from_env("nccl")
+        parallel.data_parallel(model, loss_f)
+    torch.manual_seed(1234 + rank)
+    data = torch.rand((B,) + img, device=device)        # synthetic, resident in HBM
+    storer = defaultdict(list)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer._train_iteration_async(data, storer)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer._train_iteration_async(data, storer)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    flops_img = flops_per_image_train(args.channels)
+    out = {
+        "metric": "images/sec (whole node) at 64x64x3, btcvae loss" if args.loss == "btcvae" else
+                  "images/sec (whole node) at 64x64x%d, %s loss" % (args.channels, args.loss),
+        "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s_celeba: Burgess VAE 64x64x%d, %s loss, z=10, B=%d per GPU (global %d), Adam lr %g, "
+                               "n_data=202599, fwd+loss+bwd+Adam%s" % (args.loss, args.channels, args.loss, B, B * world, lr,
+                                                                      "+RCCL all-reduce" if world > 1 else ""),
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "final_loss": round(final_loss, 4)},
+        "step_tflops": round(flops_img * B * world / (ms * 1e-3) / 1e12, 2) if args.loss != "factor" else None,
+        "step_frac_of_fp32_peak": round(flops_img * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        if args.loss != "factor" else None,
+    }
+    if not args.no_roofline:
+        out["roofline"] = dominant_kernel_roofline(B if args.loss != "factor" else B // 2, device)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.loss, img, B)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

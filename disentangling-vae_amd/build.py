@@ -1,0 +1,53 @@
+"""Build libdvae_hip.so (gfx950) in-tree: hipcc cross-compiles without a GPU.
+
+    python disentangling-vae_amd/build.py [--force]
+
+The .so lands in disentangling-vae_amd/lib/ (git-ignored, but it travels with gpurun
+snapshots).  Objects are rebuilt only when a source / header is newer.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "lib", "libdvae_hip.so")
+HEADERS = [os.path.join(SRC, "common.h"), os.path.join(HERE, "..", "include", "dvae_hip.h")]
+SOURCES = ["conv_generic", "conv_mfma", "conv_thin", "linear", "loss", "capi"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(SRC, s + ".hip"), os.path.join(OBJ, s + ".o")
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in HEADERS):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        for err in ex.map(run, jobs):
+            if verbose and err.strip():
+                sys.stderr.write(err)
+    objs = [os.path.join(OBJ, s + ".o") for s in SOURCES]
+    if force or jobs or not os.path.exists(LIB):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,216 @@
+// extern "C" surface of libdvae_hip.so (see include/dvae_hip.h): argument checking and
+// dispatch between the tuned gfx950 kernels and the shape-generic HIP kernels.
+#include <stdarg.h>
+#include <stdlib.h>
+#include "common.h"
+
+namespace dvae {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+bool use_generic_only() {
+  const char* e = getenv("DVAE_FORCE_GENERIC");
+  return e && e[0] == '1';
+}
+
+static int check_layout(int l) { return l == DVAE_NCHW || l == DVAE_NHWC; }
+
+// big[N,Cb,2Hs,2Ws] -> small[N,Cs,Hs,Ws]
+static int run_down(const ConvArgs& a, hipStream_t s) {
+  if (!use_generic_only()) {
+    int r = launch_down_mfma32(a, s);
+    if (r <= 0) return r;
+    r = launch_down_thin(a, s);
+    if (r <= 0) return r;
+  }
+  return launch_down_generic(a, s);
+}
+static int run_up(const ConvArgs& a, hipStream_t s) {
+  if (!use_generic_only()) {
+    int r = launch_up_mfma32(a, s);
+    if (r <= 0) return r;
+    r = launch_up_thin(a, s);
+    if (r <= 0) return r;
+  }
+  return launch_up_generic(a, s);
+}
+static int run_wgrad(const float* big, int big_layout, const float* small, int small_layout, float* dw, float* db,
+                     int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws, float* ws, hipStream_t s) {
+  if (!use_generic_only() && ws != nullptr && Hs == Ws && Cs == 32 && small_layout == DVAE_NHWC) {
+    if (Cb == 32 && big_layout == DVAE_NHWC && (Hs == 4 || Hs == 8 || Hs == 16))
+      return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s);
+    if ((Cb == 1 || Cb == 3) && Hs == 32 && big_layout == DVAE_NCHW)
+      return launch_wgrad_thin(big, small, dw, db, bias_from_big, N, Cb, Hs, ws, s);
+  }
+  return launch_wgrad_generic(big, big_layout, small, small_layout, dw, db, bias_from_big, N, Cb, Cs, Hs, Ws, s);
+}
+
+}  // namespace dvae
+
+using namespace dvae;
+
+extern "C" {
+
+int dvae_version(void) { return DVAE_VERSION; }
+const char* dvae_last_error(void) { return g_err; }
+
+int dvae_conv4s2_fwd(const float* x, int x_layout, const float* w, const float* b, float* y, int y_layout, int N,
+                     int Cin, int H, int W, int Cout, int act, void* stream) {
+  DVAE_CHECK_ARG(x && w && y && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (H % 2 == 0) && (W % 2 == 0));
+  DVAE_CHECK_ARG(check_layout(x_layout) && check_layout(y_layout));
+  ConvArgs a{x, x_layout, nullptr, 0, w, b, nullptr, y, y_layout, N, Cin, Cout, H / 2, W / 2, act};
+  return run_down(a, (hipStream_t)stream);
+}
+
+int dvae_conv4s2_dgrad(const float* dy, int dy_layout, const float* w, const float* x_act, float* dx, int dx_layout,
+                       int N, int Cin, int H, int W, int Cout, void* stream) {
+  DVAE_CHECK_ARG(dy && w && dx && N > 0 && Cin > 0 && Cout > 0 && (H % 2 == 0) && (W % 2 == 0));
+  DVAE_CHECK_ARG(check_layout(dy_layout) && check_layout(dx_layout));
+  // conv weight w[Cout,Cin,4,4] = w[cs][cb]: small = dy (Cout channels), big = dx (Cin channels)
+  ConvArgs a{nullptr, 0, dy, dy_layout, w, nullptr, x_act, dx, dx_layout, N, Cin, Cout, H / 2, W / 2, DVAE_ACT_NONE};
+  return run_up(a, (hipStream_t)stream);
+}
+
+int dvae_conv4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_layout, float* dw, float* db, int N,
+                       int Cin, int H, int W, int Cout, float* ws, void* stream) {
+  DVAE_CHECK_ARG(x && dy && dw && N > 0 && (H % 2 == 0) && (W % 2 == 0));
+  return run_wgrad(x, x_layout, dy, dy_layout, dw, db, /*bias_from_big=*/0, N, Cin, Cout, H / 2, W / 2, ws,
+                   (hipStream_t)stream);
+}
+
+int dvae_convT4s2_fwd(const float* x, int x_layout, const float* w, const float* b, float* y, int y_layout, int N,
+                      int Cin, int H, int W, int Cout, int act, void* stream) {
+  DVAE_CHECK_ARG(x && w && y && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
+  DVAE_CHECK_ARG(check_layout(x_layout) && check_layout(y_layout));
+  // convT weight w[Cin,Cout,4,4] = w[cs][cb]: small = x (Cin channels), big = y (Cout channels)
+  ConvArgs a{nullptr, 0, x, x_layout, w, b, nullptr, y, y_layout, N, Cout, Cin, H, W, act};
+  return run_up(a, (hipStream_t)stream);
+}
+
+int dvae_convT4s2_dgrad(const float* dy, int dy_layout, const float* w, const float* x_act, float* dx, int dx_layout,
+                        int N, int Cin, int H, int W, int Cout, void* stream) {
+  DVAE_CHECK_ARG(dy && w && dx && N > 0 && Cin > 0 && Cout > 0);
+  DVAE_CHECK_ARG(check_layout(dy_layout) && check_layout(dx_layout));
+  ConvArgs a{dy, dy_layout, nullptr, 0, w, nullptr, x_act, dx, dx_layout, N, Cout, Cin, H, W, DVAE_ACT_NONE};
+  return run_down(a, (hipStream_t)stream);
+}
+
+int dvae_convT4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_layout, float* dw, float* db, int N,
+                        int Cin, int H, int W, int Cout, float* ws, void* stream) {
+  DVAE_CHECK_ARG(x && dy && dw && N > 0);
+  return run_wgrad(dy, dy_layout, x, x_layout, dw, db, /*bias_from_big=*/1, N, Cout, Cin, H, W, ws,
+                   (hipStream_t)stream);
+}
+
+size_t dvae_conv_wgrad_ws_floats(void) {
+  size_t a = wgrad32_ws_floats(), b = wgrad_thin_ws_floats();
+  return a > b ? a : b;
+}
+
+int dvae_relayout(const float* src, int src_layout, float* dst, int N, int C, int H, int W, void* stream) {
+  DVAE_CHECK_ARG(src && dst && check_layout(src_layout) && N > 0 && C > 0 && H > 0 && W > 0);
+  return launch_relayout(src, src_layout, dst, N, C, H, W, (hipStream_t)stream);
+}
+
+int dvae_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act,
+                    void* stream) {
+  DVAE_CHECK_ARG(x && w && y && M > 0 && K > 0 && N > 0);
+  DVAE_CHECK_ARG(act == DVAE_ACT_NONE || act == DVAE_ACT_RELU || act == DVAE_ACT_LEAKY02);
+  return launch_linear_fwd(x, w, b, y, M, K, N, act, (hipStream_t)stream);
+}
+
+int dvae_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
+                      void* stream) {
+  DVAE_CHECK_ARG(dy && w && dx && M > 0 && K > 0 && N > 0);
+  return launch_linear_dgrad(dy, w, x_act, act, dx, M, K, N, (hipStream_t)stream);
+}
+
+int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, void* stream) {
+  DVAE_CHECK_ARG(x && dy && dw && M > 0 && K > 0 && N > 0);
+  return launch_linear_wgrad(x, dy, dw, db, M, K, N, (hipStream_t)stream);
+}
+
+int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
+                        const float* coef, int B, int D, void* stream) {
+  DVAE_CHECK_ARG(ml && mu && logvar && z && B > 0 && D > 0 && D <= 16 && (kl_dim == nullptr || coef != nullptr));
+  return launch_reparam_kl_fwd(ml, eps, mu, logvar, z, kl_dim, coef, B, D, (hipStream_t)stream);
+}
+
+int dvae_reparam_kl_bwd(const float* dz, const float* dmu_x, const float* dlv_x, const float* mu, const float* logvar,
+                        const float* eps, const float* scal, const float* coef, float* dml, int B, int D,
+                        void* stream) {
+  DVAE_CHECK_ARG(mu && logvar && scal && coef && dml && B > 0 && D > 0);
+  return launch_reparam_kl_bwd(dz, dmu_x, dlv_x, mu, logvar, eps, scal, coef, dml, B, D, (hipStream_t)stream);
+}
+
+int dvae_recon_loss(const float* recon, const float* target, long n, int dist, const float* coef, float* partials,
+                    float* g, int wrt_logit, void* stream) {
+  DVAE_CHECK_ARG(recon && target && coef && partials && n > 0 && (n % 4 == 0));
+  DVAE_CHECK_ARG(dist == DVAE_REC_BERNOULLI || dist == DVAE_REC_GAUSSIAN || dist == DVAE_REC_LAPLACE);
+  return launch_recon_loss(recon, target, n, dist, coef, partials, g, wrt_logit, (hipStream_t)stream);
+}
+
+int dvae_sigmoid_bwd(const float* grad_y, const float* y, float* out, long n, void* stream) {
+  DVAE_CHECK_ARG(grad_y && y && out && n > 0);
+  return launch_sigmoid_bwd(grad_y, y, out, n, (hipStream_t)stream);
+}
+
+int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg, int D, int row0, int Bl, int is_mss,
+                    const float* log_w, float* rowstats, void* stream) {
+  DVAE_CHECK_ARG(z && mu && logvar && rowstats && Bg > 1 && D == 10 && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg);
+  DVAE_CHECK_ARG(!is_mss || log_w);
+  return launch_btcvae_fwd(z, mu, logvar, Bg, D, row0, Bl, is_mss, log_w, rowstats, (hipStream_t)stream);
+}
+
+int dvae_btcvae_bwd(const float* z, const float* mu, const float* logvar, const float* rowstats, int Bg, int D,
+                    int row0, int Bl, int is_mss, const float* log_w, const float* coef, float* dz, float* dmu_all,
+                    float* dlv_all, void* stream) {
+  DVAE_CHECK_ARG(z && mu && logvar && rowstats && coef && dz && dmu_all && dlv_all && Bg > 1 && D == 10);
+  DVAE_CHECK_ARG(row0 >= 0 && Bl > 0 && row0 + Bl <= Bg && (!is_mss || log_w));
+  return launch_btcvae_bwd(z, mu, logvar, rowstats, Bg, D, row0, Bl, is_mss, log_w, coef, dz, dmu_all, dlv_all,
+                           (hipStream_t)stream);
+}
+
+int dvae_permute_dims(const float* z, const int64_t* perm, float* out, int B, int D, void* stream) {
+  DVAE_CHECK_ARG(z && perm && out && B > 0 && D > 0);
+  return launch_permute_dims(z, perm, out, B, D, (hipStream_t)stream);
+}
+
+int dvae_disc_losses(const float* dlogits, int Bh, const float* coef, float* sums, float* g_dtc, float* g_tc,
+                     void* stream) {
+  DVAE_CHECK_ARG(dlogits && coef && sums && g_dtc && Bh > 0);
+  return launch_disc_losses(dlogits, Bh, coef, sums, g_dtc, g_tc, (hipStream_t)stream);
+}
+
+int dvae_loss_pack(const float* rec_partials, const float* kl_dim, int D, const float* rowstats, int Bl,
+                   const float* disc_sums, float* packed, void* stream) {
+  DVAE_CHECK_ARG(rec_partials && packed && D >= 0 && D <= 16);
+  return launch_loss_pack(rec_partials, kl_dim, D, rowstats, Bl, disc_sums, packed, (hipStream_t)stream);
+}
+
+int dvae_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal, void* stream) {
+  DVAE_CHECK_ARG(packed && coef && scal && D >= 0 && D <= 16 && Bg > 0);
+  DVAE_CHECK_ARG(kind >= DVAE_LOSS_BETAH && kind <= DVAE_LOSS_FACTOR);
+  return launch_loss_finalize(kind, packed, D, Bg, coef, scal, (hipStream_t)stream);
+}
+
+int dvae_set_coef(float* coef, float c0, float c1, float c2, float c3, float c4, float c5, float c6, float c7,
+                  void* stream) {
+  DVAE_CHECK_ARG(coef);
+  const float v[8] = {c0, c1, c2, c3, c4, c5, c6, c7};
+  return launch_set_coef(coef, v, (hipStream_t)stream);
+}
+
+int dvae_add(const float* a, const float* b, float* out, long n, void* stream) {
+  DVAE_CHECK_ARG(a && b && out && n > 0);
+  return launch_add(a, b, out, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Shared helpers for the gfx950 kernels of libdvae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/dvae_hip.h"
+
+namespace dvae {
+
+void set_error(const char* fmt, ...);
+
+#define DVAE_CHECK_ARG(cond)                                                            \
+  do {                                                                                  \
+    if (!(cond)) {                                                                      \
+      dvae::set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, #cond);        \
+      return -1;                                                                        \
+    }                                                                                   \
+  } while (0)
+
+#define DVAE_CHECK_LAUNCH()                                                             \
+  do {                                                                                  \
+    hipError_t e__ = hipGetLastError();                                                 \
+    if (e__ != hipSuccess) {                                                            \
+      dvae::set_error("%s:%d: launch failed: %s", __FILE__, __LINE__,                   \
+                      hipGetErrorString(e__));                                          \
+      return -2;                                                                        \
+    }                                                                                   \
+  } while (0)
+
+// element strides of a [N,C,H,W] tensor stored as NCHW or NHWC
+struct Strides {
+  long n, c, h, w;
+};
+static inline Strides make_strides(int layout, int C, int H, int W) {
+  Strides s;
+  if (layout == DVAE_NHWC) {
+    s.n = (long)H * W * C; s.h = (long)W * C; s.w = C; s.c = 1;
+  } else {
+    s.n = (long)C * H * W; s.c = (long)H * W; s.h = W; s.w = 1;
+  }
+  return s;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- launchers implemented in the individual .hip files ---------------------------------
+// "down": big[N,Cb,2Hs,2Ws] -> small[N,Cs,Hs,Ws]  (Conv2d fwd, ConvTranspose2d dgrad)
+// "up"  : small -> big                           (ConvTranspose2d fwd, Conv2d dgrad)
+// "wg"  : dw[Cs,Cb,4,4] = sum small (*) big       (both wgrads)
+// weights are always indexed w[cs][cb][kh][kw].
+struct ConvArgs {
+  const float* big; int big_layout;
+  const float* small; int small_layout;
+  const float* w; const float* bias; const float* mask;
+  float* out; int out_layout;
+  int N, Cb, Cs, Hs, Ws;  // Hs,Ws: SMALL spatial dims (big is 2Hs x 2Ws)
+  int act;
+};
+int launch_down_generic(const ConvArgs& a, hipStream_t s);
+int launch_up_generic(const ConvArgs& a, hipStream_t s);
+int launch_wgrad_generic(const float* big, int big_layout, const float* small, int small_layout,
+                         float* dw, float* db, int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws,
+                         hipStream_t s);
+// MFMA paths (32 <-> 32 channels, NHWC, Hs == Ws in {4,8,16}); return 1 if not applicable
+int launch_down_mfma32(const ConvArgs& a, hipStream_t s);
+int launch_up_mfma32(const ConvArgs& a, hipStream_t s);
+int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big,
+                        int N, int Hs, float* ws, hipStream_t s);
+// thin paths (Cb in {1,3}, Cs == 32, big NCHW 64x64 / small NHWC 32x32)
+int launch_down_thin(const ConvArgs& a, hipStream_t s);
+int launch_up_thin(const ConvArgs& a, hipStream_t s);
+int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big,
+                      int N, int Cb, int Hs, float* ws, hipStream_t s);
+
+size_t wgrad32_ws_floats();
+size_t wgrad_thin_ws_floats();
+int launch_relayout(const float* src, int src_layout, float* dst, int N, int C, int H, int W, hipStream_t s);
+
+int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act,
+                      hipStream_t s);
+int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
+                        hipStream_t s);
+int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, hipStream_t s);
+
+int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
+                          const float* coef, int B, int D, hipStream_t s);
+int launch_reparam_kl_bwd(const float* dz, const float* dmu_x, const float* dlv_x, const float* mu, const float* logvar,
+                          const float* eps, const float* scal, const float* coef, float* dml, int B, int D,
+                          hipStream_t s);
+int launch_recon_loss(const float* recon, const float* target, long n, int dist, const float* coef, float* partials,
+                      float* g, int wrt_logit, hipStream_t s);
+int launch_sigmoid_bwd(const float* gy, const float* y, float* out, long n, hipStream_t s);
+int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, int D, int row0, int Bl, int is_mss,
+                      const float* log_w, float* rowstats, hipStream_t s);
+int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const float* rowstats, int Bg, int D, int row0,
+                      int Bl, int is_mss, const float* log_w, const float* coef, float* dz, float* dmu, float* dlv,
+                      hipStream_t s);
+int launch_permute_dims(const float* z, const int64_t* perm, float* out, int B, int D, hipStream_t s);
+int launch_disc_losses(const float* lg, int Bh, const float* coef, float* sums, float* g_dtc, float* g_tc,
+                       hipStream_t s);
+int launch_loss_pack(const float* rec_partials, const float* kl_dim, int D, const float* rowstats, int Bl,
+                     const float* disc_sums, float* packed, hipStream_t s);
+int launch_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal, hipStream_t s);
+int launch_set_coef(float* coef, const float* v, hipStream_t s);
+int launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);
+
+bool use_generic_only();  // DVAE_FORCE_GENERIC=1 (debug / A-B reference path, still HIP)
+
+}  // namespace dvae

@@ -1,0 +1,483 @@
+// gfx950 MFMA kernels for the 32 <-> 32 channel k4/s2/p1 convolutions of the Burgess
+// encoder/decoder (conv2, conv3, conv_64, convT_64, convT1, convT2 and all their dgrads and
+// wgrads: 18 of the 23 conv-shaped launches of a training step and ~75 % of its FLOPs).
+//
+// Formulation (all fp32, exact: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain):
+//   down  : small[p][cs] = sum_{tap,cb} big[pix(p,tap)][cb] * w[cs][cb][tap]   M = 32 pixels, N = 32 cs, K = 512
+//   up    : big[p'][cb]  = sum_{tap in class,cs} small[nb(p',tap)][cs] * w[cs][cb][tap]   4 parity classes, K = 128
+//   wgrad : dw[cs][cb][tap] = sum_p small[p][cs] * big[pix(p,tap)][cb]           M = 32 cs, N = 32 cb, K = pixels
+// Activations are NHWC (a pixel's 32 channels = one 128-byte line), so the MFMA A operand of
+// down/up is read from LDS as one ds_read_b128 per 4 MFMAs (k order inside a tap is permuted
+// so that lanes 0-31 / 32-63 take channels 8q+j / 8q+4+j) and the D fragment stores whole
+// 128-byte pixel lines.  A workgroup (8 waves, one per CU: 64 KB of re-laid-out weights live
+// in LDS) is persistent over "units" of 64 small pixels; the next unit's activation tile is
+// prefetched into registers while the current one is in the MFMA loop.
+// The big-side tile is stored in LDS split by column parity ([row][par][col/2][32ch]) with the
+// 16-byte channel chunks XOR-swizzled, so that the stride-2 im2col reads of a lane group fall
+// on distinct banks.
+#include "common.h"
+
+namespace dvae {
+
+template <int HS>
+struct Geo {
+  static constexpr int HB = 2 * HS;
+  static constexpr int U = 64;                                        // small pixels per unit
+  static constexpr int IMGS = (HS * HS >= U) ? 1 : U / (HS * HS);      // images per unit
+  static constexpr int R = (HS * HS >= U) ? U / HS : HS;              // small rows per image per unit
+  static constexpr int BROWS = 2 * R + 2;                             // big rows (with halo) per image
+  static constexpr int CW = HS + 1;                                   // column pairs per parity
+  static constexpr int BPC = 2 * HS + 2;                              // padded big columns
+  static constexpr int BIG_FLOATS = IMGS * BROWS * 2 * CW * 32;
+  static constexpr int BIG_SLOTS = IMGS * BROWS * BPC * 8;            // 16-byte slots to stage
+  static constexpr int BIG_NPF = (BIG_SLOTS + 511) / 512;
+  static constexpr int SROWS = R + 2, SCOLS = HS + 2;                 // small tile with halo
+  static constexpr int SH_FLOATS = IMGS * SROWS * SCOLS * 32;
+  static constexpr int SH_SLOTS = IMGS * SROWS * SCOLS * 8;
+  static constexpr int SH_NPF = (SH_SLOTS + 511) / 512;
+};
+
+template <int HS> __device__ __forceinline__ int swz_big(int r, int cw);
+template <> __device__ __forceinline__ int swz_big<16>(int r, int cw) { return (cw >> 1) & 7; }
+template <> __device__ __forceinline__ int swz_big<8>(int r, int cw) { return ((cw >> 1) & 3) | (((r >> 1) & 1) << 2); }
+template <> __device__ __forceinline__ int swz_big<4>(int r, int cw) { return ((cw >> 1) & 1) | (((r >> 1) & 3) << 1); }
+template <int HS> __device__ __forceinline__ int swz_small(int row, int col);
+template <> __device__ __forceinline__ int swz_small<16>(int row, int col) { return (col >> 1) & 7; }
+template <> __device__ __forceinline__ int swz_small<8>(int row, int col) { return ((col >> 1) & 3) | ((row & 1) << 2); }
+template <> __device__ __forceinline__ int swz_small<4>(int row, int col) { return ((col >> 1) & 1) | ((row & 3) << 1); }
+
+// ---- staging helpers ----------------------------------------------------------------------
+template <int HS>
+__device__ __forceinline__ void load_big(f32x4 (&pf)[Geo<HS>::BIG_NPF], const float* __restrict__ big, int unit,
+                                         int N, int tid) {
+  using G = Geo<HS>;
+  const long P0 = (long)unit * G::U;
+  const int n0 = (int)(P0 / (HS * HS));
+  const int sy0 = (int)(P0 % (HS * HS)) / HS;
+#pragma unroll
+  for (int k = 0; k < G::BIG_NPF; ++k) {
+    int s = tid + k * 512;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s < G::BIG_SLOTS) {
+      int chunk = s & 7;
+      int t = s >> 3;
+      int pc = t % G::BPC; t /= G::BPC;
+      int r = t % G::BROWS;
+      int img = t / G::BROWS;
+      int n = n0 + img, by = 2 * sy0 - 1 + r, bx = pc - 1;
+      if (n < N && by >= 0 && by < G::HB && bx >= 0 && bx < G::HB)
+        v = *reinterpret_cast<const f32x4*>(big + (((long)n * G::HB + by) * G::HB + bx) * 32 + chunk * 4);
+    }
+    pf[k] = v;
+  }
+}
+
+template <int HS>
+__device__ __forceinline__ void store_big(const f32x4 (&pf)[Geo<HS>::BIG_NPF], float* bt, int tid) {
+  using G = Geo<HS>;
+#pragma unroll
+  for (int k = 0; k < G::BIG_NPF; ++k) {
+    int s = tid + k * 512;
+    if (s < G::BIG_SLOTS) {
+      int chunk = s & 7;
+      int t = s >> 3;
+      int pc = t % G::BPC; t /= G::BPC;
+      int r = t % G::BROWS;
+      int img = t / G::BROWS;
+      int par = pc & 1, cw = pc >> 1;
+      float* dst = bt + (((img * G::BROWS + r) * 2 + par) * G::CW + cw) * 32 + ((chunk ^ swz_big<HS>(r, cw)) << 2);
+      *reinterpret_cast<f32x4*>(dst) = pf[k];
+    }
+  }
+}
+
+template <int HS>
+__device__ __forceinline__ void load_small_halo(f32x4 (&pf)[Geo<HS>::SH_NPF], const float* __restrict__ small,
+                                                int unit, int N, int tid) {
+  using G = Geo<HS>;
+  const long P0 = (long)unit * G::U;
+  const int n0 = (int)(P0 / (HS * HS));
+  const int sy0 = (int)(P0 % (HS * HS)) / HS;
+#pragma unroll
+  for (int k = 0; k < G::SH_NPF; ++k) {
+    int s = tid + k * 512;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s < G::SH_SLOTS) {
+      int chunk = s & 7;
+      int t = s >> 3;
+      int col = t % G::SCOLS; t /= G::SCOLS;
+      int row = t % G::SROWS;
+      int img = t / G::SROWS;
+      int n = n0 + img, sy = sy0 - 1 + row, sx = col - 1;
+      if (n < N && sy >= 0 && sy < HS && sx >= 0 && sx < HS)
+        v = *reinterpret_cast<const f32x4*>(small + (((long)n * HS + sy) * HS + sx) * 32 + chunk * 4);
+    }
+    pf[k] = v;
+  }
+}
+
+template <int HS>
+__device__ __forceinline__ void store_small_halo(const f32x4 (&pf)[Geo<HS>::SH_NPF], float* st, int tid) {
+  using G = Geo<HS>;
+#pragma unroll
+  for (int k = 0; k < G::SH_NPF; ++k) {
+    int s = tid + k * 512;
+    if (s < G::SH_SLOTS) {
+      int chunk = s & 7;
+      int t = s >> 3;
+      int col = t % G::SCOLS; t /= G::SCOLS;
+      int row = t % G::SROWS;
+      int img = t / G::SROWS;
+      float* dst = st + ((img * G::SROWS + row) * G::SCOLS + col) * 32 + ((chunk ^ swz_small<HS>(row, col)) << 2);
+      *reinterpret_cast<f32x4*>(dst) = pf[k];
+    }
+  }
+}
+
+// weights w[cs][cb][16] -> LDS image wl[tap][kc/4][n][kc%4] where kc is the contracted channel
+// and n the output channel.  KC_IS_CB: down (contract over cb, n = cs); else up (contract cs).
+template <bool KC_IS_CB>
+__device__ __forceinline__ void stage_weights(const float* __restrict__ w, float* wl, int tid) {
+  for (int idx = tid; idx < 16384; idx += 512) {
+    int cs = idx >> 9, cb = (idx >> 4) & 31, tap = idx & 15;
+    int kc = KC_IS_CB ? cb : cs;
+    int n = KC_IS_CB ? cs : cb;
+    wl[((tap * 8 + (kc >> 2)) * 32 + n) * 4 + (kc & 3)] = w[idx];
+  }
+}
+
+__device__ __forceinline__ float epilogue_act(float v, int act) {
+  if (act == DVAE_ACT_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+
+#define MFMA4(acc, a, b)                                                       \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a)[0], (b)[0], acc, 0, 0, 0);    \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a)[1], (b)[1], acc, 0, 0, 0);    \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a)[2], (b)[2], acc, 0, 0, 0);    \
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a)[3], (b)[3], acc, 0, 0, 0);
+
+// ---- down: big -> small ------------------------------------------------------------------
+template <int HS>
+__global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, const float* __restrict__ w,
+                                                const float* __restrict__ bias, const float* __restrict__ mask,
+                                                float* __restrict__ out, int N, int act, int n_units) {
+  using G = Geo<HS>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                    // 16384 floats
+  float* bt = smem + 16384;            // G::BIG_FLOATS
+  float* red = bt + G::BIG_FLOATS;     // 2 * 3 * 16 * 64 floats
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int mt = wv & 1, kh = wv >> 1;
+  const int i = lane & 31, h = lane >> 5;
+  const int p = mt * 32 + i;
+  const int img_l = p / (G::R * HS), sy_l = (p / HS) % G::R, sx = p % HS;
+  const int r = 2 * sy_l + kh;
+
+  f32x4 pf[G::BIG_NPF];
+  int unit = blockIdx.x;
+  if (unit < n_units) load_big<HS>(pf, big, unit, N, tid);
+  stage_weights<true>(w, wl, tid);
+  const float bv = bias ? bias[i] : 0.f;
+
+  for (; unit < n_units; unit += gridDim.x) {
+    store_big<HS>(pf, bt, tid);
+    __syncthreads();
+    if (unit + (int)gridDim.x < n_units) load_big<HS>(pf, big, unit + gridDim.x, N, tid);
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw) {
+      const int par = kw & 1, cw = sx + (kw >> 1);
+      const float* arow = bt + (((img_l * G::BROWS + r) * 2 + par) * G::CW + cw) * 32;
+      const int sw = swz_big<HS>(r, cw);
+      const float* brow = wl + ((kh * 4 + kw) * 8) * 128 + i * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int chunk = 2 * q + h;
+        f32x4 a = *reinterpret_cast<const f32x4*>(arow + ((chunk ^ sw) << 2));
+        f32x4 b = *reinterpret_cast<const f32x4*>(brow + chunk * 128);
+        MFMA4(acc, a, b)
+      }
+    }
+    // reduce the 4 kh-slices of each M-tile through LDS
+    if (kh > 0) {
+      float* dst = red + ((mt * 3 + kh - 1) * 16) * 64 + lane;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dst[e * 64] = acc[e];
+    }
+    __syncthreads();
+    if (kh == 0) {
+      const long P0 = (long)unit * G::U + mt * 32;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc[e];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) v += red[((mt * 3 + s) * 16 + e) * 64 + lane];
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const long pix = P0 + row;
+        if (pix < (long)N * HS * HS) {
+          const long o = pix * 32 + i;
+          v = epilogue_act(v + bv, act);
+          if (mask) v = mask[o] > 0.f ? v : 0.f;
+          out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- up: small -> big --------------------------------------------------------------------
+template <int HS>
+__global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, const float* __restrict__ w,
+                                              const float* __restrict__ bias, const float* __restrict__ mask,
+                                              float* __restrict__ out, int N, int act, int n_units) {
+  using G = Geo<HS>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;              // 16384 floats
+  float* st = smem + 16384;      // G::SH_FLOATS
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cls = wv & 3, mt = wv >> 2;
+  const int py = cls >> 1, px = cls & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const int p = mt * 32 + i;
+  const int img_l = p / (G::R * HS), m = (p / HS) % G::R, l = p % HS;
+
+  f32x4 pf[G::SH_NPF];
+  int unit = blockIdx.x;
+  if (unit < n_units) load_small_halo<HS>(pf, small, unit, N, tid);
+  stage_weights<false>(w, wl, tid);
+  const float bv = bias ? bias[i] : 0.f;
+
+  for (; unit < n_units; unit += gridDim.x) {
+    __syncthreads();  // previous unit's reads of st are complete
+    store_small_halo<HS>(pf, st, tid);
+    __syncthreads();
+    if (unit + (int)gridDim.x < n_units) load_small_halo<HS>(pf, small, unit + gridDim.x, N, tid);
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) {
+      const int kh = 1 - py + 2 * ty;
+      const int row = m + (py - ty) + 1;
+#pragma unroll
+      for (int tx = 0; tx < 2; ++tx) {
+        const int kw = 1 - px + 2 * tx;
+        const int col = l + (px - tx) + 1;
+        const float* arow = st + ((img_l * G::SROWS + row) * G::SCOLS + col) * 32;
+        const int sw = swz_small<HS>(row, col);
+        const float* brow = wl + ((kh * 4 + kw) * 8) * 128 + i * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int chunk = 2 * q + h;
+          f32x4 a = *reinterpret_cast<const f32x4*>(arow + ((chunk ^ sw) << 2));
+          f32x4 b = *reinterpret_cast<const f32x4*>(brow + chunk * 128);
+          MFMA4(acc, a, b)
+        }
+      }
+    }
+    const long P0 = (long)unit * G::U;
+    const int n0 = (int)(P0 / (HS * HS));
+    const int sy0 = (int)(P0 % (HS * HS)) / HS;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rowp = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int pp = mt * 32 + rowp;
+      const int im = pp / (G::R * HS), mm = (pp / HS) % G::R, ll = pp % HS;
+      const int n = n0 + im;
+      if (n < N) {
+        const int by = 2 * (sy0 + mm) + py, bx = 2 * ll + px;
+        const long o = (((long)n * G::HB + by) * G::HB + bx) * 32 + i;
+        float v = epilogue_act(acc[e] + bv, act);
+        if (mask) v = mask[o] > 0.f ? v : 0.f;
+        out[o] = v;
+      }
+    }
+  }
+}
+
+// ---- wgrad ---------------------------------------------------------------------------------
+#define WG_MAX_BLOCKS 256
+template <int HS>
+__global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, const float* __restrict__ small,
+                                                 float* __restrict__ ws, int N, int n_units) {
+  using G = Geo<HS>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* bt = smem;                     // G::BIG_FLOATS
+  float* sp = smem + G::BIG_FLOATS;     // 64 * 32
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int kh = wv >> 1, kwb = wv & 1;  // taps (kh, 2*kwb) and (kh, 2*kwb+1)
+  const int i = lane & 31, h = lane >> 5;
+
+  f32x4 pf[G::BIG_NPF];
+  f32x4 pfs;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+  float sumS = 0.f, sumB0 = 0.f, sumB1 = 0.f;
+
+  int unit = blockIdx.x;
+  const long npix = (long)N * HS * HS;
+  auto load_sp = [&](int u) {
+    long e0 = (long)u * G::U * 32 + tid * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (e0 < npix * 32) v = *reinterpret_cast<const f32x4*>(small + e0);
+    pfs = v;
+  };
+  if (unit < n_units) { load_big<HS>(pf, big, unit, N, tid); load_sp(unit); }
+
+  for (; unit < n_units; unit += gridDim.x) {
+    __syncthreads();
+    store_big<HS>(pf, bt, tid);
+    *reinterpret_cast<f32x4*>(sp + tid * 4) = pfs;
+    __syncthreads();
+    if (unit + (int)gridDim.x < n_units) { load_big<HS>(pf, big, unit + gridDim.x, N, tid); load_sp(unit + gridDim.x); }
+
+#pragma unroll 8
+    for (int t = 0; t < 32; ++t) {
+      const int p = 2 * t + h;
+      const int img_l = p / (G::R * HS), sy_l = (p / HS) % G::R, sx = p % HS;
+      const float a = sp[p * 32 + i];
+      const int r = 2 * sy_l + kh;
+      const int cw = sx + kwb;
+      const float* b0p = bt + (((img_l * G::BROWS + r) * 2 + 0) * G::CW + cw) * 32;
+      const int sw = swz_big<HS>(r, cw);
+      const int off = (((i >> 2) ^ sw) << 2) + (i & 3);
+      const float b0 = b0p[off];
+      const float b1 = b0p[G::CW * 32 + off];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+      sumS += a; sumB0 += b0; sumB1 += b1;
+    }
+  }
+  // partial results of this workgroup
+  float* wsw = ws + (long)blockIdx.x * 16384;
+  const int tap0 = kh * 4 + 2 * kwb;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int cs = (e & 3) + 8 * (e >> 2) + 4 * h;
+    wsw[(tap0 * 32 + cs) * 32 + i] = acc0[e];
+    wsw[((tap0 + 1) * 32 + cs) * 32 + i] = acc1[e];
+  }
+  float* wsb = ws + (long)WG_MAX_BLOCKS * 16384 + (long)blockIdx.x * 160;
+  sumS += __shfl_xor(sumS, 32, 64);
+  sumB0 += __shfl_xor(sumB0, 32, 64);
+  sumB1 += __shfl_xor(sumB1, 32, 64);
+  if (h == 0) {
+    if (wv == 0) wsb[i] = sumS;
+    // taps (1,1)=5 -> wave 2 second tap, (1,2)=6 -> wave 3 first, (2,1)=9 -> wave 4 second, (2,2)=10 -> wave 5 first
+    if (wv == 2) wsb[32 + i] = sumB1;
+    if (wv == 3) wsb[64 + i] = sumB0;
+    if (wv == 4) wsb[96 + i] = sumB1;
+    if (wv == 5) wsb[128 + i] = sumB0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict__ ws, float* __restrict__ dw,
+                                                        float* __restrict__ db, int bias_from_big, int nblk) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (tap, cs, cb)
+  if (idx < 16384) {
+    float v = 0.f;
+    for (int g = 0; g < nblk; ++g) v += ws[(long)g * 16384 + idx];
+    const int tap = idx >> 10, cs = (idx >> 5) & 31, cb = idx & 31;
+    dw[(cs * 32 + cb) * 16 + tap] = v;
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x < 32) {
+    const float* wsb = ws + (long)WG_MAX_BLOCKS * 16384;
+    float v = 0.f;
+    for (int g = 0; g < nblk; ++g) {
+      const float* q = wsb + (long)g * 160;
+      if (bias_from_big) v += (q[32 + threadIdx.x] + q[64 + threadIdx.x]) + (q[96 + threadIdx.x] + q[128 + threadIdx.x]);
+      else v += q[threadIdx.x];
+    }
+    db[threadIdx.x] = v;
+  }
+}
+
+size_t wgrad32_ws_floats() { return (size_t)WG_MAX_BLOCKS * 16384 + (size_t)WG_MAX_BLOCKS * 160; }
+
+// ---- launchers -----------------------------------------------------------------------------
+static int units_for(int N, int HS) { return (int)(((long)N * HS * HS + 63) / 64); }
+
+template <int HS>
+static int launch_down_t(const ConvArgs& a, hipStream_t s) {
+  using G = Geo<HS>;
+  const int n_units = units_for(a.N, HS);
+  const int grid = n_units < 256 ? n_units : 256;
+  const size_t lds = (16384 + G::BIG_FLOATS + 2 * 3 * 16 * 64) * sizeof(float);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_down32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(k_down32<HS>, dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int HS>
+static int launch_up_t(const ConvArgs& a, hipStream_t s) {
+  using G = Geo<HS>;
+  const int n_units = units_for(a.N, HS);
+  const int grid = n_units < 256 ? n_units : 256;
+  const size_t lds = (16384 + G::SH_FLOATS) * sizeof(float);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_up32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(k_up32<HS>, dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int HS>
+static int launch_wgrad_t(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
+                          float* ws, hipStream_t s) {
+  using G = Geo<HS>;
+  const int n_units = units_for(N, HS);
+  const int grid = n_units < WG_MAX_BLOCKS ? n_units : WG_MAX_BLOCKS;
+  const size_t lds = (G::BIG_FLOATS + 64 * 32) * sizeof(float);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units);
+  DVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(64), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+static bool mfma32_applicable(int Cb, int Cs, int Hs, int Ws, int l0, int l1, int l2) {
+  return Cb == 32 && Cs == 32 && Hs == Ws && (Hs == 4 || Hs == 8 || Hs == 16) && l0 == DVAE_NHWC &&
+         l1 == DVAE_NHWC && l2 == DVAE_NHWC;
+}
+
+int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
+  if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.big_layout, a.out_layout, DVAE_NHWC)) return 1;
+  if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
+  switch (a.Hs) {
+    case 16: return launch_down_t<16>(a, s);
+    case 8: return launch_down_t<8>(a, s);
+    default: return launch_down_t<4>(a, s);
+  }
+}
+
+int launch_up_mfma32(const ConvArgs& a, hipStream_t s) {
+  if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.small_layout, a.out_layout, DVAE_NHWC)) return 1;
+  if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
+  switch (a.Hs) {
+    case 16: return launch_up_t<16>(a, s);
+    case 8: return launch_up_t<8>(a, s);
+    default: return launch_up_t<4>(a, s);
+  }
+}
+
+int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
+                        int Hs, float* ws, hipStream_t s) {
+  switch (Hs) {
+    case 16: return launch_wgrad_t<16>(big, small, dw, db, bias_from_big, N, ws, s);
+    case 8: return launch_wgrad_t<8>(big, small, dw, db, bias_from_big, N, ws, s);
+    case 4: return launch_wgrad_t<4>(big, small, dw, db, bias_from_big, N, ws, s);
+    default: return 1;
+  }
+}
+
+}  // namespace dvae

@@ -1,0 +1,323 @@
+// gfx950 kernels for the two "thin" ends of the Burgess network at 64x64 images:
+//   conv1  : x[N,C,64,64] (NCHW, C in {1,3}) -> 32ch 32x32 (NHWC)      encoders.py:54,73
+//   convT3 : 32ch 32x32 (NHWC) -> [N,C,64,64] (NCHW) + sigmoid          decoders.py:65,82
+// and their backward passes.  With C in {1,3} these layers are bandwidth-shaped:
+//   down_thin  (conv1 fwd, convT3 dgrad): K = 16*C; MFMA 32x32x2 f32 with M = 32 pixels of one
+//              output row, N = 32 channels; weights live in 8*C VGPRs per lane.
+//   up_thin    (convT3 fwd): N = C output channels is too narrow for the matrix core; VALU
+//              kernel, one thread per small pixel producing its 2x2xC outputs, weights are
+//              wave-uniform (scalar loads -> SGPR operands), inputs staged in swizzled LDS.
+//   wgrad_thin (conv1 / convT3 wgrad): M = 32 cs, N = 16*C (cb,tap) columns, K = pixels.
+#include "common.h"
+
+namespace dvae {
+
+// LDS image of the big (NCHW) tile: [cb][row][par][cw], conflict-free strides
+#define TB_ROWS 10                // 4 small rows -> 10 big rows with halo
+#define TB_PAR 34                 // floats per parity half-row (33 used)
+#define TB_ROW 68                 // floats per row
+#define TB_PLANE (TB_ROWS * TB_ROW + 16)
+
+// stage big rows [2*sy0-1, 2*sy0+8] of image n, channels [0,C), zero padded
+__device__ __forceinline__ void stage_big_thin(const float* __restrict__ big, float* bt, int n, int sy0, int C,
+                                               bool valid, int tid, int nthreads) {
+  const int total = C * TB_ROWS * 66;
+  for (int e = tid; e < total; e += nthreads) {
+    int pc = e % 66; int t = e / 66; int r = t % TB_ROWS; int cb = t / TB_ROWS;
+    int by = 2 * sy0 - 1 + r, bx = pc - 1;
+    float v = 0.f;
+    if (valid && by >= 0 && by < 64 && bx >= 0 && bx < 64) v = big[(((long)n * C + cb) * 64 + by) * 64 + bx];
+    bt[cb * TB_PLANE + r * TB_ROW + (pc & 1) * TB_PAR + (pc >> 1)] = v;
+  }
+}
+
+// ---- down_thin: big NCHW [N,C,64,64] -> small NHWC [N,32,32,32] ----------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, const float* __restrict__ mask,
+                                                   float* __restrict__ out, int N, int act) {
+  __shared__ float bt[C * TB_PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int unit = blockIdx.x;          // (n, quad of 4 small rows)
+  const int n = unit >> 3, sy0 = (unit & 7) * 4;
+  // B operand: w[cs = i][k], k = cb*16 + kh*4 + kw = 2*kk + h
+  float wreg[8 * C];
+#pragma unroll
+  for (int kk = 0; kk < 8 * C; ++kk) wreg[kk] = w[i * (16 * C) + 2 * kk + h];
+  stage_big_thin(big, bt, n, sy0, C, n < N, tid, 256);
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int sy_l = wv;  // this wave's small row inside the unit; lane i = sx
+#pragma unroll
+  for (int kk = 0; kk < 8 * C; ++kk) {
+    // k = 2kk + h : kw = (2kk+h)&3 -> {2*(kk&1) + h}, kh = (kk>>1)&3, cb = kk>>3
+    const int kwb = (kk & 1);              // kw = 2*kwb + h  -> par = h, cw = sx + kwb
+    const int kh = (kk >> 1) & 3, cb = kk >> 3;
+    const float a = bt[cb * TB_PLANE + (2 * sy_l + kh) * TB_ROW + h * TB_PAR + i + kwb];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[kk], acc, 0, 0, 0);
+  }
+  const float bv = bias ? bias[i] : 0.f;
+  if (n < N) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int sx = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const long o = ((((long)n * 32 + sy0 + sy_l) * 32) + sx) * 32 + i;
+      float v = acc[e] + bv;
+      if (act == DVAE_ACT_RELU) v = v > 0.f ? v : 0.f;
+      if (mask) v = mask[o] > 0.f ? v : 0.f;
+      out[o] = v;
+    }
+  }
+}
+
+// ---- up_thin: small NHWC [N,32,32,32] -> big NCHW [N,C,64,64], bias + act ------------------
+// block = 128 threads = 4 small rows x 32 columns; LDS tile = 6 rows x 34 cols x 32 ch (swizzled)
+#define UT_ROWS 6
+#define UT_COLS 34
+template <int C>
+__global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                 int act) {
+  __shared__ __attribute__((aligned(16))) float st[UT_ROWS * UT_COLS * 32];
+  const int tid = threadIdx.x;
+  const int unit = blockIdx.x;
+  const int n = unit >> 3, sy0 = (unit & 7) * 4;
+  for (int s = tid; s < UT_ROWS * UT_COLS * 8; s += 128) {
+    int chunk = s & 7; int t = s >> 3; int col = t % UT_COLS; int row = t / UT_COLS;
+    int sy = sy0 - 1 + row, sx = col - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < N && sy >= 0 && sy < 32 && sx >= 0 && sx < 32)
+      v = *reinterpret_cast<const f32x4*>(small + ((((long)n * 32 + sy) * 32) + sx) * 32 + chunk * 4);
+    *reinterpret_cast<f32x4*>(st + (row * UT_COLS + col) * 32 + ((chunk ^ ((col >> 1) & 7)) << 2)) = v;
+  }
+  __syncthreads();
+  const int m = tid >> 5, l = tid & 31;
+  float acc[4][C];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int cb = 0; cb < C; ++cb) acc[c][cb] = 0.f;
+
+#pragma unroll 1
+  for (int q = 0; q < 8; ++q) {   // 4 contracted channels per iteration
+    f32x4 x[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int row = m + dy, col = l + dx;  // (m + (dy-1)) + 1
+        x[dy][dx] = *reinterpret_cast<const f32x4*>(st + (row * UT_COLS + col) * 32 + ((q ^ ((col >> 1) & 7)) << 2));
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cs = q * 4 + j;
+#pragma unroll
+      for (int cb = 0; cb < C; ++cb) {
+        const float* wp = w + (cs * C + cb) * 16;   // wave-uniform -> scalar loads
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+          // big row by = 2*sy - 1 + kh: py = (kh+1)&1, small row offset dsy = (py + 1 - kh) / 2  in {-1,0,1}
+          const int py = (kh + 1) & 1;
+          const int dsy = (py + 1 - kh) / 2;   // kh=0:+1 (py=1) kh=1:0 (py=0) kh=2:0 (py=1) kh=3:-1 (py=0)
+#pragma unroll
+          for (int kw = 0; kw < 4; ++kw) {
+            const int px = (kw + 1) & 1;
+            const int dsx = (px + 1 - kw) / 2;
+            acc[py * 2 + px][cb] = fmaf(x[dsy + 1][dsx + 1][j], wp[kh * 4 + kw], acc[py * 2 + px][cb]);
+          }
+        }
+      }
+    }
+  }
+  if (n < N) {
+    const int sy = sy0 + m;
+#pragma unroll
+    for (int cb = 0; cb < C; ++cb) {
+      const float bv = bias ? bias[cb] : 0.f;
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        float v0 = acc[py * 2 + 0][cb] + bv, v1 = acc[py * 2 + 1][cb] + bv;
+        if (act == DVAE_ACT_SIGMOID) { v0 = 1.f / (1.f + expf(-v0)); v1 = 1.f / (1.f + expf(-v1)); }
+        else if (act == DVAE_ACT_RELU) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+        float2 v = make_float2(v0, v1);
+        *reinterpret_cast<float2*>(out + ((((long)n * C + cb) * 64) + 2 * sy + py) * 64 + 2 * l) = v;
+      }
+    }
+  }
+}
+
+// ---- wgrad_thin ----------------------------------------------------------------------------
+#define WT_MAX_BLOCKS 512
+template <int C>
+__global__ __launch_bounds__(256) void k_wgrad_thin(const float* __restrict__ big, const float* __restrict__ small,
+                                                    float* __restrict__ ws, int N, int n_units) {
+  constexpr int NT = (16 * C + 31) / 32;   // N-tiles of 32 (cb,tap) columns
+  __shared__ __attribute__((aligned(16))) float bt[C * TB_PLANE];
+  __shared__ __attribute__((aligned(16))) float sp[8192];  // 128 px x 32 ch tile; reused (8192 floats) for the cross-wave reduction
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  float sumS = 0.f, sumB[NT];
+  int boff[NT];
+  bool bval[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    sumB[t] = 0.f;
+    const int nidx = t * 32 + i;
+    bval[t] = nidx < 16 * C;
+    const int cb = bval[t] ? (nidx >> 4) : 0, kh = (nidx >> 2) & 3, kw = nidx & 3;
+    boff[t] = cb * TB_PLANE + kh * TB_ROW + (kw & 1) * TB_PAR + (kw >> 1);
+  }
+  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const int n = unit >> 3, sy0 = (unit & 7) * 4;
+    __syncthreads();
+    stage_big_thin(big, bt, n, sy0, C, n < N, tid, 256);
+    {
+      const float* src = small + ((((long)n * 32 + sy0) * 32)) * 32;  // 128 pixels x 32 ch contiguous
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < N) v = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
+        *reinterpret_cast<f32x4*>(sp + (tid + k * 256) * 4) = v;
+      }
+    }
+    __syncthreads();
+    // wave wv handles small row sy_l = wv (32 pixels = 16 k-steps)
+#pragma unroll 4
+    for (int t = 0; t < 16; ++t) {
+      const int sx = 2 * t + h;
+      const float a = sp[(wv * 32 + sx) * 32 + i];
+      sumS += a;
+      const int base = (2 * wv) * TB_ROW + sx;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float b = bt[base + boff[nt]];
+        b = bval[nt] ? b : 0.f;
+        sumB[nt] += b;
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+      }
+    }
+  }
+  // cross-wave reduction through LDS (reuse sp: 4 waves x NT x 16 x 64 floats <= 8192)
+  __syncthreads();
+  float* red = sp;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[((wv * NT + nt) * 16 + e) * 64 + lane] = acc[nt][e];
+  __syncthreads();
+  float* wsw = ws + (long)blockIdx.x * (NT * 1024 + 32 + NT * 32);
+  for (int idx = tid; idx < NT * 1024; idx += 256) {
+    const int nt = idx >> 10, e = (idx >> 6) & 15, ln = idx & 63;
+    float v = red[((0 * NT + nt) * 16 + e) * 64 + ln] + red[((1 * NT + nt) * 16 + e) * 64 + ln] +
+              red[((2 * NT + nt) * 16 + e) * 64 + ln] + red[((3 * NT + nt) * 16 + e) * 64 + ln];
+    const int cs = (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+    const int nidx = nt * 32 + (ln & 31);
+    wsw[nt * 1024 + cs * 32 + (ln & 31)] = v;   // [nt][cs][j]
+    (void)nidx;
+  }
+  __syncthreads();
+  // bias partial sums: sumS per cs (h halves + 4 waves), sumB per (cb,tap) column
+  sumS += __shfl_xor(sumS, 32, 64);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) sumB[nt] += __shfl_xor(sumB[nt], 32, 64);
+  float* redb = sp;  // [wv][1+NT][32]
+  if (h == 0) {
+    redb[(wv * (1 + NT)) * 32 + i] = sumS;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) redb[(wv * (1 + NT) + 1 + nt) * 32 + i] = sumB[nt];
+  }
+  __syncthreads();
+  if (tid < (1 + NT) * 32) {
+    float v = redb[tid] + redb[(1 + NT) * 32 + tid] + redb[2 * (1 + NT) * 32 + tid] + redb[3 * (1 + NT) * 32 + tid];
+    wsw[NT * 1024 + tid] = v;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_wgrad_thin_reduce(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           float* __restrict__ db, int bias_from_big, int nblk) {
+  constexpr int NT = (16 * C + 31) / 32;
+  constexpr int STRIDE = NT * 1024 + 32 + NT * 32;
+  // dw[cs][cb][tap] : element (cs, nidx = cb*16+tap)
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 32 * 16 * C; idx += gridDim.x * 256) {
+    const int cs = idx / (16 * C), nidx = idx % (16 * C);
+    const int nt = nidx >> 5, j = nidx & 31;
+    float v = 0.f;
+    for (int g = 0; g < nblk; ++g) v += ws[(long)g * STRIDE + nt * 1024 + cs * 32 + j];
+    dw[idx] = v;
+  }
+  if (db && blockIdx.x == 0) {
+    if (!bias_from_big) {
+      if (threadIdx.x < 32) {
+        float v = 0.f;
+        for (int g = 0; g < nblk; ++g) v += ws[(long)g * STRIDE + NT * 1024 + threadIdx.x];
+        db[threadIdx.x] = v;
+      }
+    } else if (threadIdx.x < C) {
+      // every big pixel appears exactly once under taps (kh,kw) in {1,2}x{1,2}
+      const int cb = threadIdx.x;
+      float v = 0.f;
+      for (int g = 0; g < nblk; ++g) {
+        const float* q = ws + (long)g * STRIDE + NT * 1024 + 32;
+        const int t5 = cb * 16 + 5, t6 = cb * 16 + 6, t9 = cb * 16 + 9, t10 = cb * 16 + 10;
+        v += (q[(t5 >> 5) * 32 + (t5 & 31)] + q[(t6 >> 5) * 32 + (t6 & 31)]) +
+             (q[(t9 >> 5) * 32 + (t9 & 31)] + q[(t10 >> 5) * 32 + (t10 & 31)]);
+      }
+      db[cb] = v;
+    }
+  }
+}
+
+size_t wgrad_thin_ws_floats() { return (size_t)WT_MAX_BLOCKS * (2 * 1024 + 32 + 2 * 32); }
+
+// ---- launchers -------------------------------------------------------------------------------
+static bool thin_applicable(const ConvArgs& a) {
+  return (a.Cb == 1 || a.Cb == 3) && a.Cs == 32 && a.Hs == 32 && a.Ws == 32;
+}
+
+int launch_down_thin(const ConvArgs& a, hipStream_t s) {
+  if (!thin_applicable(a) || a.big_layout != DVAE_NCHW || a.out_layout != DVAE_NHWC) return 1;
+  if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
+  const int grid = a.N * 8;
+  if (a.Cb == 1) hipLaunchKernelGGL(k_down_thin<1>, dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
+  else hipLaunchKernelGGL(k_down_thin<3>, dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_up_thin(const ConvArgs& a, hipStream_t s) {
+  if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
+  const int grid = a.N * 8;
+  if (a.Cb == 1) hipLaunchKernelGGL(k_up_thin<1>, dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act);
+  else hipLaunchKernelGGL(k_up_thin<3>, dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N, int Cb,
+                      int Hs, float* ws, hipStream_t s) {
+  if (!(Cb == 1 || Cb == 3) || Hs != 32) return 1;
+  const int n_units = N * 8;
+  const int grid = n_units < WT_MAX_BLOCKS ? n_units : WT_MAX_BLOCKS;
+  if (Cb == 1) {
+    hipLaunchKernelGGL(k_wgrad_thin<1>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
+    DVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(2), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+  } else {
+    hipLaunchKernelGGL(k_wgrad_thin<3>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
+    DVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(6), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+  }
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace dvae

@@ -1,0 +1,529 @@
+// Latent-space and loss kernels of the training step: reparameterisation + per-dim KL
+// (vae.py:52-71, losses.py:452-480), reconstruction likelihoods (losses.py:394-449), the
+// beta-TCVAE minibatch estimator and its analytic gradient (losses.py:523-544, math.py:8-73),
+// FactorVAE permute_dims / discriminator losses (losses.py:261-265,293-295,483-508) and the
+// scalar epilogue of the loss plugins.  All reductions are fixed-order (deterministic).
+#include "common.h"
+
+namespace dvae {
+
+#define LOG2PI 1.8378770664093453f
+
+// ---- reparam + KL ----------------------------------------------------------------------------
+// single workgroup: B*D elements, D <= 16 per-dim sums
+__global__ __launch_bounds__(1024) void k_reparam_kl_fwd(const float* __restrict__ ml, const float* __restrict__ eps,
+                                                         float* __restrict__ mu, float* __restrict__ logvar,
+                                                         float* __restrict__ z, float* __restrict__ kl_dim,
+                                                         const float* __restrict__ coef, int B, int D) {
+  __shared__ float red[16][16];
+  const int tid = threadIdx.x;
+  float kl[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) kl[d] = 0.f;
+  for (int b = tid; b < B; b += blockDim.x) {
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      if (d < D) {
+        const float m = ml[(long)b * 2 * D + 2 * d], lv = ml[(long)b * 2 * D + 2 * d + 1];
+        mu[(long)b * D + d] = m;
+        logvar[(long)b * D + d] = lv;
+        float zz = m;
+        if (eps) zz = m + expf(0.5f * lv) * eps[(long)b * D + d];
+        z[(long)b * D + d] = zz;
+        kl[d] += 0.5f * (-1.f - lv + m * m + expf(lv));
+      }
+    }
+  }
+  if (!kl_dim) return;
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    float v = wave_sum(kl[d]);
+    if (lane == 0) red[wv][d] = v;
+  }
+  __syncthreads();
+  if (tid < D) {
+    float v = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) v += red[w][tid];
+    kl_dim[tid] = v * coef[DVAE_C_INV_B];
+  }
+}
+
+__global__ void k_reparam_kl_bwd(const float* __restrict__ dz, const float* __restrict__ dmu_x,
+                                 const float* __restrict__ dlv_x, const float* __restrict__ mu,
+                                 const float* __restrict__ logvar, const float* __restrict__ eps,
+                                 const float* __restrict__ scal, const float* __restrict__ coef,
+                                 float* __restrict__ dml, int B, int D) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)B * D) return;
+  const float klw = scal[DVAE_S_KLW] * coef[DVAE_C_INV_B];
+  const float m = mu[idx], lv = logvar[idx];
+  const float g = dz ? dz[idx] : 0.f;
+  float dm = g + klw * m;
+  float dl = klw * 0.5f * (expf(lv) - 1.f);
+  if (eps) dl += g * eps[idx] * 0.5f * expf(0.5f * lv);
+  if (dmu_x) dm += dmu_x[idx];
+  if (dlv_x) dl += dlv_x[idx];
+  const long b = idx / D; const int d = idx % D;
+  dml[b * 2 * D + 2 * d] = dm;
+  dml[b * 2 * D + 2 * d + 1] = dl;
+}
+
+// ---- reconstruction loss ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_recon_loss(const float* __restrict__ recon, const float* __restrict__ target,
+                                                    long n, int dist, const float* __restrict__ coef,
+                                                    float* __restrict__ partials, float* __restrict__ g,
+                                                    int wrt_logit) {
+  const float gs = coef[DVAE_C_INV_B];
+  float acc = 0.f;
+  const long n4 = n >> 2;
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(recon);
+  const f32x4* t4 = reinterpret_cast<const f32x4*>(target);
+  f32x4* g4 = reinterpret_cast<f32x4*>(g);
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+    const f32x4 pv = r4[q], xv = t4[q];
+    f32x4 gv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p = pv[j], x = xv[j];
+      float term, dldp;
+      if (dist == DVAE_REC_BERNOULLI) {
+        // ATen binary_cross_entropy: (x-1)*max(log1p(-p),-100) - x*max(log(p),-100);
+        // backward: (p-x)/max((1-p)*p, 1e-12)
+        term = (x - 1.f) * fmaxf(log1pf(-p), -100.f) - x * fmaxf(logf(p), -100.f);
+        dldp = (p - x) / fmaxf((1.f - p) * p, 1e-12f);
+      } else if (dist == DVAE_REC_GAUSSIAN) {
+        const float d = p * 255.f - x * 255.f;     // mse(255p, 255x, sum) / 255
+        term = d * d / 255.f;
+        dldp = 2.f * d;
+      } else {
+        const float d = p - x;                      // 3 * l1(sum)
+        term = 3.f * fabsf(d);
+        dldp = d > 0.f ? 3.f : (d < 0.f ? -3.f : 0.f);
+      }
+      acc += term;
+      gv[j] = gs * dldp;
+      if (wrt_logit) gv[j] *= (1.f - p) * p;        // sigmoid backward: grad * (1-y) * y
+    }
+    if (g) g4[q] = gv;
+  }
+  __shared__ float red[4];
+  float v = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- beta-TCVAE ------------------------------------------------------------------------------
+__device__ __forceinline__ float log_w_ij(int i, int j, int Bg, float lN, float lS, float lM) {
+  // math.py:66-72 with M+1 == B: column 0 <- 1/N, column 1 <- strat, then W[M-1,0] <- strat
+  if (j == 0) return (i == Bg - 2) ? lS : lN;
+  if (j == 1) return lS;
+  return lM;
+}
+
+// online logsumexp state merge
+__device__ __forceinline__ void lse_push(float& m, float& s, float v) {
+  if (v > m) { s = s * expf(m - v) + 1.f; m = v; }
+  else s += expf(v - m);
+}
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+  if (m2 > m) { s = s * expf(m - m2) + s2; m = m2; }
+  else if (m2 > -INFINITY) { s += s2 * expf(m2 - m); }
+}
+
+#define TC_MAXD 16
+// one wave per row i; 4 rows per workgroup; columns j strided over lanes
+template <int D>
+__global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z, const float* __restrict__ mu,
+                                                    const float* __restrict__ lv, int Bg, int row0, int Bl, int is_mss,
+                                                    const float* __restrict__ log_w, float* __restrict__ rowstats) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int il = blockIdx.x * 4 + wv;
+  if (il >= Bl) return;
+  const int i = row0 + il;
+  const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
+  float zi[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) zi[d] = z[(long)i * D + d];
+  float mS = -INFINITY, sS = 0.f, md[D], sd[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { md[d] = -INFINITY; sd[d] = 0.f; }
+  for (int j = lane; j < Bg; j += 64) {
+    const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
+    float S = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float m = mu[(long)j * D + d], l = lv[(long)j * D + d];
+      const float diff = zi[d] - m;
+      const float ld = (-0.5f * (LOG2PI + l) - 0.5f * (diff * diff * expf(-l))) + lw;
+      S += ld;
+      lse_push(md[d], sd[d], ld);
+    }
+    lse_push(mS, sS, S);
+  }
+  // wave reduction of the (max, sum) pairs
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float m2 = __shfl_xor(mS, o, 64), s2 = __shfl_xor(sS, o, 64);
+    lse_merge(mS, sS, m2, s2);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      m2 = __shfl_xor(md[d], o, 64); s2 = __shfl_xor(sd[d], o, 64);
+      lse_merge(md[d], sd[d], m2, s2);
+    }
+  }
+  if (lane == 0) {
+    float* rs = rowstats + (long)il * 16;
+    float log_pz = 0.f, log_qzCx = 0.f, log_prod = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float m = mu[(long)i * D + d], l = lv[(long)i * D + d];
+      const float diff = zi[d] - m;
+      log_qzCx += -0.5f * (LOG2PI + l) - 0.5f * (diff * diff * expf(-l));
+      log_pz += -0.5f * LOG2PI - 0.5f * (zi[d] * zi[d]);
+      const float lse = md[d] + logf(sd[d]);
+      rs[4 + d] = lse;
+      log_prod += lse;
+    }
+    rs[0] = log_pz;
+    rs[1] = mS + logf(sS);
+    rs[2] = log_prod;
+    rs[3] = log_qzCx;
+  }
+}
+
+// row pass: dz[i] (one wave per local row i)
+template <int D>
+__global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict__ z, const float* __restrict__ mu,
+                                                         const float* __restrict__ lv, const float* __restrict__ rowstats,
+                                                         int Bg, int row0, int Bl, int is_mss,
+                                                         const float* __restrict__ log_w, const float* __restrict__ coef,
+                                                         float* __restrict__ dz) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int il = blockIdx.x * 4 + wv;
+  if (il >= Bl) return;
+  const int i = row0 + il;
+  const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
+  const float alpha = coef[DVAE_C_ALPHA], beta = coef[DVAE_C_BETA], gam = coef[DVAE_C_GAMMA] * coef[DVAE_C_ANNEAL];
+  const float invB = 1.f / (float)Bg;
+  const float cP = (beta - alpha) * invB, cQ = (gam - beta) * invB;
+  const float* rs = rowstats + (long)il * 16;
+  const float lqz = rs[1];
+  float zi[D], lse[D], g[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { zi[d] = z[(long)i * D + d]; lse[d] = rs[4 + d]; g[d] = 0.f; }
+  for (int j = lane; j < Bg; j += 64) {
+    const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
+    float ld[D], r[D];
+    float S = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float m = mu[(long)j * D + d], l = lv[(long)j * D + d];
+      const float iv = expf(-l);
+      const float diff = zi[d] - m;
+      r[d] = diff * iv;
+      ld[d] = (-0.5f * (LOG2PI + l) - 0.5f * (diff * diff * iv)) + lw;
+      S += ld[d];
+    }
+    const float P = expf(S - lqz);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float G = cP * P + cQ * expf(ld[d] - lse[d]);
+      g[d] -= G * r[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) g[d] = wave_sum(g[d]);
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      // diagonal terms: alpha * log q(z_i|x_i) / B  and  -gamma' * log p(z_i) / B
+      const float m = mu[(long)i * D + d], l = lv[(long)i * D + d];
+      const float r = (zi[d] - m) * expf(-l);
+      dz[(long)il * D + d] = g[d] - alpha * invB * r + gam * invB * zi[d];
+    }
+  }
+}
+
+// column pass: dmu[j], dlv[j] summed over the local rows (one wave per column j)
+template <int D>
+__global__ __launch_bounds__(256) void k_btcvae_bwd_cols(const float* __restrict__ z, const float* __restrict__ mu,
+                                                         const float* __restrict__ lv, const float* __restrict__ rowstats,
+                                                         int Bg, int row0, int Bl, int is_mss,
+                                                         const float* __restrict__ log_w, const float* __restrict__ coef,
+                                                         float* __restrict__ dmu, float* __restrict__ dlv) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wv;
+  if (j >= Bg) return;
+  const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
+  const float alpha = coef[DVAE_C_ALPHA], beta = coef[DVAE_C_BETA], gam = coef[DVAE_C_GAMMA] * coef[DVAE_C_ANNEAL];
+  const float invB = 1.f / (float)Bg;
+  const float cP = (beta - alpha) * invB, cQ = (gam - beta) * invB;
+  float mj[D], lj[D], ivj[D], gm[D], gl[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    mj[d] = mu[(long)j * D + d]; lj[d] = lv[(long)j * D + d]; ivj[d] = expf(-lj[d]); gm[d] = 0.f; gl[d] = 0.f;
+  }
+  for (int il = lane; il < Bl; il += 64) {
+    const int i = row0 + il;
+    const float* rs = rowstats + (long)il * 16;
+    const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
+    float ld[D], r[D], diff[D];
+    float S = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      diff[d] = z[(long)i * D + d] - mj[d];
+      r[d] = diff[d] * ivj[d];
+      ld[d] = (-0.5f * (LOG2PI + lj[d]) - 0.5f * (diff[d] * diff[d] * ivj[d])) + lw;
+      S += ld[d];
+    }
+    const float P = expf(S - rs[1]);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const float G = cP * P + cQ * expf(ld[d] - rs[4 + d]);
+      gm[d] += G * r[d];
+      gl[d] += G * (-0.5f + 0.5f * r[d] * diff[d]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) { gm[d] = wave_sum(gm[d]); gl[d] = wave_sum(gl[d]); }
+  if (lane == 0) {
+    const bool local = (j >= row0 && j < row0 + Bl);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      float a = gm[d], b = gl[d];
+      if (local) {  // diagonal term alpha * log q(z_j|x_j) / B
+        const float diff = z[(long)j * D + d] - mj[d];
+        const float r = diff * ivj[d];
+        a += alpha * invB * r;
+        b += alpha * invB * (-0.5f + 0.5f * r * diff);
+      }
+      dmu[(long)j * D + d] = a;
+      dlv[(long)j * D + d] = b;
+    }
+  }
+}
+
+// ---- FactorVAE pieces ----------------------------------------------------------------------
+__global__ void k_permute_dims(const float* __restrict__ z, const int64_t* __restrict__ perm, float* __restrict__ out,
+                               int B, int D) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)B * D) return;
+  const int b = idx / D, d = idx % D;
+  out[idx] = z[perm[(long)d * B + b] * D + d];
+}
+
+__global__ __launch_bounds__(256) void k_disc_losses(const float* __restrict__ lg, int Bh, const float* __restrict__ coef,
+                                                     float* __restrict__ sums, float* __restrict__ g_dtc,
+                                                     float* __restrict__ g_tc) {
+  // single workgroup; rows [0,Bh): D(z1) target 0, rows [Bh,2Bh): D(z_perm) target 1
+  float s_tc = 0.f, s_ce0 = 0.f, s_ce1 = 0.f;
+  const float inv = 1.f / (float)Bh;
+  const float gtc = coef[DVAE_C_ANNEAL] * coef[DVAE_C_BETA] * inv;
+  for (int r = threadIdx.x; r < 2 * Bh; r += blockDim.x) {
+    const float a = lg[2 * r], b = lg[2 * r + 1];
+    const float mx = fmaxf(a, b);
+    const float lse = mx + logf(expf(a - mx) + expf(b - mx));
+    const float p0 = expf(a - lse), p1 = expf(b - lse);
+    if (r < Bh) {
+      s_tc += a - b;
+      s_ce0 += lse - a;
+      g_dtc[2 * r] = 0.5f * inv * (p0 - 1.f);
+      g_dtc[2 * r + 1] = 0.5f * inv * p1;
+      if (g_tc) { g_tc[2 * r] = gtc; g_tc[2 * r + 1] = -gtc; }
+    } else {
+      s_ce1 += lse - b;
+      g_dtc[2 * r] = 0.5f * inv * p0;
+      g_dtc[2 * r + 1] = 0.5f * inv * (p1 - 1.f);
+    }
+  }
+  __shared__ float red[3][4];
+  float v0 = wave_sum(s_tc), v1 = wave_sum(s_ce0), v2 = wave_sum(s_ce1);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v0; red[1][threadIdx.x >> 6] = v1; red[2][threadIdx.x >> 6] = v2; }
+  __syncthreads();
+  if (threadIdx.x < 3) sums[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (threadIdx.x == 3) sums[3] = 0.f;
+}
+
+// ---- scalar epilogue -------------------------------------------------------------------------
+// pack: local sums -> packed[DVAE_NPACK] (sum-all-reduce this buffer over ranks when sharded)
+__global__ __launch_bounds__(256) void k_loss_pack(const float* __restrict__ rec_partials,
+                                                   const float* __restrict__ kl_dim, int D,
+                                                   const float* __restrict__ rowstats, int Bl,
+                                                   const float* __restrict__ disc_sums, float* __restrict__ packed) {
+  __shared__ float red[5][4];
+  const int tid = threadIdx.x;
+  float r = 0.f;
+  for (int k = tid; k < DVAE_REC_NPART; k += 256) r += rec_partials[k];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (rowstats) {
+    for (int i = tid; i < Bl; i += 256) {
+      const float* rs = rowstats + (long)i * 16;
+      s0 += rs[0]; s1 += rs[1]; s2 += rs[2]; s3 += rs[3];
+    }
+  }
+  float v[5] = {r, s0, s1, s2, s3};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    float w = wave_sum(v[k]);
+    if ((tid & 63) == 0) red[k][tid >> 6] = w;
+  }
+  __syncthreads();
+  if (tid < 5) {
+    const float t = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+    packed[tid == 0 ? 0 : 16 + tid] = t;          // [0] rec, [17..20] rowstat sums
+  }
+  if (tid >= 32 && tid < 32 + 16) packed[1 + (tid - 32)] = (kl_dim && (tid - 32) < D) ? kl_dim[tid - 32] : 0.f;
+  if (tid >= 64 && tid < 64 + 3) packed[21 + (tid - 64)] = disc_sums ? disc_sums[tid - 64] : 0.f;
+  if (tid >= 96 && tid < 96 + 8) packed[24 + (tid - 96)] = 0.f;
+}
+
+__global__ void k_loss_finalize(int kind, const float* __restrict__ packed, int D, int Bg,
+                                const float* __restrict__ coef, float* __restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float rec = packed[0] * coef[DVAE_C_INV_B];
+  float kl = 0.f;
+  for (int d = 0; d < D; ++d) { kl += packed[1 + d]; scal[DVAE_S_KL0 + d] = packed[1 + d]; }
+  const float anneal = coef[DVAE_C_ANNEAL];
+  float loss = rec, klw = 0.f, mi = 0.f, tc = 0.f, dw = 0.f, dtc = 0.f;
+  if (kind == DVAE_LOSS_BETAH) {
+    klw = anneal * coef[DVAE_C_BETA];
+    loss = rec + klw * kl;
+  } else if (kind == DVAE_LOSS_BETAB) {
+    const float dlt = kl - coef[DVAE_C_CAP];
+    loss = rec + coef[DVAE_C_BETA] * fabsf(dlt);
+    klw = coef[DVAE_C_BETA] * (dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f));
+  } else if (kind == DVAE_LOSS_BTCVAE) {
+    const float invB = 1.f / (float)Bg;
+    const float s_pz = packed[17], s_qz = packed[18], s_prod = packed[19], s_qzcx = packed[20];
+    mi = (s_qzcx - s_qz) * invB;
+    tc = (s_qz - s_prod) * invB;
+    dw = (s_prod - s_pz) * invB;
+    loss = rec + (coef[DVAE_C_ALPHA] * mi + coef[DVAE_C_BETA] * tc + anneal * coef[DVAE_C_GAMMA] * dw);
+  } else if (kind == DVAE_LOSS_FACTOR) {
+    const float invh = 1.f / (float)Bg;   // Bg = (global) half batch
+    tc = packed[21] * invh;
+    dtc = 0.5f * (packed[22] * invh + packed[23] * invh);
+    klw = 1.f;
+    loss = rec + kl + anneal * coef[DVAE_C_BETA] * tc;
+  }
+  scal[DVAE_S_LOSS] = loss; scal[DVAE_S_REC] = rec; scal[DVAE_S_KL] = kl; scal[DVAE_S_MI] = mi;
+  scal[DVAE_S_TC] = tc; scal[DVAE_S_DWKL] = dw; scal[DVAE_S_KLW] = klw; scal[DVAE_S_DTC] = dtc;
+}
+
+__global__ void k_sigmoid_bwd(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = gy[i] * ((1.f - y[i]) * y[i]);
+}
+
+struct Coef8 { float v[8]; };
+__global__ void k_set_coef(float* __restrict__ coef, Coef8 c) {
+  if (threadIdx.x < 8) coef[threadIdx.x] = c.v[threadIdx.x];
+}
+
+__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
+                          const float* coef, int B, int D, hipStream_t s) {
+  int threads = B >= 1024 ? 1024 : ((B + 63) / 64) * 64;
+  hipLaunchKernelGGL(k_reparam_kl_fwd, dim3(1), dim3(threads), 0, s, ml, eps, mu, logvar, z, kl_dim, coef, B, D);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_reparam_kl_bwd(const float* dz, const float* dmu_x, const float* dlv_x, const float* mu, const float* logvar,
+                          const float* eps, const float* scal, const float* coef, float* dml, int B, int D,
+                          hipStream_t s) {
+  long n = (long)B * D;
+  hipLaunchKernelGGL(k_reparam_kl_bwd, dim3((n + 255) / 256), dim3(256), 0, s, dz, dmu_x, dlv_x, mu, logvar, eps, scal,
+                     coef, dml, B, D);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_recon_loss(const float* recon, const float* target, long n, int dist, const float* coef, float* partials,
+                      float* g, int wrt_logit, hipStream_t s) {
+  hipLaunchKernelGGL(k_recon_loss, dim3(DVAE_REC_NPART), dim3(256), 0, s, recon, target, n, dist, coef, partials, g,
+                     wrt_logit);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, int D, int row0, int Bl, int is_mss,
+                      const float* log_w, float* rowstats, hipStream_t s) {
+  dim3 grid((Bl + 3) / 4), block(256);
+  if (D == 10) hipLaunchKernelGGL(k_btcvae_fwd<10>, grid, block, 0, s, z, mu, lv, Bg, row0, Bl, is_mss, log_w, rowstats);
+  else return 1;
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const float* rowstats, int Bg, int D, int row0,
+                      int Bl, int is_mss, const float* log_w, const float* coef, float* dz, float* dmu, float* dlv,
+                      hipStream_t s) {
+  if (D != 10) return 1;
+  hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
+                     is_mss, log_w, coef, dz);
+  DVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_btcvae_bwd_cols<10>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
+                     is_mss, log_w, coef, dmu, dlv);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_permute_dims(const float* z, const int64_t* perm, float* out, int B, int D, hipStream_t s) {
+  long n = (long)B * D;
+  hipLaunchKernelGGL(k_permute_dims, dim3((n + 255) / 256), dim3(256), 0, s, z, perm, out, B, D);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_disc_losses(const float* lg, int Bh, const float* coef, float* sums, float* g_dtc, float* g_tc,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(k_disc_losses, dim3(1), dim3(256), 0, s, lg, Bh, coef, sums, g_dtc, g_tc);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_loss_pack(const float* rec_partials, const float* kl_dim, int D, const float* rowstats, int Bl,
+                     const float* disc_sums, float* packed, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_pack, dim3(1), dim3(256), 0, s, rec_partials, kl_dim, D, rowstats, Bl, disc_sums, packed);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, s, kind, packed, D, Bg, coef, scal);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_sigmoid_bwd(const float* gy, const float* y, float* out, long n, hipStream_t s) {
+  long g = (n + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_sigmoid_bwd, dim3(g), dim3(256), 0, s, gy, y, out, n);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_set_coef(float* coef, const float* v, hipStream_t s) {
+  Coef8 c;
+  for (int i = 0; i < 8; ++i) c.v[i] = v[i];
+  hipLaunchKernelGGL(k_set_coef, dim3(1), dim3(64), 0, s, coef, c);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_add(const float* a, const float* b, float* out, long n, hipStream_t s) {
+  long g = (n + 255) / 256; if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_add, dim3(g), dim3(256), 0, s, a, b, out, n);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace dvae

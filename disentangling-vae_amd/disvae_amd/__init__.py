@@ -1,0 +1,6 @@
+"""disvae_amd -- MI355X-native drop-in for the training path of ``disvae``
+(YannDubs/disentangling-vae): same names as disvae/__init__.py:1-3."""
+from .models.vae import init_specific_model
+from .training import Trainer
+
+__all__ = ["init_specific_model", "Trainer"]

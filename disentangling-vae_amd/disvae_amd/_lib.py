@@ -1,0 +1,92 @@
+"""ctypes binding of libdvae_hip.so (the C-ABI declared in include/dvae_hip.h).
+
+The library is the product: there is NO CPU or PyTorch fallback.  If the shared object is
+missing or a symbol cannot be resolved, importing an op fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DVAE_HIP_LIB", os.path.join(_HERE, "..", "lib", "libdvae_hip.so"))
+
+NCHW, NHWC = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
+REC = {"bernoulli": 0, "gaussian": 1, "laplace": 2}
+LOSS_BETAH, LOSS_BETAB, LOSS_BTCVAE, LOSS_FACTOR = 0, 1, 2, 3
+# scalar slots (dvae_hip.h)
+S_LOSS, S_REC, S_KL, S_KL0, S_MI, S_TC, S_DWKL, S_KLW, S_DTC, NSCAL = 0, 1, 2, 3, 19, 20, 21, 22, 23, 32
+C_INV_B, C_ANNEAL, C_BETA, C_ALPHA, C_GAMMA, C_CAP, NCOEF = 0, 1, 2, 3, 4, 5, 8
+REC_NPART = 512
+NPACK = 32
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_long
+
+# name -> argtypes (all return int unless listed in _RESTYPE)
+SIGNATURES = {
+    "dvae_version": [],
+    "dvae_last_error": [],
+    "dvae_conv4s2_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "dvae_conv4s2_dgrad": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "dvae_conv4s2_wgrad": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "dvae_convT4s2_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "dvae_convT4s2_dgrad": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "dvae_convT4s2_wgrad": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "dvae_conv_wgrad_ws_floats": [],
+    "dvae_relayout": [_p, _i, _p, _i, _i, _i, _i, _p],
+    "dvae_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "dvae_linear_dgrad": [_p, _p, _p, _i, _p, _i, _i, _i, _p],
+    "dvae_linear_wgrad": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "dvae_reparam_kl_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "dvae_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "dvae_recon_loss": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
+    "dvae_sigmoid_bwd": [_p, _p, _p, _l, _p],
+    "dvae_btcvae_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "dvae_btcvae_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "dvae_permute_dims": [_p, _p, _p, _i, _i, _p],
+    "dvae_disc_losses": [_p, _i, _p, _p, _p, _p, _p],
+    "dvae_loss_pack": [_p, _p, _i, _p, _i, _p, _p, _p],
+    "dvae_loss_finalize": [_i, _p, _i, _i, _p, _p, _p],
+    "dvae_set_coef": [_p] + [ctypes.c_float] * 8 + [_p],
+    "dvae_add": [_p, _p, _p, _l, _p],
+}
+_RESTYPE = {"dvae_last_error": ctypes.c_char_p, "dvae_conv_wgrad_ws_floats": ctypes.c_size_t}
+
+
+class DvaeHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        path = os.path.abspath(LIB_PATH)
+        if not os.path.exists(path):
+            raise DvaeHipError(
+                "libdvae_hip.so not found at %s -- build it with `python disentangling-vae_amd/build.py` "
+                "(there is no CPU / PyTorch fallback for the training-step kernels)" % path)
+        h = ctypes.CDLL(path)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is missing: fail loudly
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, ctypes.c_int)
+        _lib = h
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point, raise on a non-zero status."""
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        raise DvaeHipError("%s failed (%d): %s" % (name, rc, h.dvae_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

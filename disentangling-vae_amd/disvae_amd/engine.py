@@ -1,0 +1,268 @@
+"""Host-side orchestration of the HIP kernels for the Burgess VAE (forward + backward).
+
+This is plumbing only: torch tensors are used as device-memory containers, every FLOP of
+the network runs in libdvae_hip.so through the C-ABI (``_lib.call``).  Layout contract:
+  * API boundary (input batch, reconstruction): NCHW fp32, like the reference;
+  * internal conv activations: NHWC (one pixel = one 128-byte line of 32 channels);
+  * the 4x4x32 tensor between the conv stack and the FC stack is re-laid-out to the
+    reference's (c,h,w) flatten order (encoders.py:80, decoders.py:74) so that lin1 / lin3
+    weights keep their state_dict layout.
+Reference being replaced: EncoderBurgess.forward (encoders.py:69-89), VAE.reparameterize
+(vae.py:52-71), DecoderBurgess.forward (decoders.py:67-84) and their autograd backward
+(training.py:157).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, NCHW, NHWC, ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+HID = 32
+HIDDEN_DIM = 256
+
+
+def vae_param_shapes(img_size, latent_dim=10):
+    """name -> shape in the reference's registration order (encoders.py:54-67,
+    decoders.py:53-65; convT_64 precedes convT1)."""
+    c, h, w = img_size
+    if [h, w] not in ([32, 32], [64, 64]):
+        raise RuntimeError("{} sized images not supported. Only (None, 32, 32) and (None, 64, 64) supported. "
+                           "Build your own architecture or reshape images!".format(img_size))
+    is64 = h == 64
+    shapes = OrderedDict()
+
+    def add(name, wshape, nb):
+        shapes[name + ".weight"] = tuple(wshape)
+        shapes[name + ".bias"] = (nb,)
+
+    add("encoder.conv1", (HID, c, 4, 4), HID)
+    add("encoder.conv2", (HID, HID, 4, 4), HID)
+    add("encoder.conv3", (HID, HID, 4, 4), HID)
+    if is64:
+        add("encoder.conv_64", (HID, HID, 4, 4), HID)
+    add("encoder.lin1", (HIDDEN_DIM, HID * 16), HIDDEN_DIM)
+    add("encoder.lin2", (HIDDEN_DIM, HIDDEN_DIM), HIDDEN_DIM)
+    add("encoder.mu_logvar_gen", (2 * latent_dim, HIDDEN_DIM), 2 * latent_dim)
+    add("decoder.lin1", (HIDDEN_DIM, latent_dim), HIDDEN_DIM)
+    add("decoder.lin2", (HIDDEN_DIM, HIDDEN_DIM), HIDDEN_DIM)
+    add("decoder.lin3", (HID * 16, HIDDEN_DIM), HID * 16)
+    if is64:
+        add("decoder.convT_64", (HID, HID, 4, 4), HID)
+    add("decoder.convT1", (HID, HID, 4, 4), HID)
+    add("decoder.convT2", (HID, HID, 4, 4), HID)
+    add("decoder.convT3", (HID, c, 4, 4), c)
+    return shapes
+
+
+class ParamArena:
+    """All parameters of a module in ONE flat fp32 buffer (+ one flat gradient buffer):
+    a single RCCL all-reduce covers every gradient, and nn.Parameter views keep the
+    reference's state_dict names/shapes so torch.optim.Adam works unchanged."""
+
+    def __init__(self, shapes, device="cpu"):
+        self.shapes = OrderedDict(shapes)
+        self.offsets = OrderedDict()
+        off = 0
+        for k, s in self.shapes.items():
+            n = 1
+            for d in s:
+                n *= d
+            self.offsets[k] = (off, n)
+            off += (n + 3) // 4 * 4   # keep every tensor 16-byte aligned
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+
+    def view(self, name, grad=False):
+        off, n = self.offsets[name]
+        buf = self.grad if grad else self.flat
+        return buf[off:off + n].view(self.shapes[name])
+
+    def to(self, device):
+        self.flat = self.flat.to(device)
+        self.grad = self.grad.to(device)
+        return self
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Buffers:
+    """Activation / gradient workspace for one batch size."""
+
+    def __init__(self, eng, B):
+        dev = eng.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.B = B
+        D = eng.latent_dim
+        self.enc_act = [f(B, h, h, HID) for h in eng.enc_sizes]       # NHWC outputs of the conv layers
+        self.enc_gact = [f(B, h, h, HID) for h in eng.enc_sizes]
+        self.a_flat = f(B, HID * 16)
+        self.ga_flat = f(B, HID * 16)
+        self.h1, self.h2 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM)
+        self.gh1, self.gh2 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM)
+        self.ml, self.dml = f(B, 2 * D), f(B, 2 * D)
+        self.mu, self.logvar, self.z = f(B, D), f(B, D), f(B, D)
+        self.d1, self.d2, self.d3 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM), f(B, HID * 16)
+        self.gd1, self.gd2, self.gd3 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM), f(B, HID * 16)
+        self.d3n, self.gd3n = f(B, 4, 4, HID), f(B, 4, 4, HID)
+        self.dec_act = [f(B, h, h, HID) for h in eng.dec_sizes]       # NHWC outputs of the hidden convT layers
+        self.dec_gact = [f(B, h, h, HID) for h in eng.dec_sizes]
+        c, hh, ww = eng.img_size
+        self.recon = f(B, c, hh, ww)
+        self.g_logit = f(B, c, hh, ww)
+        self.dz = f(B, D)
+
+
+class VAEEngine:
+    """Forward / backward of the Burgess VAE on one MI355X through libdvae_hip.so."""
+
+    def __init__(self, img_size, latent_dim, arena):
+        _lib.lib()  # fail loudly if the HIP library is missing
+        self.img_size = tuple(img_size)
+        self.latent_dim = latent_dim
+        self.arena = arena
+        c, h, w = self.img_size
+        self.is64 = h == 64
+        self.enc_names = ["conv1", "conv2", "conv3"] + (["conv_64"] if self.is64 else [])
+        self.enc_sizes = [h >> (i + 1) for i in range(len(self.enc_names))]   # output H of each conv
+        self.dec_names = (["convT_64"] if self.is64 else []) + ["convT1", "convT2"]
+        self.dec_sizes = [8 << i for i in range(len(self.dec_names))]         # output H of each hidden convT
+        self._bufs = {}
+        self._ws = None
+
+    @property
+    def device(self):
+        return self.arena.flat.device
+
+    def p(self, name):
+        return self.arena.view(name)
+
+    def g(self, name):
+        return self.arena.view(name, grad=True)
+
+    def buffers(self, B):
+        b = self._bufs.get(B)
+        if b is None or b.recon.device != self.device:
+            b = _Buffers(self, B)
+            self._bufs[B] = b
+        if self._ws is None or self._ws.device != self.device:
+            n = _lib.lib().dvae_conv_wgrad_ws_floats()
+            self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
+        return b
+
+    # ------------------------------------------------------------------ forward
+    def encode(self, x, buf, n=None):
+        """x[B,C,H,W] (NCHW) -> buf.ml[B,2D] (interleaved mu/logvar)."""
+        s = _stream()
+        B = x.shape[0] if n is None else n
+        c, H, _ = self.img_size
+        src, src_layout, cin, h = x, NCHW, c, H
+        for name, act in zip(self.enc_names, buf.enc_act):
+            call("dvae_conv4s2_fwd", ptr(src), src_layout, ptr(self.p("encoder.%s.weight" % name)),
+                 ptr(self.p("encoder.%s.bias" % name)), ptr(act), NHWC, B, cin, h, h, HID, ACT_RELU, s)
+            src, src_layout, cin, h = act, NHWC, HID, h // 2
+        call("dvae_relayout", ptr(src), NHWC, ptr(buf.a_flat), B, HID, 4, 4, s)
+        call("dvae_linear_fwd", ptr(buf.a_flat), ptr(self.p("encoder.lin1.weight")), ptr(self.p("encoder.lin1.bias")),
+             ptr(buf.h1), B, HID * 16, HIDDEN_DIM, ACT_RELU, s)
+        call("dvae_linear_fwd", ptr(buf.h1), ptr(self.p("encoder.lin2.weight")), ptr(self.p("encoder.lin2.bias")),
+             ptr(buf.h2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, s)
+        call("dvae_linear_fwd", ptr(buf.h2), ptr(self.p("encoder.mu_logvar_gen.weight")),
+             ptr(self.p("encoder.mu_logvar_gen.bias")), ptr(buf.ml), B, HIDDEN_DIM, 2 * self.latent_dim, ACT_NONE, s)
+
+    def reparam(self, buf, eps, kl_dim=None, coef=None, n=None):
+        B = buf.B if n is None else n
+        call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(kl_dim),
+             ptr(coef), B, self.latent_dim, _stream())
+
+    def decode(self, z, buf, n=None):
+        """z[B,D] -> buf.recon[B,C,H,W] (NCHW, post-sigmoid)."""
+        s = _stream()
+        B = z.shape[0] if n is None else n
+        D = self.latent_dim
+        call("dvae_linear_fwd", ptr(z), ptr(self.p("decoder.lin1.weight")), ptr(self.p("decoder.lin1.bias")),
+             ptr(buf.d1), B, D, HIDDEN_DIM, ACT_RELU, s)
+        call("dvae_linear_fwd", ptr(buf.d1), ptr(self.p("decoder.lin2.weight")), ptr(self.p("decoder.lin2.bias")),
+             ptr(buf.d2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, s)
+        call("dvae_linear_fwd", ptr(buf.d2), ptr(self.p("decoder.lin3.weight")), ptr(self.p("decoder.lin3.bias")),
+             ptr(buf.d3), B, HIDDEN_DIM, HID * 16, ACT_RELU, s)
+        call("dvae_relayout", ptr(buf.d3), NCHW, ptr(buf.d3n), B, HID, 4, 4, s)
+        src, h = buf.d3n, 4
+        for name, act in zip(self.dec_names, buf.dec_act):
+            call("dvae_convT4s2_fwd", ptr(src), NHWC, ptr(self.p("decoder.%s.weight" % name)),
+                 ptr(self.p("decoder.%s.bias" % name)), ptr(act), NHWC, B, HID, h, h, HID, ACT_RELU, s)
+            src, h = act, h * 2
+        c = self.img_size[0]
+        call("dvae_convT4s2_fwd", ptr(src), NHWC, ptr(self.p("decoder.convT3.weight")),
+             ptr(self.p("decoder.convT3.bias")), ptr(buf.recon), NCHW, B, HID, h, h, c, ACT_SIGMOID, s)
+
+    # ------------------------------------------------------------------ backward
+    def decode_backward(self, z, buf, n=None):
+        """buf.g_logit (grad w.r.t. the pre-sigmoid output) -> decoder weight grads, buf.dz."""
+        s = _stream()
+        B = z.shape[0] if n is None else n
+        D = self.latent_dim
+        c = self.img_size[0]
+        ws = ptr(self._ws)
+        acts = [buf.d3n] + buf.dec_act          # inputs of convT_64/convT1/convT2/convT3
+        gacts = [buf.gd3n] + buf.dec_gact
+        names = self.dec_names + ["convT3"]
+        couts = [HID] * len(self.dec_names) + [c]
+        hs = [4 << i for i in range(len(names))]  # input H of each convT
+        dy, dy_layout = buf.g_logit, NCHW
+        for k in range(len(names) - 1, -1, -1):
+            name, x_in, gx, h = names[k], acts[k], gacts[k], hs[k]
+            call("dvae_convT4s2_wgrad", ptr(x_in), NHWC, ptr(dy), dy_layout, ptr(self.g("decoder.%s.weight" % name)),
+                 ptr(self.g("decoder.%s.bias" % name)), B, HID, h, h, couts[k], ws, s)
+            call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(x_in), ptr(gx),
+                 NHWC, B, HID, h, h, couts[k], s)
+            dy, dy_layout = gx, NHWC
+        call("dvae_relayout", ptr(buf.gd3n), NHWC, ptr(buf.gd3), B, HID, 4, 4, s)
+        call("dvae_linear_wgrad", ptr(buf.d2), ptr(buf.gd3), ptr(self.g("decoder.lin3.weight")),
+             ptr(self.g("decoder.lin3.bias")), B, HIDDEN_DIM, HID * 16, s)
+        call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
+             B, HIDDEN_DIM, HID * 16, s)
+        call("dvae_linear_wgrad", ptr(buf.d1), ptr(buf.gd2), ptr(self.g("decoder.lin2.weight")),
+             ptr(self.g("decoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, s)
+        call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
+             B, HIDDEN_DIM, HIDDEN_DIM, s)
+        call("dvae_linear_wgrad", ptr(z), ptr(buf.gd1), ptr(self.g("decoder.lin1.weight")),
+             ptr(self.g("decoder.lin1.bias")), B, D, HIDDEN_DIM, s)
+        call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
+             B, D, HIDDEN_DIM, s)
+
+    def encode_backward(self, x, buf, n=None):
+        """buf.dml (grad w.r.t. the interleaved mu/logvar output) -> encoder weight grads."""
+        s = _stream()
+        B = x.shape[0] if n is None else n
+        c, H, _ = self.img_size
+        ws = ptr(self._ws)
+        call("dvae_linear_wgrad", ptr(buf.h2), ptr(buf.dml), ptr(self.g("encoder.mu_logvar_gen.weight")),
+             ptr(self.g("encoder.mu_logvar_gen.bias")), B, HIDDEN_DIM, 2 * self.latent_dim, s)
+        call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
+             ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, s)
+        call("dvae_linear_wgrad", ptr(buf.h1), ptr(buf.gh2), ptr(self.g("encoder.lin2.weight")),
+             ptr(self.g("encoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, s)
+        call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
+             B, HIDDEN_DIM, HIDDEN_DIM, s)
+        call("dvae_linear_wgrad", ptr(buf.a_flat), ptr(buf.gh1), ptr(self.g("encoder.lin1.weight")),
+             ptr(self.g("encoder.lin1.bias")), B, HID * 16, HIDDEN_DIM, s)
+        call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
+             ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, s)
+        last = len(self.enc_names) - 1
+        call("dvae_relayout", ptr(buf.ga_flat), NCHW, ptr(buf.enc_gact[last]), B, HID, 4, 4, s)
+        for k in range(last, -1, -1):
+            name = self.enc_names[k]
+            h_in = self.enc_sizes[k] * 2
+            if k > 0:
+                x_in, x_layout, cin = buf.enc_act[k - 1], NHWC, HID
+            else:
+                x_in, x_layout, cin = x, NCHW, c
+            dy = buf.enc_gact[k]
+            call("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), NHWC, ptr(self.g("encoder.%s.weight" % name)),
+                 ptr(self.g("encoder.%s.bias" % name)), B, cin, h_in, h_in, HID, ws, s)
+            if k > 0:
+                call("dvae_conv4s2_dgrad", ptr(dy), NHWC, ptr(self.p("encoder.%s.weight" % name)), ptr(x_in),
+                     ptr(buf.enc_gact[k - 1]), NHWC, B, cin, h_in, h_in, HID, s)

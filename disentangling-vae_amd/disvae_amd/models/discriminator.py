@@ -1,0 +1,127 @@
+"""FactorVAE discriminator (disvae/models/discriminator.py): 6-layer MLP
+latent_dim -> 1000 x5 -> 2 with LeakyReLU(0.2); forward / backward are chains of the fp32
+MFMA GEMM kernel of libdvae_hip.so.  Parameters live in one flat arena like the VAE's."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from ..engine import ParamArena
+from .. import _lib
+from .._lib import call, ptr, ACT_NONE, ACT_LEAKY02
+from ..utils.initialization import reference_init_
+
+
+class _Layer(nn.Module):
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.weight = nn.Parameter(weight)
+        self.bias = nn.Parameter(bias)
+
+
+class Discriminator(nn.Module):
+    def __init__(self, neg_slope=0.2, latent_dim=10, hidden_units=1000):
+        super().__init__()
+        if neg_slope != 0.2:
+            raise ValueError("the HIP epilogue implements LeakyReLU(0.2) only (discriminator.py:11)")
+        self.neg_slope = neg_slope
+        self.z_dim = latent_dim
+        self.hidden_units = hidden_units
+        dims = [latent_dim] + [hidden_units] * 5 + [2]
+        self.dims = dims
+        shapes = OrderedDict()
+        for i in range(6):
+            shapes["lin%d.weight" % (i + 1)] = (dims[i + 1], dims[i])
+            shapes["lin%d.bias" % (i + 1)] = (dims[i + 1],)
+        self._arena = ParamArena(shapes, "cpu")
+        self._layer_names = ["lin%d" % (i + 1) for i in range(6)]
+        for n in self._layer_names:
+            self.add_module(n, _Layer(self._arena.view(n + ".weight"), self._arena.view(n + ".bias")))
+        self._acts = {}
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """discriminator.py:72-73 (weights_init => kaiming_uniform 'relu' on every Linear)."""
+        dev = self._arena.flat.device
+        if dev.type != "cpu":
+            self._move(torch.device("cpu"))
+        reference_init_(self._arena, self._layer_names)
+        if dev.type != "cpu":
+            self._move(dev)
+
+    def _move(self, device):
+        self._arena.to(device)
+        for n in self._layer_names:
+            layer = getattr(self, n)
+            layer.weight.data = self._arena.view(n + ".weight")
+            layer.bias.data = self._arena.view(n + ".bias")
+        self._acts = {}
+
+    def _apply(self, fn, *args, **kwargs):
+        new_flat = fn(self._arena.flat)
+        if new_flat.dtype != torch.float32:
+            raise TypeError("the HIP engine computes in fp32 only")
+        if new_flat.device != self._arena.flat.device:
+            self._move(new_flat.device)
+        return self
+
+    @property
+    def arena(self):
+        return self._arena
+
+    def assign_grads(self):
+        for n in self._layer_names:
+            layer = getattr(self, n)
+            layer.weight.grad = self._arena.view(n + ".weight", grad=True)
+            layer.bias.grad = self._arena.view(n + ".bias", grad=True)
+
+    # ---- raw (non-autograd) engine used by FactorKLoss ------------------------------------
+    def _buffers(self, M):
+        b = self._acts.get(M)
+        if b is None:
+            dev = self._arena.flat.device
+            f = lambda n: torch.empty(M, n, dtype=torch.float32, device=dev)
+            b = dict(h=[f(self.dims[i + 1]) for i in range(6)],           # outputs of lin1..lin6
+                     g=[f(self.dims[i]) for i in range(6)],               # grads w.r.t. inputs of lin1..lin6
+                     g2=[f(self.dims[i]) for i in range(6)])              # second (dgrad-only) chain
+            self._acts[M] = b
+        return b
+
+    def forward_raw(self, z, M):
+        """z[M,latent] -> logits[M,2] (discriminator.py:60-70); activations kept for backward."""
+        if self._arena.flat.device.type != "cuda":
+            raise _lib.DvaeHipError("the native Discriminator computes only on an MI355X (no CPU fallback)")
+        s = torch.cuda.current_stream().cuda_stream
+        b = self._buffers(M)
+        x = z
+        for i, n in enumerate(self._layer_names):
+            act = ACT_LEAKY02 if i < 5 else ACT_NONE
+            call("dvae_linear_fwd", ptr(x), ptr(self._arena.view(n + ".weight")), ptr(self._arena.view(n + ".bias")),
+                 ptr(b["h"][i]), M, self.dims[i], self.dims[i + 1], act, s)
+            x = b["h"][i]
+        return x
+
+    def backward_raw(self, z, g_logits, M, rows=None, wgrad=True, chain="g"):
+        """Back-propagate g_logits[rows,2] through the MLP evaluated by forward_raw(z, M).
+        rows < M restricts to the first `rows` samples (dgrad-only chain of quirk Q1).
+        Returns the gradient w.r.t. z ([rows, latent])."""
+        s = torch.cuda.current_stream().cuda_stream
+        b = self._buffers(M)
+        R = M if rows is None else rows
+        dy = g_logits
+        for i in range(5, -1, -1):
+            n = self._layer_names[i]
+            x_in = z if i == 0 else b["h"][i - 1]
+            if wgrad:
+                call("dvae_linear_wgrad", ptr(x_in), ptr(dy), ptr(self._arena.view(n + ".weight", grad=True)),
+                     ptr(self._arena.view(n + ".bias", grad=True)), R, self.dims[i], self.dims[i + 1], s)
+            gx = b[chain][i]
+            call("dvae_linear_dgrad", ptr(dy), ptr(self._arena.view(n + ".weight")), None if i == 0 else ptr(x_in),
+                 ACT_LEAKY02 if i > 0 else ACT_NONE, ptr(gx), R, self.dims[i], self.dims[i + 1], s)
+            dy = gx
+        return dy
+
+    def forward(self, z):
+        """nn.Module-style call (inference / evaluation); returns detached logits."""
+        M = z.shape[0]
+        return self.forward_raw(z.contiguous(), M).clone()

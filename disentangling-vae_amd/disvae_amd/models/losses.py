@@ -1,0 +1,569 @@
+"""Loss plugins with the API of disvae/models/losses.py (get_loss_f, BaseLoss, BetaHLoss,
+BetaBLoss, FactorKLoss, BtcvaeLoss, LOSSES, RECON_DIST) on the HIP kernels.
+
+Two ways in:
+  * ``loss(data, recon, latent_dist, is_train, storer, latent_sample=...)`` -- the reference
+    signature (losses.py:78); returns a 0-d tensor wired into autograd through thin
+    torch.autograd.Function wrappers around the kernels, so the reference's own
+    Trainer / Evaluator code keeps working with the native model;
+  * ``loss.fused_step(data, model, optimizer, storer)`` -- what the native Trainer uses: one
+    stream of kernel launches for forward + loss + backward (no autograd graph, gradients
+    land in the flat arena, all scalars in one small device buffer), then optimizer.step().
+Host-side state (n_train_steps, annealing, storer cadence) follows losses.py:71-75,105-114.
+"""
+import abc
+
+import torch
+
+from .. import _lib
+from .._lib import call, ptr
+from ..utils.math import log_importance_weights
+from .discriminator import Discriminator
+
+LOSSES = ["VAE", "betaH", "betaB", "factor", "btcvae"]  # losses.py:17
+RECON_DIST = ["bernoulli", "laplace", "gaussian"]        # losses.py:18
+
+
+def get_loss_f(loss_name, **kwargs_parse):
+    """losses.py:22-49 -- same keys consumed."""
+    kwargs_all = dict(rec_dist=kwargs_parse["rec_dist"], steps_anneal=kwargs_parse["reg_anneal"])
+    if loss_name == "betaH":
+        return BetaHLoss(beta=kwargs_parse["betaH_B"], **kwargs_all)
+    elif loss_name == "VAE":
+        return BetaHLoss(beta=1, **kwargs_all)
+    elif loss_name == "betaB":
+        return BetaBLoss(C_init=kwargs_parse["betaB_initC"], C_fin=kwargs_parse["betaB_finC"],
+                         gamma=kwargs_parse["betaB_G"], **kwargs_all)
+    elif loss_name == "factor":
+        return FactorKLoss(kwargs_parse["device"], gamma=kwargs_parse["factor_G"],
+                           disc_kwargs=dict(latent_dim=kwargs_parse["latent_dim"]),
+                           optim_kwargs=dict(lr=kwargs_parse["lr_disc"], betas=(0.5, 0.9)), **kwargs_all)
+    elif loss_name == "btcvae":
+        return BtcvaeLoss(kwargs_parse["n_data"], alpha=kwargs_parse["btcvae_A"], beta=kwargs_parse["btcvae_B"],
+                          gamma=kwargs_parse["btcvae_G"], **kwargs_all)
+    else:
+        assert loss_name not in LOSSES
+        raise ValueError("Uknown loss : {}".format(loss_name))
+
+
+def linear_annealing(init, fin, step, annealing_steps):
+    """losses.py:511-518."""
+    if annealing_steps == 0:
+        return fin
+    assert fin > init
+    delta = fin - init
+    return min(init + delta * step / annealing_steps, fin)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Scratch:
+    """Small device buffers shared by the loss kernels of one loss object."""
+
+    def __init__(self, device):
+        f = lambda n: torch.zeros(n, dtype=torch.float32, device=device)
+        self.device = device
+        self.coef = f(_lib.NCOEF)
+        self.coef_host = [0.0] * _lib.NCOEF
+        self.scal = f(_lib.NSCAL)
+        self.packed = f(_lib.NPACK)
+        self.partials = f(_lib.REC_NPART)
+        self.kl_dim = f(16)
+        self.disc_sums = f(4)
+        self.log_w = f(4)
+        self._log_w_key = None
+        self.rowstats = None
+        self.lat = {}
+
+    def set_coef(self, **kw):
+        h = self.coef_host
+        for k, v in kw.items():
+            h[getattr(_lib, "C_" + k)] = float(v)
+        # values travel as kernel arguments: ordered with the stream, no host sync
+        call("dvae_set_coef", ptr(self.coef), *h, _stream())
+
+    def set_log_w(self, batch, n_data):
+        key = (batch, n_data)
+        if key != self._log_w_key:
+            self.log_w[:3].copy_(log_importance_weights(batch, n_data))
+            self._log_w_key = key
+
+    def latent(self, name, rows, cols):
+        t = self.lat.get((name, rows, cols))
+        if t is None:
+            t = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
+            self.lat[(name, rows, cols)] = t
+        return t
+
+
+class BaseLoss(abc.ABC):
+    """losses.py:53-114."""
+
+    def __init__(self, record_loss_every=50, rec_dist="bernoulli", steps_anneal=0):
+        self.n_train_steps = 0
+        self.record_loss_every = record_loss_every
+        self.rec_dist = rec_dist
+        self.steps_anneal = steps_anneal
+        self._scratch = None
+        self.comm = None   # set by disvae_amd.parallel.DataParallel for sharded batches
+
+    @abc.abstractmethod
+    def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):
+        pass
+
+    def _pre_call(self, is_train, storer):
+        if is_train:
+            self.n_train_steps += 1
+        if not is_train or self.n_train_steps % self.record_loss_every == 1:
+            storer = storer
+        else:
+            storer = None
+        return storer
+
+    def scratch(self, device):
+        if self._scratch is None or self._scratch.device != device:
+            self._scratch = _Scratch(device)
+        return self._scratch
+
+    def _rec_code(self):
+        if self.rec_dist not in _lib.REC:
+            assert self.rec_dist not in RECON_DIST
+            raise ValueError("Unkown distribution: {}".format(self.rec_dist))  # losses.py:442
+        return _lib.REC[self.rec_dist]
+
+    # world size / rank of the data-parallel group (1 / 0 without a communicator)
+    def _world(self):
+        return (1, 0) if self.comm is None else (self.comm.world_size, self.comm.rank)
+
+    @staticmethod
+    def _store_common(storer, vals, D):
+        storer['recon_loss'].append(vals[_lib.S_REC])
+
+    @staticmethod
+    def _store_kl(storer, vals, D):
+        storer['kl_loss'].append(vals[_lib.S_KL])
+        for i in range(D):
+            storer['kl_loss_' + str(i)].append(vals[_lib.S_KL0 + i])
+
+
+# ------------------------------------------------------------------------------------------
+# autograd-compatible pieces (reference call signature)
+# ------------------------------------------------------------------------------------------
+class _ReconLossFn(torch.autograd.Function):
+    """_reconstruction_loss (losses.py:394-449): sum over pixels / batch."""
+
+    @staticmethod
+    def forward(ctx, recon, data, dist_code, scratch):
+        recon, data = recon.contiguous(), data.contiguous()
+        B = recon.shape[0]
+        scratch.set_coef(INV_B=1.0 / B)
+        g = torch.empty_like(recon)
+        call("dvae_recon_loss", ptr(recon), ptr(data), recon.numel(), dist_code, ptr(scratch.coef),
+             ptr(scratch.partials), ptr(g), 0, _stream())
+        ctx.save_for_backward(g)
+        return scratch.partials.sum() / B
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        return g * gout, None, None, None
+
+
+class _KLFn(torch.autograd.Function):
+    """_kl_normal_loss (losses.py:452-480) -> per-dim KL [D] (mean over batch)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, scratch):
+        B, D = mu.shape
+        ml = torch.stack((mu, logvar), dim=-1).reshape(B, 2 * D).contiguous()
+        scratch.set_coef(INV_B=1.0 / B)
+        tmp = torch.empty(3, B, D, dtype=torch.float32, device=mu.device)
+        kl_dim = torch.empty(16, dtype=torch.float32, device=mu.device)
+        call("dvae_reparam_kl_fwd", ptr(ml), None, ptr(tmp[0]), ptr(tmp[1]), ptr(tmp[2]), ptr(kl_dim),
+             ptr(scratch.coef), B, D, _stream())
+        ctx.save_for_backward(mu, logvar)
+        return kl_dim[:D].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        mu, logvar = ctx.saved_tensors
+        B = mu.shape[0]
+        gmu = gout.unsqueeze(0) * mu / B
+        glv = gout.unsqueeze(0) * 0.5 * (logvar.exp() - 1) / B
+        return gmu, glv, None
+
+
+class _BtcvaeFn(torch.autograd.Function):
+    """_get_log_pz_qz_prodzi_qzCx + the three batch means (losses.py:364-373, 523-544) ->
+    tensor [mi, tc, dw_kl]; backward through dvae_btcvae_bwd for each requested term."""
+
+    @staticmethod
+    def forward(ctx, z, mu, logvar, n_data, is_mss, scratch):
+        z, mu, logvar = z.contiguous(), mu.contiguous(), logvar.contiguous()
+        B, D = z.shape
+        scratch.set_log_w(B, n_data)
+        rowstats = torch.empty(B, 16, dtype=torch.float32, device=z.device)
+        call("dvae_btcvae_fwd", ptr(z), ptr(mu), ptr(logvar), B, D, 0, B, int(is_mss), ptr(scratch.log_w),
+             ptr(rowstats), _stream())
+        s = rowstats[:, :4].sum(0) / B   # log_pz, log_qz, log_prod_qzi, log_q_zCx
+        ctx.save_for_backward(z, mu, logvar, rowstats)
+        ctx.is_mss, ctx.scratch = is_mss, scratch
+        return torch.stack((s[3] - s[1], s[1] - s[2], s[2] - s[0]))
+
+    @staticmethod
+    def backward(ctx, gout):
+        z, mu, logvar, rowstats = ctx.saved_tensors
+        B, D = z.shape
+        # d(a*mi + b*tc + c*dw)/d(.) with (alpha, beta, gamma*anneal) = (a, b, c)
+        a, b, c = [float(v) for v in gout.tolist()]
+        coef = torch.zeros(_lib.NCOEF, dtype=torch.float32)
+        coef[_lib.C_ALPHA], coef[_lib.C_BETA], coef[_lib.C_GAMMA], coef[_lib.C_ANNEAL] = a, b, c, 1.0
+        coef = coef.to(z.device)
+        dz, dmu, dlv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        call("dvae_btcvae_bwd", ptr(z), ptr(mu), ptr(logvar), ptr(rowstats), B, D, 0, B, int(ctx.is_mss),
+             ptr(ctx.scratch.log_w), ptr(coef), ptr(dz), ptr(dmu), ptr(dlv), _stream())
+        return dz, dmu, dlv, None, None, None
+
+
+def _reconstruction_loss(data, recon_data, distribution="bernoulli", storer=None, scratch=None):
+    """losses.py:394-449."""
+    if distribution not in _lib.REC:
+        assert distribution not in RECON_DIST
+        raise ValueError("Unkown distribution: {}".format(distribution))
+    scratch = scratch or _Scratch(recon_data.device)
+    loss = _ReconLossFn.apply(recon_data, data, _lib.REC[distribution], scratch)
+    if distribution == "laplace":
+        loss = loss * (loss != 0)
+    if storer is not None:
+        storer['recon_loss'].append(loss.item())
+    return loss
+
+
+def _kl_normal_loss(mean, logvar, storer=None, scratch=None):
+    """losses.py:452-480."""
+    scratch = scratch or _Scratch(mean.device)
+    latent_kl = _KLFn.apply(mean, logvar, scratch)
+    total_kl = latent_kl.sum()
+    if storer is not None:
+        storer['kl_loss'].append(total_kl.item())
+        for i in range(mean.size(1)):
+            storer['kl_loss_' + str(i)].append(latent_kl[i].item())
+    return total_kl
+
+
+def _permute_dims(latent_sample, perms=None):
+    """losses.py:483-508; the permutations are drawn with torch.randperm on the CPU generator
+    like the reference (:505) unless injected (perms: int64 [D,B])."""
+    B, D = latent_sample.shape
+    if perms is None:
+        perms = torch.stack([torch.randperm(B) for _ in range(D)])
+    perms = perms.to(device=latent_sample.device, dtype=torch.int64).contiguous()
+    out = torch.empty_like(latent_sample)
+    call("dvae_permute_dims", ptr(latent_sample.contiguous()), ptr(perms), ptr(out), B, D, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# loss classes
+# ------------------------------------------------------------------------------------------
+class _SingleOptimizerLoss(BaseLoss):
+    """Shared fused step of BetaH / BetaB / Btcvae (training.py:152-158 + the loss __call__)."""
+
+    KIND = None
+
+    def _coefs(self, is_train):
+        raise NotImplementedError
+
+    def _store(self, storer, vals, D):
+        raise NotImplementedError
+
+    def fused_step(self, data, model, optimizer, storer, eps=None):
+        is_train = model.training
+        storer = self._pre_call(is_train, storer)
+        eng = model.engine
+        B, D = data.shape[0], model.latent_dim
+        world, rank = self._world()
+        Bg = B * world
+        buf = eng.buffers(B)
+        sc = self.scratch(data.device)
+        sc.set_coef(INV_B=1.0 / Bg, **self._coefs(is_train))
+        s = _stream()
+        if is_train and eps is None:
+            eps = torch.randn(B, D, dtype=torch.float32, device=data.device)   # vae.py:67
+        if not is_train:
+            eps = None
+        data = data.contiguous()
+        eng.encode(data, buf)
+        eng.reparam(buf, eps, sc.kl_dim, sc.coef)
+        eng.decode(buf.z, buf)
+        call("dvae_recon_loss", ptr(buf.recon), ptr(data), buf.recon.numel(), self._rec_code(), ptr(sc.coef),
+             ptr(sc.partials), ptr(buf.g_logit), 1, s)
+        rowstats = None
+        if self.KIND == _lib.LOSS_BTCVAE:
+            zg, mug, lvg = buf.z, buf.mu, buf.logvar
+            if world > 1:
+                zg, mug, lvg = self.comm.all_gather_latents(buf.z, buf.mu, buf.logvar)
+            sc.set_log_w(Bg, self.n_data)
+            rowstats = sc.latent("rowstats", B, 16)
+            call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Bg, D, rank * B, B, int(self.is_mss), ptr(sc.log_w),
+                 ptr(rowstats), s)
+        call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
+        if world > 1:
+            self.comm.all_reduce(sc.packed)
+        call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), s)
+        if is_train:
+            dz_x = dmu_x = dlv_x = None
+            if self.KIND == _lib.LOSS_BTCVAE:
+                dz_x = sc.latent("dz_tc", B, D)
+                dmu_all, dlv_all = sc.latent("dmu_all", Bg, D), sc.latent("dlv_all", Bg, D)
+                call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Bg, D, rank * B, B,
+                     int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), s)
+                if world > 1:
+                    dmu_x, dlv_x = self.comm.reduce_scatter_cols(dmu_all, dlv_all)
+                else:
+                    dmu_x, dlv_x = dmu_all, dlv_all
+            eng.decode_backward(buf.z, buf)
+            if dz_x is not None:
+                call("dvae_add", ptr(buf.dz), ptr(dz_x), ptr(buf.dz), buf.dz.numel(), s)
+            call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dmu_x), ptr(dlv_x), ptr(buf.mu), ptr(buf.logvar), ptr(eps),
+                 ptr(sc.scal), ptr(sc.coef), ptr(buf.dml), B, D, s)
+            eng.encode_backward(data, buf)
+            if world > 1:
+                self.comm.all_reduce(model.arena.grad)
+            model.assign_grads()          # optimizer.zero_grad(); loss.backward()  (training.py:156-157)
+            optimizer.step()              # training.py:158
+        if storer is not None:
+            vals = sc.scal.tolist()       # ONE device->host copy for every logged scalar
+            self._store(storer, vals, D)
+        return sc.scal[_lib.S_LOSS]
+
+
+class BetaHLoss(_SingleOptimizerLoss):
+    """losses.py:117-153."""
+    KIND = _lib.LOSS_BETAH
+
+    def __init__(self, beta=4, **kwargs):
+        super().__init__(**kwargs)
+        self.beta = beta
+
+    def _coefs(self, is_train):
+        anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
+        return dict(ANNEAL=anneal, BETA=self.beta)
+
+    def _store(self, storer, vals, D):
+        storer['recon_loss'].append(vals[_lib.S_REC])
+        self._store_kl(storer, vals, D)
+        storer['loss'].append(vals[_lib.S_LOSS])
+
+    def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):
+        storer = self._pre_call(is_train, storer)
+        sc = self.scratch(recon_data.device)
+        rec_loss = _reconstruction_loss(data, recon_data, storer=storer, distribution=self.rec_dist, scratch=sc)
+        kl_loss = _kl_normal_loss(*latent_dist, storer, scratch=sc)
+        anneal_reg = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
+        loss = rec_loss + anneal_reg * (self.beta * kl_loss)
+        if storer is not None:
+            storer['loss'].append(loss.item())
+        return loss
+
+
+class BetaBLoss(_SingleOptimizerLoss):
+    """losses.py:156-202."""
+    KIND = _lib.LOSS_BETAB
+
+    def __init__(self, C_init=0., C_fin=20., gamma=100., **kwargs):
+        super().__init__(**kwargs)
+        self.gamma = gamma
+        self.C_init = C_init
+        self.C_fin = C_fin
+
+    def _capacity(self, is_train):
+        return (linear_annealing(self.C_init, self.C_fin, self.n_train_steps, self.steps_anneal)
+                if is_train else self.C_fin)
+
+    def _coefs(self, is_train):
+        return dict(ANNEAL=1.0, BETA=self.gamma, CAP=self._capacity(is_train))
+
+    def _store(self, storer, vals, D):
+        storer['recon_loss'].append(vals[_lib.S_REC])
+        self._store_kl(storer, vals, D)
+        storer['loss'].append(vals[_lib.S_LOSS])
+
+    def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):
+        storer = self._pre_call(is_train, storer)
+        sc = self.scratch(recon_data.device)
+        rec_loss = _reconstruction_loss(data, recon_data, storer=storer, distribution=self.rec_dist, scratch=sc)
+        kl_loss = _kl_normal_loss(*latent_dist, storer, scratch=sc)
+        C = self._capacity(is_train)
+        loss = rec_loss + self.gamma * (kl_loss - C).abs()
+        if storer is not None:
+            storer['loss'].append(loss.item())
+        return loss
+
+
+class BtcvaeLoss(_SingleOptimizerLoss):
+    """losses.py:316-391 (is_mss=True default, never overridden by get_loss_f)."""
+    KIND = _lib.LOSS_BTCVAE
+
+    def __init__(self, n_data, alpha=1., beta=6., gamma=1., is_mss=True, **kwargs):
+        super().__init__(**kwargs)
+        self.n_data = n_data
+        self.beta = beta
+        self.alpha = alpha
+        self.gamma = gamma
+        self.is_mss = is_mss
+
+    def _coefs(self, is_train):
+        anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
+        return dict(ANNEAL=anneal, ALPHA=self.alpha, BETA=self.beta, GAMMA=self.gamma)
+
+    def _store(self, storer, vals, D):
+        storer['recon_loss'].append(vals[_lib.S_REC])
+        storer['loss'].append(vals[_lib.S_LOSS])
+        storer['mi_loss'].append(vals[_lib.S_MI])
+        storer['tc_loss'].append(vals[_lib.S_TC])
+        storer['dw_kl_loss'].append(vals[_lib.S_DWKL])
+        self._store_kl(storer, vals, D)
+
+    def __call__(self, data, recon_batch, latent_dist, is_train, storer, latent_sample=None):
+        storer = self._pre_call(is_train, storer)
+        sc = self.scratch(recon_batch.device)
+        rec_loss = _reconstruction_loss(data, recon_batch, storer=storer, distribution=self.rec_dist, scratch=sc)
+        terms = _BtcvaeFn.apply(latent_sample, latent_dist[0], latent_dist[1], self.n_data, self.is_mss, sc)
+        mi_loss, tc_loss, dw_kl_loss = terms[0], terms[1], terms[2]
+        anneal_reg = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
+        loss = rec_loss + (self.alpha * mi_loss + self.beta * tc_loss + anneal_reg * self.gamma * dw_kl_loss)
+        if storer is not None:
+            storer['loss'].append(loss.item())
+            storer['mi_loss'].append(mi_loss.item())
+            storer['tc_loss'].append(tc_loss.item())
+            storer['dw_kl_loss'].append(dw_kl_loss.item())
+            with torch.no_grad():
+                _ = _kl_normal_loss(latent_dist[0].detach(), latent_dist[1].detach(), storer, scratch=sc)
+        return loss
+
+
+class FactorKLoss(BaseLoss):
+    """losses.py:205-313.  ``call_optimize`` runs the whole two-optimizer iteration on the HIP
+    kernels, including quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1 because the
+    reference does not detach d_z and steps the VAE optimizer after d_tc_loss.backward())."""
+
+    def __init__(self, device, gamma=10., disc_kwargs={}, optim_kwargs=dict(lr=5e-5, betas=(0.5, 0.9)), **kwargs):
+        super().__init__(**kwargs)
+        self.gamma = gamma
+        self.device = device
+        self.discriminator = Discriminator(**disc_kwargs).to(self.device)
+        self.optimizer_d = torch.optim.Adam(self.discriminator.parameters(), **optim_kwargs)
+
+    def __call__(self, *args, **kwargs):
+        raise ValueError("Use `call_optimize` to also train the discriminator")  # losses.py:240-241
+
+    def call_optimize(self, data, model, optimizer, storer, noise=None):
+        """noise: optional (eps1[Bh,D], eps2[Bh,D], perms int64[D,Bh]) injected for parity;
+        by default eps are drawn on the device and the permutations with torch.randperm on the
+        CPU generator, in the reference's order (losses.py:254,286,505)."""
+        is_train = model.training
+        storer = self._pre_call(is_train, storer)
+        eng = model.engine
+        disc = self.discriminator
+        D = model.latent_dim
+        B = data.size(0)
+        Bh = B // 2
+        world, rank = self._world()
+        Bhg = Bh * world
+        dev = data.device
+        s = _stream()
+        sc = self.scratch(dev)
+        anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
+        sc.set_coef(INV_B=1.0 / Bhg, ANNEAL=anneal, BETA=self.gamma)
+        data = data.contiguous()
+        if noise is not None:
+            eps1, eps2, perms = noise
+        elif is_train:
+            eps1 = torch.randn(Bh, D, dtype=torch.float32, device=dev)
+            eps2 = torch.randn(Bh, D, dtype=torch.float32, device=dev)
+            perms = None
+        else:
+            eps1 = eps2 = perms = None
+        buf = eng.buffers(B)
+        n_enc = 2 * Bh if is_train else Bh
+        eng.encode(data, buf, n=n_enc)                                # data1 and data2 in one pass
+        # reparameterise the two halves (KL only over data1, denominator = half batch; losses.py:255-259)
+        call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps1), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(sc.kl_dim),
+             ptr(sc.coef), Bh, D, s)
+        eng.decode(buf.z, buf, n=Bh)
+        call("dvae_recon_loss", ptr(buf.recon), ptr(data), Bh * data[0].numel(), self._rec_code(), ptr(sc.coef),
+             ptr(sc.partials), ptr(buf.g_logit), 1, s)
+        if not is_train:
+            # evaluation: vae_loss only (losses.py:276-278); discriminator on z1
+            logits = disc.forward_raw(buf.z, Bh)
+            g_dtc = sc.latent("g_dtc", 2 * Bh, 2)
+            lg2 = sc.latent("lg2", 2 * Bh, 2)
+            lg2[:Bh].copy_(logits[:Bh]); lg2[Bh:].copy_(logits[:Bh])
+            call("dvae_disc_losses", ptr(lg2), Bh, ptr(sc.coef), ptr(sc.disc_sums), ptr(g_dtc), None, s)
+            call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), s)
+            if world > 1:
+                self.comm.all_reduce(sc.packed)
+            call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), s)
+            if storer is not None:
+                vals = sc.scal.tolist()
+                storer['recon_loss'].append(vals[_lib.S_REC])
+                self._store_kl(storer, vals, D)
+                storer['loss'].append(vals[_lib.S_LOSS])
+                storer['tc_loss'].append(vals[_lib.S_TC])
+            return sc.scal[_lib.S_LOSS]
+        off = Bh
+        call("dvae_reparam_kl_fwd", ptr(buf.ml[off:]), ptr(eps2), ptr(buf.mu[off:]), ptr(buf.logvar[off:]),
+             ptr(buf.z[off:]), None, None, Bh, D, s)                  # sample_latent(data2), losses.py:286
+        # z_perm: permute across the (global) half batch, losses.py:287
+        zin = sc.latent("disc_in", 2 * Bh, D)
+        zin[:Bh].copy_(buf.z[:Bh])
+        z2 = buf.z[off:off + Bh]
+        if world > 1:
+            z2g = self.comm.all_gather_rows(z2)
+        else:
+            z2g = z2
+        if perms is None:
+            perms = torch.stack([torch.randperm(Bhg) for _ in range(D)])   # CPU generator (shared seed across ranks)
+        perms = perms.to(device=dev, dtype=torch.int64).contiguous()
+        zperm_g = sc.latent("zperm_g", Bhg, D)
+        call("dvae_permute_dims", ptr(z2g.contiguous()), ptr(perms), ptr(zperm_g), Bhg, D, s)
+        zin[Bh:].copy_(zperm_g[rank * Bh:(rank + 1) * Bh])
+        logits = disc.forward_raw(zin, 2 * Bh)                        # D(z1) and D(z_perm) in one pass
+        g_dtc = sc.latent("g_dtc", 2 * Bh, 2)
+        g_tc = sc.latent("g_tc", Bh, 2)
+        call("dvae_disc_losses", ptr(logits), Bh, ptr(sc.coef), ptr(sc.disc_sums), ptr(g_dtc), ptr(g_tc), s)
+        if world > 1:
+            # the CE / tc means run over the global half batch
+            g_dtc.mul_(1.0 / world); g_tc.mul_(1.0 / world)
+        call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), s)
+        if world > 1:
+            self.comm.all_reduce(sc.packed)
+        call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), s)
+        # discriminator backward of d_tc_loss (weight grads + dz), losses.py:303-304
+        dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
+        # tc term of vae_loss through D: dgrad only, first half (its disc weight grads are zeroed at :303)
+        dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2")
+        eng.decode_backward(buf.z, buf, n=Bh)
+        call("dvae_add", ptr(buf.dz), ptr(dz_a), ptr(buf.dz), Bh * D, s)      # quirk Q1
+        call("dvae_add", ptr(buf.dz), ptr(dz_b), ptr(buf.dz), Bh * D, s)
+        call("dvae_reparam_kl_bwd", ptr(buf.dz), None, None, ptr(buf.mu), ptr(buf.logvar), ptr(eps1), ptr(sc.scal),
+             ptr(sc.coef), ptr(buf.dml), Bh, D, s)
+        eng.encode_backward(data, buf, n=Bh)
+        if world > 1:
+            self.comm.all_reduce(model.arena.grad)
+            self.comm.all_reduce(disc.arena.grad)
+        model.assign_grads()
+        disc.assign_grads()
+        optimizer.step()              # losses.py:307
+        self.optimizer_d.step()       # losses.py:308
+        if storer is not None:
+            vals = sc.scal.tolist()
+            storer['recon_loss'].append(vals[_lib.S_REC])
+            self._store_kl(storer, vals, D)
+            storer['loss'].append(vals[_lib.S_LOSS])
+            storer['tc_loss'].append(vals[_lib.S_TC])
+            storer['discrim_loss'].append(vals[_lib.S_DTC])
+        return sc.scal[_lib.S_LOSS]

@@ -1,0 +1,166 @@
+/*
+ * libdvae_hip.so -- C-ABI of the MI355X (gfx950) kernels behind the disvae training step.
+ *
+ * The reference (YannDubs/disentangling-vae) is pure Python on torch.nn and has NO native
+ * FFI for this path: every entry point below replaces the ATen call(s) that the cited
+ * reference line reaches through torch.nn / torch.nn.functional / autograd.  The host side
+ * (disentangling-vae_amd/disvae_amd) binds them with ctypes; see INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to fp32 (int64 where stated); sizes are element counts;
+ *   - `stream` is a hipStream_t passed as void*; calls only ENQUEUE work (no allocation, no
+ *     synchronisation, no ownership transfer); workspace is caller-provided;
+ *   - return 0 on success, <0 on invalid argument / launch error (text via dvae_last_error());
+ *   - re-entrant per stream; safe to capture into a hipGraph.
+ *   - layouts: DVAE_NCHW (reference / API boundary) or DVAE_NHWC (engine-internal, 32-channel
+ *     activations); weights always keep the reference's state_dict shapes.
+ */
+#ifndef DVAE_HIP_H
+#define DVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVAE_VERSION 100
+
+enum { DVAE_NCHW = 0, DVAE_NHWC = 1 };
+enum { DVAE_ACT_NONE = 0, DVAE_ACT_RELU = 1, DVAE_ACT_LEAKY02 = 2, DVAE_ACT_SIGMOID = 3 };
+enum { DVAE_REC_BERNOULLI = 0, DVAE_REC_GAUSSIAN = 1, DVAE_REC_LAPLACE = 2 };
+enum { DVAE_LOSS_BETAH = 0, DVAE_LOSS_BETAB = 1, DVAE_LOSS_BTCVAE = 2, DVAE_LOSS_FACTOR = 3 };
+
+/* scalar slots written by dvae_loss_finalize (float[DVAE_NSCAL]) */
+enum {
+  DVAE_S_LOSS = 0, DVAE_S_REC = 1, DVAE_S_KL = 2, DVAE_S_KL0 = 3 /* ..3+D-1, D<=16 */,
+  DVAE_S_MI = 19, DVAE_S_TC = 20, DVAE_S_DWKL = 21, DVAE_S_KLW = 22, DVAE_S_DTC = 23,
+  DVAE_NSCAL = 32
+};
+/* coefficient slots read by the loss kernels (float[DVAE_NCOEF], host-written every step) */
+enum {
+  DVAE_C_INV_B = 0,   /* 1 / (reconstruction+KL batch denominator) */
+  DVAE_C_ANNEAL = 1,  /* linear_annealing value of this step */
+  DVAE_C_BETA = 2,    /* betaH beta | betaB gamma | btcvae beta | factor gamma */
+  DVAE_C_ALPHA = 3,   /* btcvae alpha */
+  DVAE_C_GAMMA = 4,   /* btcvae gamma */
+  DVAE_C_CAP = 5,     /* betaB capacity C of this step */
+  DVAE_NCOEF = 8
+};
+
+int dvae_version(void);
+const char* dvae_last_error(void);
+
+/* ---- Conv2d(k=4,s=2,p=1): encoders.py:54-60,73-77 (nn.Conv2d + torch.relu) -------------
+ * x[N,Cin,H,W] -> y[N,Cout,H/2,W/2], w[Cout,Cin,4,4], y = act(conv(x,w)+b).               */
+int dvae_conv4s2_fwd(const float* x, int x_layout, const float* w, const float* b, float* y,
+                     int y_layout, int N, int Cin, int H, int W, int Cout, int act, void* stream);
+/* autograd of the above (training.py:157 loss.backward): dy is the gradient w.r.t. the
+ * PRE-activation output; dx = conv_dgrad(dy,w) (* [x_act > 0] when x_act != NULL, i.e. the
+ * ReLU backward of the producing layer fused in).  H,W are the dims of x.                   */
+int dvae_conv4s2_dgrad(const float* dy, int dy_layout, const float* w, const float* x_act, float* dx,
+                       int dx_layout, int N, int Cin, int H, int W, int Cout, void* stream);
+/* dw[Cout,Cin,4,4] = sum x (*) dy ; db[Cout] = sum dy (db may be NULL).
+ * ws: workspace of at least dvae_conv_wgrad_ws_floats() floats.                             */
+int dvae_conv4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_layout, float* dw,
+                       float* db, int N, int Cin, int H, int W, int Cout, float* ws, void* stream);
+
+/* ---- ConvTranspose2d(k=4,s=2,p=1): decoders.py:57-65,77-82 ------------------------------
+ * x[N,Cin,H,W] -> y[N,Cout,2H,2W], w[Cin,Cout,4,4]; act in {none, relu, sigmoid}.          */
+int dvae_convT4s2_fwd(const float* x, int x_layout, const float* w, const float* b, float* y,
+                      int y_layout, int N, int Cin, int H, int W, int Cout, int act, void* stream);
+/* dx[N,Cin,H,W] from dy[N,Cout,2H,2W] (pre-activation grad), fused ReLU mask like above.   */
+int dvae_convT4s2_dgrad(const float* dy, int dy_layout, const float* w, const float* x_act, float* dx,
+                        int dx_layout, int N, int Cin, int H, int W, int Cout, void* stream);
+int dvae_convT4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_layout, float* dw,
+                        float* db, int N, int Cin, int H, int W, int Cout, float* ws, void* stream);
+size_t dvae_conv_wgrad_ws_floats(void);
+
+/* NCHW <-> NHWC re-layout of a [N,C,H,W] tensor (the flatten of encoders.py:80 /
+ * the view of decoders.py:74 are in c,h,w order; the engine's conv activations are NHWC).  */
+int dvae_relayout(const float* src, int src_layout, float* dst, int N, int C, int H, int W, void* stream);
+
+/* ---- nn.Linear: encoders.py:63-67,81-86; decoders.py:53-55,71-73; discriminator.py:51-68 --
+ * y[M,N] = act(x[M,K] w[N,K]^T + b[N]);  act in {none, relu, leaky 0.2}.                    */
+int dvae_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N,
+                    int act, void* stream);
+/* dx[M,K] = dy[M,N] w[N,K], times act'(x_act) when x_act != NULL (x_act = the post-activation
+ * input of this layer, i.e. the ReLU / LeakyReLU backward of the previous layer fused in). */
+int dvae_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx,
+                      int M, int K, int N, void* stream);
+/* dw[N,K] = dy^T x ; db[N] = column sums of dy (db may be NULL).                            */
+int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N,
+                      void* stream);
+
+/* ---- reparameterisation + per-dim Gaussian KL: vae.py:52-71, losses.py:452-480 -----------
+ * ml[B,2D] is the interleaved output of mu_logvar_gen (encoders.py:87: mu = ml[:,0::2],
+ * logvar = ml[:,1::2]).  z = mu + exp(.5 logvar) eps (eps == NULL: z = mu, eval mode).
+ * kl_dim[D] (may be NULL) = coef[INV_B] * sum_b 0.5(-1 - lv + mu^2 + e^lv).                 */
+int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z,
+                        float* kl_dim, const float* coef, int B, int D, void* stream);
+/* dml[B,2D] (interleaved) from dz[B,D] and optional direct grads dmu_x/dlv_x[B,D];
+ * the KL term enters with weight scal[DVAE_S_KLW] * coef[INV_B].                            */
+int dvae_reparam_kl_bwd(const float* dz, const float* dmu_x, const float* dlv_x, const float* mu,
+                        const float* logvar, const float* eps, const float* scal, const float* coef,
+                        float* dml, int B, int D, void* stream);
+
+/* ---- reconstruction likelihood: losses.py:394-449 (F.binary_cross_entropy / mse / l1) ----
+ * recon, target: [n] elements.  partials[DVAE_REC_NPART] receives per-block partial sums of
+ * the un-normalised loss; g[n] (may be NULL) = coef[INV_B] * dLoss/d(pre-sigmoid logit)
+ * when wrt_logit != 0 (the logit gradient is what the fused backward consumes).            */
+#define DVAE_REC_NPART 512
+int dvae_recon_loss(const float* recon, const float* target, long n, int dist, const float* coef,
+                    float* partials, float* g, int wrt_logit, void* stream);
+/* wrt_logit == 0: g is the gradient w.r.t. `recon` itself (autograd-compatible path).      */
+/* out[n] = grad_y * (1 - y) * y : backward of the final torch.sigmoid (decoders.py:82).     */
+int dvae_sigmoid_bwd(const float* grad_y, const float* y, float* out, long n, void* stream);
+
+/* ---- beta-TCVAE estimator: losses.py:523-544, utils/math.py:8-73 --------------------------
+ * z,mu,logvar: [Bg,D] (the whole -- global -- batch); this call evaluates rows
+ * [row0,row0+Bl).  log_w = {log(1/N), log(strat), log(1/M)} in fp32 as the reference
+ * computes them (math.py:66-73), ignored when is_mss == 0.
+ * rowstats[Bl,16]: log_pz, log_qz, log_prod_qzi, log_q_zCx, lse_d[0..D-1].                  */
+int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg, int D, int row0,
+                    int Bl, int is_mss, const float* log_w, float* rowstats, void* stream);
+/* gradient of alpha*mi + beta*tc + anneal*gamma*dw_kl (means over Bg rows) restricted to
+ * rows [row0,row0+Bl): dz[Bl,D] (local rows), dmu_all/dlv_all[Bg,D] (column sums over the
+ * local rows; reduce over ranks when the batch is sharded).                                 */
+int dvae_btcvae_bwd(const float* z, const float* mu, const float* logvar, const float* rowstats,
+                    int Bg, int D, int row0, int Bl, int is_mss, const float* log_w,
+                    const float* coef, float* dz, float* dmu_all, float* dlv_all, void* stream);
+
+/* ---- FactorVAE pieces: losses.py:261-265,293-295,483-508 ----------------------------------*/
+/* out[b,d] = z[perm[d*B+b], d]; perm int64 [D,B] (torch.randperm per latent dim).          */
+int dvae_permute_dims(const float* z, const int64_t* perm, float* out, int B, int D, void* stream);
+/* dlogits[2*Bh,2]: rows [0,Bh) = D(z1), rows [Bh,2Bh) = D(z_perm).  sums[4] receives
+ * {sum(d_z[:,0]-d_z[:,1]), sum CE(d_z,0), sum CE(d_z_perm,1), 0};
+ * g_dtc[2Bh,2] = d(0.5(CE+CE))/dlogits; g_tc[Bh,2] = coef[ANNEAL]*coef[BETA]/Bh * [+1,-1]. */
+int dvae_disc_losses(const float* dlogits, int Bh, const float* coef, float* sums, float* g_dtc,
+                     float* g_tc, void* stream);
+
+/* ---- scalar epilogue of the loss plugins: losses.py:139-153,186-202,268-274,369-389 -------
+ * dvae_loss_pack reduces this rank's partial sums into packed[DVAE_NPACK]:
+ *   [0] sum of rec_partials, [1..16] kl_dim, [17..20] column sums of rowstats[:,0..3]
+ *   (log_pz, log_qz, log_prod_qzi, log_q_zCx), [21..23] discriminator sums.
+ * When the batch is sharded over ranks, sum-all-reduce `packed` before dvae_loss_finalize.
+ * dvae_loss_finalize(kind = DVAE_LOSS_*) writes scal[DVAE_NSCAL]; Bg = global batch
+ * (btcvae) or global half batch (factor).                                                   */
+#define DVAE_NPACK 32
+int dvae_loss_pack(const float* rec_partials, const float* kl_dim, int D, const float* rowstats, int Bl,
+                   const float* disc_sums, float* packed, void* stream);
+int dvae_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal,
+                       void* stream);
+
+/* coef[0..7] <- the eight values (passed as kernel arguments: in-order with the stream, no
+ * host buffer whose lifetime must outlive the launch).                                      */
+int dvae_set_coef(float* coef, float c0, float c1, float c2, float c3, float c4, float c5, float c6,
+                  float c7, void* stream);
+
+/* out[i] = a[i] + b[i] (n elements), helper for merging latent gradients (quirk Q1).       */
+int dvae_add(const float* a, const float* b, float* out, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVAE_HIP_H */

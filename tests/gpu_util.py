@@ -1,0 +1,58 @@
+"""Helpers for the -m gpu parity tests: every call goes through the C-ABI (ctypes)."""
+import os
+import contextlib
+
+import numpy as np
+import torch
+
+from disvae_amd import _lib
+from disvae_amd._lib import call, ptr
+
+DEV = "cuda"
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev(t):
+    return t.detach().to(DEV, torch.float32).contiguous()
+
+
+def nhwc(t):
+    """NCHW torch tensor -> NHWC-contiguous device buffer."""
+    return dev(t.permute(0, 2, 3, 1).contiguous())
+
+
+def from_nhwc(t, N, C, H, W):
+    return t.view(N, H, W, C).permute(0, 3, 1, 2).cpu()
+
+
+@contextlib.contextmanager
+def force_generic(flag):
+    old = os.environ.get("DVAE_FORCE_GENERIC")
+    os.environ["DVAE_FORCE_GENERIC"] = "1" if flag else "0"
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("DVAE_FORCE_GENERIC", None)
+        else:
+            os.environ["DVAE_FORCE_GENERIC"] = old
+
+
+def check(got, ref, rtol=1e-4, atol_rel=2e-5, what=""):
+    """got: device/cpu fp32 tensor; ref: cpu tensor (fp64 preferred)."""
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what + ": non-finite values"
+    scale = ref.abs().max().item()
+    err = (got - ref).abs()
+    tol = atol_rel * scale + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError("%s: %d/%d mismatches, max abs err %.3e (scale %.3e), first at %s: got %.6e ref %.6e"
+                             % (what, int(bad.sum()), bad.numel(), err.max().item(), scale, idx,
+                                got[tuple(idx)].item(), ref[tuple(idx)].item()))

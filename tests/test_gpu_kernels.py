@@ -1,0 +1,282 @@
+"""-m gpu: every HIP kernel through the C-ABI vs torch CPU (fp64 accumulation) on the same
+seeded inputs.  Tolerance: rtol 1e-4 plus 2e-5 x max|ref| (fp32 accumulation-order noise)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import *  # noqa
+from gpu_util import _lib  # noqa
+from oracle import disvae_oracle as O
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+CONV_CASES = [
+    # N, Cin, H, x_layout                 (Cout = 32, y NHWC)
+    (3, 1, 64, _lib.NCHW), (5, 3, 64, _lib.NCHW),          # conv1 (thin, MFMA K=16C)
+    (3, 32, 32, _lib.NHWC), (70, 32, 32, _lib.NHWC),       # conv2 (MFMA HS=16; 280 units > 256 workgroups)
+    (5, 32, 16, _lib.NHWC), (6, 32, 8, _lib.NHWC), (9, 32, 8, _lib.NHWC),   # conv3 / conv_64 (tails)
+    (2, 1, 32, _lib.NCHW),                                  # MNIST geometry -> generic kernel
+]
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("N,Cin,H,xl", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(N, Cin, H, xl, generic):
+    if generic and N > 9:
+        pytest.skip("large case only for the tuned path")
+    Cout = 32
+    x = _rand(N, Cin, H, H, seed=1)
+    w = _rand(Cout, Cin, 4, 4, seed=2, scale=0.2)
+    b = _rand(Cout, seed=3, scale=0.1)
+    xd = nhwc(x) if xl == _lib.NHWC else dev(x)
+    wd, bd = dev(w), dev(b)
+    y = torch.empty(N, H // 2, H // 2, Cout, device=DEV)
+    with force_generic(generic):
+        call("dvae_conv4s2_fwd", ptr(xd), xl, ptr(wd), ptr(bd), ptr(y), _lib.NHWC, N, Cin, H, H, Cout, _lib.ACT_RELU, stream())
+        ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+        check(from_nhwc(y, N, Cout, H // 2, H // 2), ref, what="conv fwd")
+        # wgrad + bias grad
+        dy = _rand(N, Cout, H // 2, H // 2, seed=4)
+        dyd = nhwc(dy)
+        ws = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), device=DEV)
+        dw, db = torch.full((Cout, Cin, 4, 4), 7.0, device=DEV), torch.full((Cout,), 7.0, device=DEV)
+        call("dvae_conv4s2_wgrad", ptr(xd), xl, ptr(dyd), _lib.NHWC, ptr(dw), ptr(db), N, Cin, H, H, Cout, ptr(ws), stream())
+        xr = x.double().requires_grad_(True)
+        wr = w.double().requires_grad_(True)
+        br = b.double().requires_grad_(True)
+        out = F.conv2d(xr, wr, br, stride=2, padding=1)
+        out.backward(dy.double())
+        check(dw, wr.grad, what="conv wgrad")
+        check(db, br.grad, what="conv bias grad")
+        # dgrad with fused ReLU mask of the producing layer
+        if Cin == 32:
+            xact = torch.relu(_rand(N, Cin, H, H, seed=5))
+            dx = torch.empty(N, H, H, Cin, device=DEV)
+            call("dvae_conv4s2_dgrad", ptr(dyd), _lib.NHWC, ptr(wd), ptr(nhwc(xact)), ptr(dx), _lib.NHWC, N, Cin, H, H, Cout, stream())
+            check(from_nhwc(dx, N, Cin, H, H), xr.grad * (xact > 0), what="conv dgrad")
+
+
+CONVT_CASES = [
+    # N, H(in), Cout, y_layout, act
+    (3, 4, 32, _lib.NHWC, _lib.ACT_RELU), (6, 4, 32, _lib.NHWC, _lib.ACT_RELU), (5, 8, 32, _lib.NHWC, _lib.ACT_RELU),
+    (3, 16, 32, _lib.NHWC, _lib.ACT_RELU), (70, 16, 32, _lib.NHWC, _lib.ACT_RELU),
+    (3, 32, 1, _lib.NCHW, _lib.ACT_SIGMOID), (5, 32, 3, _lib.NCHW, _lib.ACT_SIGMOID),
+    (2, 16, 1, _lib.NCHW, _lib.ACT_SIGMOID),
+]
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("N,H,Cout,yl,act", CONVT_CASES)
+def test_convT_fwd_dgrad_wgrad(N, H, Cout, yl, act, generic):
+    if generic and N > 9:
+        pytest.skip("large case only for the tuned path")
+    Cin = 32
+    x = torch.relu(_rand(N, Cin, H, H, seed=1))
+    w = _rand(Cin, Cout, 4, 4, seed=2, scale=0.2)
+    b = _rand(Cout, seed=3, scale=0.1)
+    xd, wd, bd = nhwc(x), dev(w), dev(b)
+    H2 = 2 * H
+    y = torch.empty((N, H2, H2, Cout) if yl == _lib.NHWC else (N, Cout, H2, H2), device=DEV)
+    with force_generic(generic):
+        call("dvae_convT4s2_fwd", ptr(xd), _lib.NHWC, ptr(wd), ptr(bd), ptr(y), yl, N, Cin, H, H, Cout, act, stream())
+        xr = x.double().requires_grad_(True)
+        wr = w.double().requires_grad_(True)
+        br = b.double().requires_grad_(True)
+        pre = F.conv_transpose2d(xr, wr, br, stride=2, padding=1)
+        ref = torch.relu(pre) if act == _lib.ACT_RELU else torch.sigmoid(pre)
+        got = from_nhwc(y, N, Cout, H2, H2) if yl == _lib.NHWC else y
+        check(got, ref, what="convT fwd")
+        dy = _rand(N, Cout, H2, H2, seed=4)
+        pre.backward(dy.double())
+        dyd = nhwc(dy) if yl == _lib.NHWC else dev(dy)
+        ws = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), device=DEV)
+        dw, db = torch.full((Cin, Cout, 4, 4), 7.0, device=DEV), torch.full((Cout,), 7.0, device=DEV)
+        call("dvae_convT4s2_wgrad", ptr(xd), _lib.NHWC, ptr(dyd), yl, ptr(dw), ptr(db), N, Cin, H, H, Cout, ptr(ws), stream())
+        check(dw, wr.grad, what="convT wgrad")
+        check(db, br.grad, what="convT bias grad")
+        dx = torch.empty(N, H, H, Cin, device=DEV)
+        call("dvae_convT4s2_dgrad", ptr(dyd), yl, ptr(wd), ptr(xd), ptr(dx), _lib.NHWC, N, Cin, H, H, Cout, stream())
+        check(from_nhwc(dx, N, Cin, H, H), xr.grad * (x > 0), what="convT dgrad")
+
+
+def test_relayout():
+    x = _rand(5, 32, 4, 4)
+    a = nhwc(x)
+    out = torch.empty(5, 512, device=DEV)
+    call("dvae_relayout", ptr(a), _lib.NHWC, ptr(out), 5, 32, 4, 4, stream())
+    assert torch.equal(out.cpu(), x.reshape(5, 512))
+    back = torch.empty(5, 4, 4, 32, device=DEV)
+    call("dvae_relayout", ptr(out), _lib.NCHW, ptr(back), 5, 32, 4, 4, stream())
+    assert torch.equal(back.cpu(), x.permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("M,K,N,act", [(7, 10, 256, _lib.ACT_RELU), (130, 512, 256, _lib.ACT_RELU),
+                                        (33, 256, 20, _lib.ACT_NONE), (64, 1000, 1000, _lib.ACT_LEAKY02),
+                                        (256, 10, 1000, _lib.ACT_LEAKY02), (100, 1000, 2, _lib.ACT_NONE),
+                                        (1, 256, 512, _lib.ACT_RELU)])
+def test_linear(M, K, N, act):
+    x = _rand(M, K, seed=1)
+    w = _rand(N, K, seed=2, scale=1 / math.sqrt(K))
+    b = _rand(N, seed=3, scale=0.1)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.empty(M, N, device=DEV)
+    call("dvae_linear_fwd", ptr(xd), ptr(wd), ptr(bd), ptr(y), M, K, N, act, stream())
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    pre = F.linear(xr, wr, br)
+    ref = {0: pre, 1: torch.relu(pre), 2: F.leaky_relu(pre, 0.2)}[act]
+    check(y, ref, what="linear fwd")
+    dy = _rand(M, N, seed=4)
+    pre.backward(dy.double())
+    dyd = dev(dy)
+    dw, db = torch.full((N, K), 7.0, device=DEV), torch.full((N,), 7.0, device=DEV)
+    call("dvae_linear_wgrad", ptr(xd), ptr(dyd), ptr(dw), ptr(db), M, K, N, stream())
+    check(dw, wr.grad, what="linear wgrad")
+    check(db, br.grad, what="linear bias grad")
+    xact = _rand(M, K, seed=5)
+    for mact in (_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_LEAKY02):
+        dx = torch.empty(M, K, device=DEV)
+        call("dvae_linear_dgrad", ptr(dyd), ptr(wd), ptr(dev(xact)) if mact else None, mact, ptr(dx), M, K, N, stream())
+        mult = {0: torch.ones_like(xact), 1: (xact > 0).float(), 2: torch.where(xact > 0, 1.0, 0.2)}[mact]
+        check(dx, xr.grad * mult.double(), what="linear dgrad act=%d" % mact)
+
+
+@pytest.mark.parametrize("B", [2, 8, 200, 1500])
+def test_reparam_kl(B):
+    D = 10
+    ml = _rand(B, 2 * D, seed=1, scale=1.5)
+    eps = torch.randn(B, D, generator=torch.Generator().manual_seed(2))
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / B
+    mld, epsd, coefd = dev(ml), dev(eps), dev(coef)
+    mu, lv, z = (torch.empty(B, D, device=DEV) for _ in range(3))
+    kl = torch.zeros(16, device=DEV)
+    call("dvae_reparam_kl_fwd", ptr(mld), ptr(epsd), ptr(mu), ptr(lv), ptr(z), ptr(kl), ptr(coefd), B, D, stream())
+    m_ref, l_ref = ml.view(B, D, 2).unbind(-1)
+    assert torch.equal(mu.cpu(), m_ref) and torch.equal(lv.cpu(), l_ref)
+    check(z, O.reparameterize(m_ref.double(), l_ref.double(), eps.double()), what="z")
+    check(kl[:D], O.kl_normal_loss(m_ref.double(), l_ref.double())[1], what="kl_dim")
+    call("dvae_reparam_kl_fwd", ptr(mld), None, ptr(mu), ptr(lv), ptr(z), None, None, B, D, stream())
+    assert torch.equal(z.cpu(), m_ref)      # eval mode: z = mean (vae.py:69-71)
+    # backward
+    dz, dmx, dlx = _rand(B, D, seed=3), _rand(B, D, seed=4), _rand(B, D, seed=5)
+    scal = torch.zeros(_lib.NSCAL); scal[_lib.S_KLW] = 2.5
+    dml = torch.empty(B, 2 * D, device=DEV)
+    call("dvae_reparam_kl_bwd", ptr(dev(dz)), ptr(dev(dmx)), ptr(dev(dlx)), ptr(dev(m_ref)), ptr(dev(l_ref)), ptr(epsd),
+         ptr(dev(scal)), ptr(coefd), ptr(dml), B, D, stream())
+    mr, lr = m_ref.double().requires_grad_(True), l_ref.double().requires_grad_(True)
+    zz = O.reparameterize(mr, lr, eps.double())
+    obj = (zz * dz.double()).sum() + (mr * dmx.double()).sum() + (lr * dlx.double()).sum() + 2.5 * O.kl_normal_loss(mr, lr)[0]
+    obj.backward()
+    ref = torch.stack((mr.grad, lr.grad), -1).reshape(B, 2 * D)
+    check(dml, ref, what="dml")
+
+
+@pytest.mark.parametrize("dist", ["bernoulli", "gaussian", "laplace"])
+def test_recon_loss(dist):
+    B, C, H = 6, 3, 64
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(B, C, H, H, generator=g) * 3
+    logits.view(-1)[:8] = torch.tensor([40., -40., 20., -20., 17., -17., 90., -90.])   # saturated sigmoids / clamps
+    x = torch.rand(B, C, H, H, generator=g)
+    x.view(-1)[:4] = torch.tensor([0., 1., 1., 0.])
+    recon = torch.sigmoid(logits)
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / B
+    parts = torch.empty(_lib.REC_NPART, device=DEV)
+    gl = torch.empty_like(recon, device=DEV)
+    call("dvae_recon_loss", ptr(dev(recon)), ptr(dev(x)), recon.numel(), _lib.REC[dist], ptr(dev(coef)), ptr(parts), ptr(gl), 1, stream())
+    ref = O.reconstruction_loss(x, recon, dist)        # fp32, like the reference
+    check(parts.sum() / B, ref, rtol=2e-5, what="recon loss " + dist)
+    lr = logits.clone().requires_grad_(True)
+    O.reconstruction_loss(x, torch.sigmoid(lr), dist).backward()
+    check(gl, lr.grad, rtol=1e-4, atol_rel=1e-6, what="dL/dlogit " + dist)
+    gr = torch.empty_like(recon, device=DEV)
+    call("dvae_recon_loss", ptr(dev(recon)), ptr(dev(x)), recon.numel(), _lib.REC[dist], ptr(dev(coef)), ptr(parts), ptr(gr), 0, stream())
+    rr = recon.clone().requires_grad_(True)
+    O.reconstruction_loss(x, rr, dist).backward()
+    check(gr, rr.grad, rtol=1e-4, atol_rel=1e-6, what="dL/drecon " + dist)
+    out = torch.empty_like(recon, device=DEV)
+    call("dvae_sigmoid_bwd", ptr(gr), ptr(dev(recon)), ptr(out), recon.numel(), stream())
+    check(out, lr.grad, rtol=1e-4, atol_rel=1e-6, what="sigmoid bwd")
+
+
+@pytest.mark.parametrize("B,n_data,mss", [(4, 100, True), (4, 100, False), (8, 737280, True), (64, 202599, True),
+                                          (256, 737280, True), (1024, 202599, True), (100, 5000, True)])
+def test_btcvae_fwd_bwd(B, n_data, mss):
+    D = 10
+    if B == 4:   # the RNG-free KAT of SURVEY 8c uses D = 3: embed it in D = 10 is not possible; use random D=10 too
+        pass
+    g = torch.Generator().manual_seed(B)
+    mu = torch.randn(B, D, generator=g)
+    lv = torch.randn(B, D, generator=g) * 0.7 - 0.5
+    eps = torch.randn(B, D, generator=g)
+    z = mu + torch.exp(0.5 * lv) * eps
+    from disvae_amd.utils.math import log_importance_weights
+    lw = torch.zeros(4); lw[:3] = log_importance_weights(B, n_data)
+    rs = torch.empty(B, 16, device=DEV)
+    zd, mud, lvd, lwd = dev(z), dev(mu), dev(lv), dev(lw)
+    call("dvae_btcvae_fwd", ptr(zd), ptr(mud), ptr(lvd), B, D, 0, B, int(mss), ptr(lwd), ptr(rs), stream())
+    ref = O.btcvae_log_densities(z.double(), mu.double(), lv.double(), n_data, mss)
+    for k, nm in enumerate(["log_pz", "log_qz", "log_prod_qzi", "log_q_zCx"]):
+        check(rs[:, k], ref[k], rtol=2e-6, atol_rel=2e-6, what=nm)
+    ref32 = O.btcvae_log_densities(z, mu, lv, n_data, mss)     # and against the fp32 reference arithmetic
+    for k in range(4):
+        check(rs[:, k], ref32[k], rtol=1e-5, atol_rel=1e-5, what="fp32 col %d" % k)
+    # row-sharded evaluation gives the same rows (data-parallel path)
+    half = B // 2
+    rs2 = torch.empty(B - half, 16, device=DEV)
+    call("dvae_btcvae_fwd", ptr(zd), ptr(mud), ptr(lvd), B, D, half, B - half, int(mss), ptr(lwd), ptr(rs2), stream())
+    assert torch.equal(rs2.cpu(), rs[half:].cpu())
+    # backward of alpha*mi + beta*tc + anneal*gamma*dw
+    alpha, beta, gamma, anneal = 1.0, 6.4, 1.5, 0.37
+    coef = torch.zeros(_lib.NCOEF)
+    coef[_lib.C_ALPHA], coef[_lib.C_BETA], coef[_lib.C_GAMMA], coef[_lib.C_ANNEAL] = alpha, beta, gamma, anneal
+    dz, dmu, dlv = (torch.empty(B, D, device=DEV) for _ in range(3))
+    call("dvae_btcvae_bwd", ptr(zd), ptr(mud), ptr(lvd), ptr(rs), B, D, 0, B, int(mss), ptr(lwd), ptr(dev(coef)),
+         ptr(dz), ptr(dmu), ptr(dlv), stream())
+    zr, mr, lr = (t.double().requires_grad_(True) for t in (z, mu, lv))
+    mi, tc, dw = O.btcvae_terms(zr, mr, lr, n_data, mss)
+    (alpha * mi + beta * tc + anneal * gamma * dw).backward()
+    check(dz, zr.grad, rtol=2e-4, atol_rel=1e-5, what="dz")
+    check(dmu, mr.grad, rtol=2e-4, atol_rel=1e-5, what="dmu")
+    check(dlv, lr.grad, rtol=2e-4, atol_rel=1e-5, what="dlv")
+    # sharded backward: column sums add up, row grads are the local rows
+    dza, dma, dla = (torch.empty(half, D, device=DEV), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV))
+    dzb, dmb, dlb = (torch.empty(B - half, D, device=DEV), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV))
+    call("dvae_btcvae_bwd", ptr(zd), ptr(mud), ptr(lvd), ptr(rs), B, D, 0, half, int(mss), ptr(lwd), ptr(dev(coef)),
+         ptr(dza), ptr(dma), ptr(dla), stream())
+    call("dvae_btcvae_bwd", ptr(zd), ptr(mud), ptr(lvd), ptr(rs2), B, D, half, B - half, int(mss), ptr(lwd), ptr(dev(coef)),
+         ptr(dzb), ptr(dmb), ptr(dlb), stream())
+    check(torch.cat((dza, dzb)), zr.grad, rtol=2e-4, atol_rel=1e-5, what="sharded dz")
+    check(dma + dmb, mr.grad, rtol=2e-4, atol_rel=1e-5, what="sharded dmu")
+    check(dla + dlb, lr.grad, rtol=2e-4, atol_rel=1e-5, what="sharded dlv")
+
+
+def test_permute_dims_and_disc_losses():
+    B, D = 37, 10
+    z = _rand(B, D, seed=1)
+    perms = torch.stack([torch.randperm(B, generator=torch.Generator().manual_seed(d)) for d in range(D)])
+    out = torch.empty(B, D, device=DEV)
+    call("dvae_permute_dims", ptr(dev(z)), ptr(perms.to(DEV)), ptr(out), B, D, stream())
+    assert torch.equal(out.cpu(), O.permute_dims(z, list(perms)))
+    Bh = 50
+    lg = _rand(2 * Bh, 2, seed=2, scale=3)
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_ANNEAL], coef[_lib.C_BETA] = 0.3, 6.4
+    sums, g_dtc, g_tc = torch.empty(4, device=DEV), torch.empty(2 * Bh, 2, device=DEV), torch.empty(Bh, 2, device=DEV)
+    call("dvae_disc_losses", ptr(dev(lg)), Bh, ptr(dev(coef)), ptr(sums), ptr(g_dtc), ptr(g_tc), stream())
+    lr = lg.double().requires_grad_(True)
+    d_z, d_zp = lr[:Bh], lr[Bh:]
+    tc = (d_z[:, 0] - d_z[:, 1]).mean()
+    ce0 = F.cross_entropy(d_z, torch.zeros(Bh, dtype=torch.long))
+    ce1 = F.cross_entropy(d_zp, torch.ones(Bh, dtype=torch.long))
+    check(sums[:3], torch.stack((tc * Bh, ce0 * Bh, ce1 * Bh)), what="disc sums")
+    (0.5 * (ce0 + ce1)).backward()
+    check(g_dtc, lr.grad, what="g_dtc")
+    ref_tc = torch.zeros(Bh, 2, dtype=torch.double); ref_tc[:, 0] = 0.3 * 6.4 / Bh; ref_tc[:, 1] = -0.3 * 6.4 / Bh
+    check(g_tc, ref_tc, what="g_tc")

@@ -1,0 +1,113 @@
+"""CPU: host-side logic of the native package (no kernels): API surface, parameter arena,
+state_dict compatibility, annealing / storer cadence, log importance weights."""
+import math
+from collections import defaultdict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import disvae_oracle as O
+from golden_util import load
+import disvae_amd
+from disvae_amd.models import losses as L
+from disvae_amd.models.vae import init_specific_model, VAE, MODELS
+from disvae_amd.models.discriminator import Discriminator
+from disvae_amd.utils.math import log_importance_weights
+
+
+def test_api_surface():
+    assert L.LOSSES == O.LOSSES == ["VAE", "betaH", "betaB", "factor", "btcvae"]
+    assert L.RECON_DIST == O.RECON_DIST and MODELS == ["Burgess"]
+    assert hasattr(disvae_amd, "Trainer") and hasattr(disvae_amd, "init_specific_model")
+    with pytest.raises(ValueError):
+        init_specific_model("Foo", (1, 32, 32), 10)
+    with pytest.raises(RuntimeError):
+        init_specific_model("Burgess", (1, 28, 28), 10)
+    with pytest.raises(ValueError):
+        L.get_loss_f("nope", rec_dist="bernoulli", reg_anneal=0)
+    kw = dict(rec_dist="bernoulli", reg_anneal=10000, betaH_B=4, betaB_initC=0, betaB_finC=25, betaB_G=1000,
+              factor_G=6.4, latent_dim=10, lr_disc=1e-4, btcvae_A=1, btcvae_B=6.4, btcvae_G=1, n_data=100,
+              device=torch.device("cpu"))
+    assert isinstance(L.get_loss_f("VAE", **kw), L.BetaHLoss) and L.get_loss_f("VAE", **kw).beta == 1
+    assert L.get_loss_f("betaH", **kw).beta == 4
+    b = L.get_loss_f("betaB", **kw)
+    assert (b.C_init, b.C_fin, b.gamma) == (0, 25, 1000)
+    t = L.get_loss_f("btcvae", **kw)
+    assert (t.n_data, t.alpha, t.beta, t.gamma, t.is_mss) == (100, 1, 6.4, 1, True)
+    f = L.get_loss_f("factor", **kw)
+    assert f.gamma == 6.4 and f.optimizer_d.defaults["betas"] == (0.5, 0.9) and f.optimizer_d.defaults["lr"] == 1e-4
+    with pytest.raises(ValueError):          # control-flow exception of losses.py:240-241
+        f(None, None, None, True, None)
+
+
+@pytest.mark.parametrize("img", [(1, 32, 32), (1, 64, 64), (3, 64, 64)])
+def test_same_seed_same_weights_and_state_dict(img):
+    torch.manual_seed(1234)
+    m = init_specific_model("Burgess", img, 10)
+    torch.manual_seed(1234)
+    ref = O.init_vae_params(img, 10)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert sd[k].shape == ref[k].shape and torch.equal(sd[k], ref[k]), k
+    n = sum(p.numel() for p in m.parameters())
+    assert n == {(1, 32, 32): 469173, (1, 64, 64): 502005, (3, 64, 64): 504055}[img]   # SURVEY 2b [probe]
+    # parameters are views into ONE flat arena; load_state_dict writes through
+    new = {k: torch.full_like(v, 0.5) for k, v in ref.items()}
+    m.load_state_dict(new)
+    assert float(m.arena.flat[:10].mean()) == 0.5
+    assert m.encoder.conv1.weight.data_ptr() == m.arena.flat.data_ptr()
+    m.assign_grads()
+    assert m.encoder.conv1.weight.grad.data_ptr() == m.arena.grad.data_ptr()
+
+
+def test_discriminator_init_matches():
+    torch.manual_seed(3)
+    d = Discriminator(latent_dim=10)
+    torch.manual_seed(3)
+    ref = O.init_disc_params(10)
+    assert sum(p.numel() for p in d.parameters()) == 4017002
+    for k, v in d.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+
+
+def test_annealing_and_storer_cadence():
+    assert L.linear_annealing(0, 1, 1, 10000) == 1e-4
+    assert L.linear_annealing(0, 25, 5000, 100000) == 1.25
+    assert L.linear_annealing(0, 1, 99, 0) == 1
+    assert L.linear_annealing(0, 1, 20000, 10000) == 1
+    with pytest.raises(AssertionError):
+        L.linear_annealing(1, 1, 1, 10)
+    lf = L.BetaHLoss(beta=4, rec_dist="bernoulli", steps_anneal=10)
+    kept = []
+    for i in range(1, 103):
+        s = lf._pre_call(True, defaultdict(list))
+        kept.append(s is not None)
+    assert [i + 1 for i, k in enumerate(kept) if k] == [1, 51, 101] and lf.n_train_steps == 102
+    assert lf._pre_call(False, {}) is not None and lf.n_train_steps == 102     # eval keeps the storer
+
+
+def test_log_importance_weights_match_matrix():
+    g = load("kats")
+    for (b, n) in [(4, 100), (8, 737280), (64, 202599)]:
+        W = g["kat_logiw_%d_%d" % (b, n)]
+        lw = log_importance_weights(b, n).numpy()
+        assert W[0, 0] == lw[0] and W[0, 1] == lw[1] and W[0, 2] == lw[2]
+        assert W[b - 2, 0] == lw[1]                       # the W[M-1, 0] exception cell
+        expect = np.full((b, b), lw[2], dtype=np.float32)
+        expect[:, 0] = lw[0]; expect[:, 1] = lw[1]; expect[b - 2, 0] = lw[1]
+        np.testing.assert_array_equal(W, expect)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from disvae_amd.utils.modelIO import save_model, load_model, load_metadata
+    torch.manual_seed(0)
+    m = init_specific_model("Burgess", (1, 32, 32), 10)
+    save_model(m, str(tmp_path))
+    meta = load_metadata(str(tmp_path))
+    assert meta["model_type"] == "Burgess" and meta["latent_dim"] == 10
+    m2 = load_model(str(tmp_path), is_gpu=False)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert not m2.training
