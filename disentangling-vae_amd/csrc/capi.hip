@@ -132,9 +132,10 @@ int dvae_linear_dgrad(const float* dy, const float* w, const float* x_act, int a
   return launch_linear_dgrad(dy, w, x_act, act, dx, M, K, N, (hipStream_t)stream);
 }
 
-int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, void* stream) {
+int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, float* ws,
+                      void* stream) {
   DVAE_CHECK_ARG(x && dy && dw && M > 0 && K > 0 && N > 0);
-  return launch_linear_wgrad(x, dy, dw, db, M, K, N, (hipStream_t)stream);
+  return launch_linear_wgrad(x, dy, dw, db, M, K, N, ws, dvae_conv_wgrad_ws_floats(), (hipStream_t)stream);
 }
 
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,

@@ -93,7 +93,8 @@ int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, 
                       hipStream_t s);
 int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
                         hipStream_t s);
-int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, hipStream_t s);
+int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, float* ws,
+                        size_t ws_floats, hipStream_t s);
 
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                           const float* coef, int B, int D, hipStream_t s);

@@ -47,91 +47,112 @@ template <> __device__ __forceinline__ int swz_small<8>(int row, int col) { retu
 template <> __device__ __forceinline__ int swz_small<4>(int row, int col) { return ((col >> 1) & 1) | ((row & 3) << 1); }
 
 // ---- staging helpers ----------------------------------------------------------------------
+// A thread stages the same 16-byte slots of every unit, so the slot -> (LDS offset, global offset,
+// row) decode (integer div/mod) is done ONCE per kernel; per unit only the image / row range
+// checks remain.
+template <int NPF>
+struct SlotDesc {
+  int lds[NPF];    // float offset of the (swizzled) LDS destination, -1: slot unused
+  int gofs[NPF];   // float offset of the source relative to the unit base pointer
+  int rimg[NPF];   // row-in-tile | (image-in-unit << 8) | (column valid << 16)
+};
+
 template <int HS>
-__device__ __forceinline__ void load_big(f32x4 (&pf)[Geo<HS>::BIG_NPF], const float* __restrict__ big, int unit,
-                                         int N, int tid) {
+__device__ __forceinline__ void init_big_slots(SlotDesc<Geo<HS>::BIG_NPF>& d, int tid) {
   using G = Geo<HS>;
-  const long P0 = (long)unit * G::U;
-  const int n0 = (int)(P0 / (HS * HS));
-  const int sy0 = (int)(P0 % (HS * HS)) / HS;
 #pragma unroll
   for (int k = 0; k < G::BIG_NPF; ++k) {
     int s = tid + k * 512;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    d.lds[k] = -1; d.gofs[k] = 0; d.rimg[k] = 0;
     if (s < G::BIG_SLOTS) {
       int chunk = s & 7;
       int t = s >> 3;
       int pc = t % G::BPC; t /= G::BPC;
       int r = t % G::BROWS;
       int img = t / G::BROWS;
-      int n = n0 + img, by = 2 * sy0 - 1 + r, bx = pc - 1;
-      if (n < N && by >= 0 && by < G::HB && bx >= 0 && bx < G::HB)
-        v = *reinterpret_cast<const f32x4*>(big + (((long)n * G::HB + by) * G::HB + bx) * 32 + chunk * 4);
-    }
-    pf[k] = v;
-  }
-}
-
-template <int HS>
-__device__ __forceinline__ void store_big(const f32x4 (&pf)[Geo<HS>::BIG_NPF], float* bt, int tid) {
-  using G = Geo<HS>;
-#pragma unroll
-  for (int k = 0; k < G::BIG_NPF; ++k) {
-    int s = tid + k * 512;
-    if (s < G::BIG_SLOTS) {
-      int chunk = s & 7;
-      int t = s >> 3;
-      int pc = t % G::BPC; t /= G::BPC;
-      int r = t % G::BROWS;
-      int img = t / G::BROWS;
-      int par = pc & 1, cw = pc >> 1;
-      float* dst = bt + (((img * G::BROWS + r) * 2 + par) * G::CW + cw) * 32 + ((chunk ^ swz_big<HS>(r, cw)) << 2);
-      *reinterpret_cast<f32x4*>(dst) = pf[k];
+      int par = pc & 1, cw = pc >> 1, bx = pc - 1;
+      d.lds[k] = (((img * G::BROWS + r) * 2 + par) * G::CW + cw) * 32 + ((chunk ^ swz_big<HS>(r, cw)) << 2);
+      d.gofs[k] = ((img * G::HB + (r - 1)) * G::HB + bx) * 32 + chunk * 4;
+      d.rimg[k] = r | (img << 8) | ((bx >= 0 && bx < G::HB) ? (1 << 16) : 0);
     }
   }
 }
 
 template <int HS>
-__device__ __forceinline__ void load_small_halo(f32x4 (&pf)[Geo<HS>::SH_NPF], const float* __restrict__ small,
-                                                int unit, int N, int tid) {
+__device__ __forceinline__ void load_big(f32x4 (&pf)[Geo<HS>::BIG_NPF], const SlotDesc<Geo<HS>::BIG_NPF>& d,
+                                         const float* __restrict__ big, int unit, int N) {
   using G = Geo<HS>;
   const long P0 = (long)unit * G::U;
   const int n0 = (int)(P0 / (HS * HS));
   const int sy0 = (int)(P0 % (HS * HS)) / HS;
+  const float* base = big + ((long)n0 * G::HB + 2 * sy0) * G::HB * 32;
 #pragma unroll
-  for (int k = 0; k < G::SH_NPF; ++k) {
-    int s = tid + k * 512;
+  for (int k = 0; k < G::BIG_NPF; ++k) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (s < G::SH_SLOTS) {
-      int chunk = s & 7;
-      int t = s >> 3;
-      int col = t % G::SCOLS; t /= G::SCOLS;
-      int row = t % G::SROWS;
-      int img = t / G::SROWS;
-      int n = n0 + img, sy = sy0 - 1 + row, sx = col - 1;
-      if (n < N && sy >= 0 && sy < HS && sx >= 0 && sx < HS)
-        v = *reinterpret_cast<const f32x4*>(small + (((long)n * HS + sy) * HS + sx) * 32 + chunk * 4);
-    }
+    const int r = d.rimg[k] & 0xff, img = (d.rimg[k] >> 8) & 0xff;
+    const int by = 2 * sy0 - 1 + r;
+    if ((d.rimg[k] >> 16) && n0 + img < N && by >= 0 && by < G::HB)
+      v = *reinterpret_cast<const f32x4*>(base + d.gofs[k]);
     pf[k] = v;
   }
 }
 
 template <int HS>
-__device__ __forceinline__ void store_small_halo(const f32x4 (&pf)[Geo<HS>::SH_NPF], float* st, int tid) {
+__device__ __forceinline__ void store_big(const f32x4 (&pf)[Geo<HS>::BIG_NPF], const SlotDesc<Geo<HS>::BIG_NPF>& d,
+                                          float* bt) {
+  using G = Geo<HS>;
+#pragma unroll
+  for (int k = 0; k < G::BIG_NPF; ++k)
+    if (d.lds[k] >= 0) *reinterpret_cast<f32x4*>(bt + d.lds[k]) = pf[k];
+}
+
+template <int HS>
+__device__ __forceinline__ void init_small_slots(SlotDesc<Geo<HS>::SH_NPF>& d, int tid) {
   using G = Geo<HS>;
 #pragma unroll
   for (int k = 0; k < G::SH_NPF; ++k) {
     int s = tid + k * 512;
+    d.lds[k] = -1; d.gofs[k] = 0; d.rimg[k] = 0;
     if (s < G::SH_SLOTS) {
       int chunk = s & 7;
       int t = s >> 3;
       int col = t % G::SCOLS; t /= G::SCOLS;
       int row = t % G::SROWS;
       int img = t / G::SROWS;
-      float* dst = st + ((img * G::SROWS + row) * G::SCOLS + col) * 32 + ((chunk ^ swz_small<HS>(row, col)) << 2);
-      *reinterpret_cast<f32x4*>(dst) = pf[k];
+      int sx = col - 1;
+      d.lds[k] = ((img * G::SROWS + row) * G::SCOLS + col) * 32 + ((chunk ^ swz_small<HS>(row, col)) << 2);
+      d.gofs[k] = ((img * HS + (row - 1)) * HS + sx) * 32 + chunk * 4;
+      d.rimg[k] = row | (img << 8) | ((sx >= 0 && sx < HS) ? (1 << 16) : 0);
     }
   }
+}
+
+template <int HS>
+__device__ __forceinline__ void load_small_halo(f32x4 (&pf)[Geo<HS>::SH_NPF], const SlotDesc<Geo<HS>::SH_NPF>& d,
+                                                const float* __restrict__ small, int unit, int N) {
+  using G = Geo<HS>;
+  const long P0 = (long)unit * G::U;
+  const int n0 = (int)(P0 / (HS * HS));
+  const int sy0 = (int)(P0 % (HS * HS)) / HS;
+  const float* base = small + ((long)n0 * HS + sy0) * HS * 32;
+#pragma unroll
+  for (int k = 0; k < G::SH_NPF; ++k) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int row = d.rimg[k] & 0xff, img = (d.rimg[k] >> 8) & 0xff;
+    const int sy = sy0 - 1 + row;
+    if ((d.rimg[k] >> 16) && n0 + img < N && sy >= 0 && sy < HS)
+      v = *reinterpret_cast<const f32x4*>(base + d.gofs[k]);
+    pf[k] = v;
+  }
+}
+
+template <int HS>
+__device__ __forceinline__ void store_small_halo(const f32x4 (&pf)[Geo<HS>::SH_NPF], const SlotDesc<Geo<HS>::SH_NPF>& d,
+                                                 float* st) {
+  using G = Geo<HS>;
+#pragma unroll
+  for (int k = 0; k < G::SH_NPF; ++k)
+    if (d.lds[k] >= 0) *reinterpret_cast<f32x4*>(st + d.lds[k]) = pf[k];
 }
 
 // weights w[cs][cb][16] -> LDS image wl[tap][kc/4][n][kc%4] where kc is the contracted channel
@@ -158,6 +179,7 @@ __device__ __forceinline__ float epilogue_act(float v, int act) {
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a)[3], (b)[3], acc, 0, 0, 0);
 
 // ---- down: big -> small ------------------------------------------------------------------
+#define SEL4(v, g, j) ((g) == 0 ? (v)[j] : (g) == 1 ? (v)[4 + (j)] : (g) == 2 ? (v)[8 + (j)] : (v)[12 + (j)])
 template <int HS>
 __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, const float* __restrict__ w,
                                                 const float* __restrict__ bias, const float* __restrict__ mask,
@@ -166,7 +188,7 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                    // 16384 floats
   float* bt = smem + 16384;            // G::BIG_FLOATS
-  float* red = bt + G::BIG_FLOATS;     // 2 * 3 * 16 * 64 floats
+  float* red = bt + G::BIG_FLOATS;     // [2 mt][4 owner][4 src][4 j][64 lanes] = 8192 floats
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int mt = wv & 1, kh = wv >> 1;
   const int i = lane & 31, h = lane >> 5;
@@ -174,16 +196,19 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
   const int img_l = p / (G::R * HS), sy_l = (p / HS) % G::R, sx = p % HS;
   const int r = 2 * sy_l + kh;
 
+  SlotDesc<G::BIG_NPF> sd;
+  init_big_slots<HS>(sd, tid);
   f32x4 pf[G::BIG_NPF];
   int unit = blockIdx.x;
-  if (unit < n_units) load_big<HS>(pf, big, unit, N, tid);
+  if (unit < n_units) load_big<HS>(pf, sd, big, unit, N);
   stage_weights<true>(w, wl, tid);
   const float bv = bias ? bias[i] : 0.f;
+  const long npix = (long)N * HS * HS;
 
   for (; unit < n_units; unit += gridDim.x) {
-    store_big<HS>(pf, bt, tid);
+    store_big<HS>(pf, sd, bt);
     __syncthreads();
-    if (unit + (int)gridDim.x < n_units) load_big<HS>(pf, big, unit + gridDim.x, N, tid);
+    if (unit + (int)gridDim.x < n_units) load_big<HS>(pf, sd, big, unit + gridDim.x, N);
 
     f32x16 acc;
 #pragma unroll
@@ -202,28 +227,24 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
         MFMA4(acc, a, b)
       }
     }
-    // reduce the 4 kh-slices of each M-tile through LDS
-    if (kh > 0) {
-      float* dst = red + ((mt * 3 + kh - 1) * 16) * 64 + lane;
+    // balanced reduction of the 4 kh-slices: wave (mt, kh) owns accumulator registers 4*kh .. 4*kh+3
 #pragma unroll
-      for (int e = 0; e < 16; ++e) dst[e * 64] = acc[e];
-    }
+    for (int e = 0; e < 16; ++e) red[(((mt * 4 + (e >> 2)) * 4 + kh) * 4 + (e & 3)) * 64 + lane] = acc[e];
     __syncthreads();
-    if (kh == 0) {
-      const long P0 = (long)unit * G::U + mt * 32;
+    const long P0 = (long)unit * G::U + mt * 32;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float v = acc[e];
+    for (int j = 0; j < 4; ++j) {
+      float v = SEL4(acc, kh, j);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) v += red[((mt * 3 + s) * 16 + e) * 64 + lane];
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-        const long pix = P0 + row;
-        if (pix < (long)N * HS * HS) {
-          const long o = pix * 32 + i;
-          v = epilogue_act(v + bv, act);
-          if (mask) v = mask[o] > 0.f ? v : 0.f;
-          out[o] = v;
-        }
+      for (int s = 0; s < 4; ++s)
+        if (s != kh) v += red[(((mt * 4 + kh) * 4 + s) * 4 + j) * 64 + lane];
+      const int row = j + 8 * kh + 4 * h;      // D-fragment row of register e = 4*kh + j
+      const long pix = P0 + row;
+      if (pix < npix) {
+        const long o = pix * 32 + i;
+        v = epilogue_act(v + bv, act);
+        if (mask) v = mask[o] > 0.f ? v : 0.f;
+        out[o] = v;
       }
     }
   }
@@ -245,17 +266,19 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
   const int p = mt * 32 + i;
   const int img_l = p / (G::R * HS), m = (p / HS) % G::R, l = p % HS;
 
+  SlotDesc<G::SH_NPF> sd;
+  init_small_slots<HS>(sd, tid);
   f32x4 pf[G::SH_NPF];
   int unit = blockIdx.x;
-  if (unit < n_units) load_small_halo<HS>(pf, small, unit, N, tid);
+  if (unit < n_units) load_small_halo<HS>(pf, sd, small, unit, N);
   stage_weights<false>(w, wl, tid);
   const float bv = bias ? bias[i] : 0.f;
 
   for (; unit < n_units; unit += gridDim.x) {
     __syncthreads();  // previous unit's reads of st are complete
-    store_small_halo<HS>(pf, st, tid);
+    store_small_halo<HS>(pf, sd, st);
     __syncthreads();
-    if (unit + (int)gridDim.x < n_units) load_small_halo<HS>(pf, small, unit + gridDim.x, N, tid);
+    if (unit + (int)gridDim.x < n_units) load_small_halo<HS>(pf, sd, small, unit + gridDim.x, N);
 
     f32x16 acc;
 #pragma unroll
@@ -313,6 +336,8 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
   const int kh = wv >> 1, kwb = wv & 1;  // taps (kh, 2*kwb) and (kh, 2*kwb+1)
   const int i = lane & 31, h = lane >> 5;
 
+  SlotDesc<G::BIG_NPF> sd;
+  init_big_slots<HS>(sd, tid);
   f32x4 pf[G::BIG_NPF];
   f32x4 pfs;
   f32x16 acc0, acc1;
@@ -328,14 +353,14 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
     if (e0 < npix * 32) v = *reinterpret_cast<const f32x4*>(small + e0);
     pfs = v;
   };
-  if (unit < n_units) { load_big<HS>(pf, big, unit, N, tid); load_sp(unit); }
+  if (unit < n_units) { load_big<HS>(pf, sd, big, unit, N); load_sp(unit); }
 
   for (; unit < n_units; unit += gridDim.x) {
     __syncthreads();
-    store_big<HS>(pf, bt, tid);
+    store_big<HS>(pf, sd, bt);
     *reinterpret_cast<f32x4*>(sp + tid * 4) = pfs;
     __syncthreads();
-    if (unit + (int)gridDim.x < n_units) { load_big<HS>(pf, big, unit + gridDim.x, N, tid); load_sp(unit + gridDim.x); }
+    if (unit + (int)gridDim.x < n_units) { load_big<HS>(pf, sd, big, unit + gridDim.x, N); load_sp(unit + gridDim.x); }
 
 #pragma unroll 8
     for (int t = 0; t < 32; ++t) {
@@ -377,24 +402,40 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
   }
 }
 
+// 256 workgroups x (64 outputs x 4 partial-groups): coalesced 256-byte rows, fixed summation order
 __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                         float* __restrict__ db, int bias_from_big, int nblk) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;  // (tap, cs, cb)
-  if (idx < 16384) {
-    float v = 0.f;
-    for (int g = 0; g < nblk; ++g) v += ws[(long)g * 16384 + idx];
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;             // (tap, cs, cb)
+  float v = 0.f;
+  for (int g = gq; g < nblk; g += 4) v += ws[(long)g * 16384 + idx];
+  red[gq][o] = v;
+  __syncthreads();
+  if (gq == 0) {
+    v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
     const int tap = idx >> 10, cs = (idx >> 5) & 31, cb = idx & 31;
     dw[(cs * 32 + cb) * 16 + tap] = v;
   }
-  if (db && blockIdx.x == 0 && threadIdx.x < 32) {
+  if (db && blockIdx.x == 0) {
+    __syncthreads();
     const float* wsb = ws + (long)WG_MAX_BLOCKS * 16384;
-    float v = 0.f;
-    for (int g = 0; g < nblk; ++g) {
+    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;   // 8 partial groups
+    float b = 0.f;
+    for (int g = part; g < nblk; g += 8) {
       const float* q = wsb + (long)g * 160;
-      if (bias_from_big) v += (q[32 + threadIdx.x] + q[64 + threadIdx.x]) + (q[96 + threadIdx.x] + q[128 + threadIdx.x]);
-      else v += q[threadIdx.x];
+      if (bias_from_big) b += (q[32 + c] + q[64 + c]) + (q[96 + c] + q[128 + c]);
+      else b += q[c];
     }
-    db[threadIdx.x] = v;
+    float* rb = &red[0][0];
+    rb[part * 32 + c] = b;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += rb[k * 32 + threadIdx.x];
+      db[threadIdx.x] = t;
+    }
   }
 }
 
@@ -408,7 +449,7 @@ static int launch_down_t(const ConvArgs& a, hipStream_t s) {
   using G = Geo<HS>;
   const int n_units = units_for(a.N, HS);
   const int grid = n_units < 256 ? n_units : 256;
-  const size_t lds = (16384 + G::BIG_FLOATS + 2 * 3 * 16 * 64) * sizeof(float);
+  const size_t lds = (16384 + G::BIG_FLOATS + 8192) * sizeof(float);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_down32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(k_down32<HS>, dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
@@ -440,7 +481,7 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units);
   DVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(64), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(256), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -18,16 +18,27 @@ namespace dvae {
 #define TB_ROW 68                 // floats per row
 #define TB_PLANE (TB_ROWS * TB_ROW + 16)
 
-// stage big rows [2*sy0-1, 2*sy0+8] of image n, channels [0,C), zero padded
-__device__ __forceinline__ void stage_big_thin(const float* __restrict__ big, float* bt, int n, int sy0, int C,
-                                               bool valid, int tid, int nthreads) {
-  const int total = C * TB_ROWS * 66;
-  for (int e = tid; e < total; e += nthreads) {
-    int pc = e % 66; int t = e / 66; int r = t % TB_ROWS; int cb = t / TB_ROWS;
-    int by = 2 * sy0 - 1 + r, bx = pc - 1;
+// stage big rows [2*sy0-1, 2*sy0+8] of image n, channels [0,C), zero padded.  256 threads:
+// 64 consecutive threads read one 256-byte image row (coalesced), 4 (channel,row) pairs in flight;
+// no integer div/mod by runtime values.
+template <int C>
+__device__ __forceinline__ void stage_big_thin(const float* __restrict__ big, float* bt, int n, int sy0, bool valid,
+                                               int tid) {
+  const int tx = tid & 63, ty = tid >> 6;
+  const int pc = tx + 1;
+  const int dst_col = (pc & 1) * TB_PAR + (pc >> 1);
+#pragma unroll
+  for (int pr = ty; pr < C * TB_ROWS; pr += 4) {
+    const int cb = pr / TB_ROWS, r = pr - cb * TB_ROWS;
+    const int by = 2 * sy0 - 1 + r;
     float v = 0.f;
-    if (valid && by >= 0 && by < 64 && bx >= 0 && bx < 64) v = big[(((long)n * C + cb) * 64 + by) * 64 + bx];
-    bt[cb * TB_PLANE + r * TB_ROW + (pc & 1) * TB_PAR + (pc >> 1)] = v;
+    if (valid && by >= 0 && by < 64) v = big[(((long)n * C + cb) * 64 + by) * 64 + tx];
+    bt[cb * TB_PLANE + r * TB_ROW + dst_col] = v;
+  }
+  if (tid < C * TB_ROWS * 2) {   // the two zero-padding columns pc = 0 and pc = 65
+    const int pr = tid >> 1, side = tid & 1;
+    const int cb = pr / TB_ROWS, r = pr - cb * TB_ROWS;
+    bt[cb * TB_PLANE + r * TB_ROW + (side ? (TB_PAR + 32) : 0)] = 0.f;
   }
 }
 
@@ -45,7 +56,7 @@ __global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big
   float wreg[8 * C];
 #pragma unroll
   for (int kk = 0; kk < 8 * C; ++kk) wreg[kk] = w[i * (16 * C) + 2 * kk + h];
-  stage_big_thin(big, bt, n, sy0, C, n < N, tid, 256);
+  stage_big_thin<C>(big, bt, n, sy0, n < N, tid);
   __syncthreads();
   f32x16 acc;
 #pragma unroll
@@ -85,13 +96,23 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
   const int tid = threadIdx.x;
   const int unit = blockIdx.x;
   const int n = unit >> 3, sy0 = (unit & 7) * 4;
-  for (int s = tid; s < UT_ROWS * UT_COLS * 8; s += 128) {
-    int chunk = s & 7; int t = s >> 3; int col = t % UT_COLS; int row = t / UT_COLS;
-    int sy = sy0 - 1 + row, sx = col - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n < N && sy >= 0 && sy < 32 && sx >= 0 && sx < 32)
-      v = *reinterpret_cast<const f32x4*>(small + ((((long)n * 32 + sy) * 32) + sx) * 32 + chunk * 4);
-    *reinterpret_cast<f32x4*>(st + (row * UT_COLS + col) * 32 + ((chunk ^ ((col >> 1) & 7)) << 2)) = v;
+  {
+    const int chunk = tid & 7, cg = tid >> 3;   // 16 columns per pass, 8 chunks of 16 bytes per pixel
+#pragma unroll
+    for (int row = 0; row < UT_ROWS; ++row) {
+      const int sy = sy0 - 1 + row;
+#pragma unroll
+      for (int cp = 0; cp < 3; ++cp) {
+        const int col = cp * 16 + cg;
+        if (col < UT_COLS) {
+          const int sx = col - 1;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (n < N && sy >= 0 && sy < 32 && sx >= 0 && sx < 32)
+            v = *reinterpret_cast<const f32x4*>(small + ((((long)n * 32 + sy) * 32) + sx) * 32 + chunk * 4);
+          *reinterpret_cast<f32x4*>(st + (row * UT_COLS + col) * 32 + ((chunk ^ ((col >> 1) & 7)) << 2)) = v;
+        }
+      }
+    }
   }
   __syncthreads();
   const int m = tid >> 5, l = tid & 31;
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const float* __restrict__ bi
   for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     const int n = unit >> 3, sy0 = (unit & 7) * 4;
     __syncthreads();
-    stage_big_thin(big, bt, n, sy0, C, n < N, tid, 256);
+    stage_big_thin<C>(big, bt, n, sy0, n < N, tid);
     {
       const float* src = small + ((((long)n * 32 + sy0) * 32)) * 32;  // 128 pixels x 32 ch contiguous
 #pragma unroll
@@ -246,32 +267,44 @@ __global__ __launch_bounds__(256) void k_wgrad_thin_reduce(const float* __restri
                                                            float* __restrict__ db, int bias_from_big, int nblk) {
   constexpr int NT = (16 * C + 31) / 32;
   constexpr int STRIDE = NT * 1024 + 32 + NT * 32;
-  // dw[cs][cb][tap] : element (cs, nidx = cb*16+tap)
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 32 * 16 * C; idx += gridDim.x * 256) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  // dw[cs][cb][tap] : element idx = cs * 16C + nidx, nidx = cb*16 + tap
+  const int idx = blockIdx.x * 64 + o;
+  float v = 0.f;
+  if (idx < 32 * 16 * C) {
     const int cs = idx / (16 * C), nidx = idx % (16 * C);
-    const int nt = nidx >> 5, j = nidx & 31;
-    float v = 0.f;
-    for (int g = 0; g < nblk; ++g) v += ws[(long)g * STRIDE + nt * 1024 + cs * 32 + j];
-    dw[idx] = v;
+    const int off = (nidx >> 5) * 1024 + cs * 32 + (nidx & 31);
+    for (int g = gq; g < nblk; g += 4) v += ws[(long)g * STRIDE + off];
   }
+  red[gq][o] = v;
+  __syncthreads();
+  if (gq == 0 && idx < 32 * 16 * C) dw[idx] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
   if (db && blockIdx.x == 0) {
+    __syncthreads();
+    // bias sums: slot [0,32) = sum of the small side per cs; slots 32.. = per (cb,tap) column sums of the big side
+    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+    float b = 0.f;
     if (!bias_from_big) {
-      if (threadIdx.x < 32) {
-        float v = 0.f;
-        for (int g = 0; g < nblk; ++g) v += ws[(long)g * STRIDE + NT * 1024 + threadIdx.x];
-        db[threadIdx.x] = v;
-      }
-    } else if (threadIdx.x < C) {
+      for (int g = part; g < nblk; g += 8) b += ws[(long)g * STRIDE + NT * 1024 + c];
+    } else if (c < C) {
       // every big pixel appears exactly once under taps (kh,kw) in {1,2}x{1,2}
-      const int cb = threadIdx.x;
-      float v = 0.f;
-      for (int g = 0; g < nblk; ++g) {
+      const int t5 = c * 16 + 5, t6 = c * 16 + 6, t9 = c * 16 + 9, t10 = c * 16 + 10;
+      for (int g = part; g < nblk; g += 8) {
         const float* q = ws + (long)g * STRIDE + NT * 1024 + 32;
-        const int t5 = cb * 16 + 5, t6 = cb * 16 + 6, t9 = cb * 16 + 9, t10 = cb * 16 + 10;
-        v += (q[(t5 >> 5) * 32 + (t5 & 31)] + q[(t6 >> 5) * 32 + (t6 & 31)]) +
+        b += (q[(t5 >> 5) * 32 + (t5 & 31)] + q[(t6 >> 5) * 32 + (t6 & 31)]) +
              (q[(t9 >> 5) * 32 + (t9 & 31)] + q[(t10 >> 5) * 32 + (t10 & 31)]);
       }
-      db[cb] = v;
+    }
+    float* rb = &red[0][0];
+    rb[part * 32 + c] = b;
+    __syncthreads();
+    const int nout = bias_from_big ? C : 32;
+    if ((int)threadIdx.x < nout) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += rb[k * 32 + threadIdx.x];
+      db[threadIdx.x] = t;
     }
   }
 }
@@ -310,11 +343,11 @@ int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db
   if (Cb == 1) {
     hipLaunchKernelGGL(k_wgrad_thin<1>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(2), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(8), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   } else {
     hipLaunchKernelGGL(k_wgrad_thin<3>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(6), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(24), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   }
   DVAE_CHECK_LAUNCH();
   return 0;

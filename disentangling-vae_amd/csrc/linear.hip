@@ -20,13 +20,20 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a, long 
                                               float* __restrict__ c, long ldc, int M, int N, int K,
                                               const float* __restrict__ bias, int act,
                                               const float* __restrict__ mask, int mask_act,
-                                              float* __restrict__ rowsum) {
+                                              float* __restrict__ rowsum, int klen) {
   __shared__ float As[GK][GLD];
   __shared__ float Bs[GK][GLD];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wi = wv >> 1, wj = wv & 1;
   const int i = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  // split-K: slice blockIdx.z covers k in [kbeg, kend) and writes a raw partial tile to c + z*M*N
+  const int kbeg = blockIdx.z * klen;
+  const int kend = (kbeg + klen < K) ? kbeg + klen : K;
+  if (gridDim.z > 1) {
+    c += (long)blockIdx.z * M * N;
+    if (rowsum) rowsum += (long)blockIdx.z * M;
+  }
 
   // per-thread staging coordinates: 2048 elements per operand tile / 256 threads = 8 each
   float pa[8], pb[8];
@@ -38,8 +45,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a, long 
       if (A_KFAST) { ak = e & (GK - 1); ai = e >> 5; } else { ai = e & (GT - 1); ak = e >> 6; }
       if (B_JFAST) { bj = e & (GT - 1); bk = e >> 6; } else { bk = e & (GK - 1); bj = e >> 5; }
       const int gi = m0 + ai, gka = k0 + ak, gkb = k0 + bk, gj = n0 + bj;
-      pa[r] = (gi < M && gka < K) ? a[gi * sAi + gka * sAk] : 0.f;
-      pb[r] = (gkb < K && gj < N) ? b[gkb * sBk + gj * sBj] : 0.f;
+      pa[r] = (gi < M && gka < kend) ? a[gi * sAi + gka * sAk] : 0.f;
+      pb[r] = (gkb < kend && gj < N) ? b[gkb * sBk + gj * sBj] : 0.f;
     }
   };
   auto store_tiles = [&]() {
@@ -60,12 +67,12 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a, long 
   float rs = 0.f;
   const bool do_rowsum = rowsum != nullptr && blockIdx.x == 0;
 
-  load_tiles(0);
-  for (int k0 = 0; k0 < K; k0 += GK) {
+  load_tiles(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
     __syncthreads();
     store_tiles();
     __syncthreads();
-    if (k0 + GK < K) load_tiles(k0 + GK);
+    if (k0 + GK < kend) load_tiles(k0 + GK);
 #pragma unroll
     for (int s = 0; s < GK / 2; ++s) {
       const float av = As[2 * s + h][wi * 32 + i];
@@ -99,12 +106,29 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a, long 
   }
 }
 
-static inline dim3 gemm_grid(int M, int N) { return dim3((N + GT - 1) / GT, (M + GT - 1) / GT); }
+static inline dim3 gemm_grid(int M, int N, int S = 1) { return dim3((N + GT - 1) / GT, (M + GT - 1) / GT, S); }
+
+// c[i] = sum_z ws[z*n + i]; db[i] = sum_z wsb[z*m + i]
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, int S, long n, float* __restrict__ c,
+                                                       const float* __restrict__ wsb, int m, float* __restrict__ db) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = 0.f;
+    for (int z = 0; z < S; ++z) v += ws[z * n + i];
+    c[i] = v;
+  }
+  if (db && blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < m; i += 256) {
+      float v = 0.f;
+      for (int z = 0; z < S; ++z) v += wsb[(long)z * m + i];
+      db[i] = v;
+    }
+  }
+}
 
 int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act,
                       hipStream_t s) {
   hipLaunchKernelGGL((k_gemm<true, false>), gemm_grid(M, N), dim3(256), 0, s, x, (long)K, 1L, w, 1L, (long)K, y,
-                     (long)N, M, N, K, b, act, (const float*)nullptr, 0, (float*)nullptr);
+                     (long)N, M, N, K, b, act, (const float*)nullptr, 0, (float*)nullptr, K);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -113,15 +137,36 @@ int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int
                         hipStream_t s) {
   // dx[M,K] = dy[M,N] w[N,K]: contraction length N
   hipLaunchKernelGGL((k_gemm<true, true>), gemm_grid(M, K), dim3(256), 0, s, dy, (long)N, 1L, w, (long)K, 1L, dx,
-                     (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, (float*)nullptr);
+                     (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, (float*)nullptr, N);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
 
-int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, hipStream_t s) {
-  // dw[N,K] = dy^T[N,M] x[M,K]: contraction length M; db[n] = sum_m dy[m][n] = row sums of A
-  hipLaunchKernelGGL((k_gemm<false, true>), gemm_grid(N, K), dim3(256), 0, s, dy, 1L, (long)N, x, (long)K, 1L, dw,
-                     (long)K, N, K, M, (const float*)nullptr, 0, (const float*)nullptr, 0, db);
+int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, float* ws,
+                        size_t ws_floats, hipStream_t s) {
+  // dw[N,K] = dy^T[N,M] x[M,K]: contraction length M (the batch); db[n] = sum_m dy[m][n] = row sums of A.
+  // Few output tiles + a long contraction: split the batch over gridDim.z and reduce (fixed order).
+  const int tiles = ((N + GT - 1) / GT) * ((K + GT - 1) / GT);
+  int S = 1;
+  if (ws) {
+    while (S < 16 && tiles * S < 256 && M / (S * 2) >= 64) S *= 2;
+    while (S > 1 && (size_t)S * ((size_t)N * K + N) > ws_floats) S /= 2;
+  }
+  if (S == 1) {
+    hipLaunchKernelGGL((k_gemm<false, true>), gemm_grid(N, K), dim3(256), 0, s, dy, 1L, (long)N, x, (long)K, 1L, dw,
+                       (long)K, N, K, M, (const float*)nullptr, 0, (const float*)nullptr, 0, db, M);
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
+  const int klen = ((M + S - 1) / S + GK - 1) / GK * GK;
+  float* wsb = ws + (size_t)S * N * K;
+  hipLaunchKernelGGL((k_gemm<false, true>), gemm_grid(N, K, S), dim3(256), 0, s, dy, 1L, (long)N, x, (long)K, 1L, ws,
+                     (long)K, N, K, M, (const float*)nullptr, 0, (const float*)nullptr, 0, db ? wsb : (float*)nullptr, klen);
+  DVAE_CHECK_LAUNCH();
+  const long n = (long)N * K;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(k_splitk_reduce, dim3(grid), dim3(256), 0, s, ws, S, n, dw, wsb, N, db);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

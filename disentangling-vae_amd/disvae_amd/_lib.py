@@ -37,7 +37,7 @@ SIGNATURES = {
     "dvae_relayout": [_p, _i, _p, _i, _i, _i, _i, _p],
     "dvae_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dvae_linear_dgrad": [_p, _p, _p, _i, _p, _i, _i, _i, _p],
-    "dvae_linear_wgrad": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "dvae_linear_wgrad": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dvae_reparam_kl_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_recon_loss": [_p, _p, _l, _i, _p, _p, _p, _i, _p],

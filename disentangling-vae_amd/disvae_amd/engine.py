@@ -221,15 +221,15 @@ class VAEEngine:
             dy, dy_layout = gx, NHWC
         call("dvae_relayout", ptr(buf.gd3n), NHWC, ptr(buf.gd3), B, HID, 4, 4, s)
         call("dvae_linear_wgrad", ptr(buf.d2), ptr(buf.gd3), ptr(self.g("decoder.lin3.weight")),
-             ptr(self.g("decoder.lin3.bias")), B, HIDDEN_DIM, HID * 16, s)
+             ptr(self.g("decoder.lin3.bias")), B, HIDDEN_DIM, HID * 16, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
              B, HIDDEN_DIM, HID * 16, s)
         call("dvae_linear_wgrad", ptr(buf.d1), ptr(buf.gd2), ptr(self.g("decoder.lin2.weight")),
-             ptr(self.g("decoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, s)
+             ptr(self.g("decoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
              B, HIDDEN_DIM, HIDDEN_DIM, s)
         call("dvae_linear_wgrad", ptr(z), ptr(buf.gd1), ptr(self.g("decoder.lin1.weight")),
-             ptr(self.g("decoder.lin1.bias")), B, D, HIDDEN_DIM, s)
+             ptr(self.g("decoder.lin1.bias")), B, D, HIDDEN_DIM, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
              B, D, HIDDEN_DIM, s)
 
@@ -240,15 +240,15 @@ class VAEEngine:
         c, H, _ = self.img_size
         ws = ptr(self._ws)
         call("dvae_linear_wgrad", ptr(buf.h2), ptr(buf.dml), ptr(self.g("encoder.mu_logvar_gen.weight")),
-             ptr(self.g("encoder.mu_logvar_gen.bias")), B, HIDDEN_DIM, 2 * self.latent_dim, s)
+             ptr(self.g("encoder.mu_logvar_gen.bias")), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
         call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
              ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, s)
         call("dvae_linear_wgrad", ptr(buf.h1), ptr(buf.gh2), ptr(self.g("encoder.lin2.weight")),
-             ptr(self.g("encoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, s)
+             ptr(self.g("encoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
              B, HIDDEN_DIM, HIDDEN_DIM, s)
         call("dvae_linear_wgrad", ptr(buf.a_flat), ptr(buf.gh1), ptr(self.g("encoder.lin1.weight")),
-             ptr(self.g("encoder.lin1.bias")), B, HID * 16, HIDDEN_DIM, s)
+             ptr(self.g("encoder.lin1.bias")), B, HID * 16, HIDDEN_DIM, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
              ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, s)
         last = len(self.enc_names) - 1

@@ -87,6 +87,12 @@ class Discriminator(nn.Module):
             self._acts[M] = b
         return b
 
+    def _ws(self):
+        if getattr(self, "_wsbuf", None) is None or self._wsbuf.device != self._arena.flat.device:
+            self._wsbuf = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), dtype=torch.float32,
+                                      device=self._arena.flat.device)
+        return self._wsbuf
+
     def forward_raw(self, z, M):
         """z[M,latent] -> logits[M,2] (discriminator.py:60-70); activations kept for backward."""
         if self._arena.flat.device.type != "cuda":
@@ -114,7 +120,7 @@ class Discriminator(nn.Module):
             x_in = z if i == 0 else b["h"][i - 1]
             if wgrad:
                 call("dvae_linear_wgrad", ptr(x_in), ptr(dy), ptr(self._arena.view(n + ".weight", grad=True)),
-                     ptr(self._arena.view(n + ".bias", grad=True)), R, self.dims[i], self.dims[i + 1], s)
+                     ptr(self._arena.view(n + ".bias", grad=True)), R, self.dims[i], self.dims[i + 1], ptr(self._ws()), s)
             gx = b[chain][i]
             call("dvae_linear_dgrad", ptr(dy), ptr(self._arena.view(n + ".weight")), None if i == 0 else ptr(x_in),
                  ACT_LEAKY02 if i > 0 else ACT_NONE, ptr(gx), R, self.dims[i], self.dims[i + 1], s)

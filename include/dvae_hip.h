@@ -89,9 +89,11 @@ int dvae_linear_fwd(const float* x, const float* w, const float* b, float* y, in
  * input of this layer, i.e. the ReLU / LeakyReLU backward of the previous layer fused in). */
 int dvae_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx,
                       int M, int K, int N, void* stream);
-/* dw[N,K] = dy^T x ; db[N] = column sums of dy (db may be NULL).                            */
+/* dw[N,K] = dy^T x ; db[N] = column sums of dy (db may be NULL).  ws (may be NULL): the
+ * dvae_conv_wgrad_ws_floats() workspace, enables the split-batch (split-K) schedule for layers
+ * with few output tiles (fixed-order reduction, deterministic).                              */
 int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N,
-                      void* stream);
+                      float* ws, void* stream);
 
 /* ---- reparameterisation + per-dim Gaussian KL: vae.py:52-71, losses.py:452-480 -----------
  * ml[B,2D] is the interleaved output of mu_logvar_gen (encoders.py:87: mu = ml[:,0::2],

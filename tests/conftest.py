@@ -15,3 +15,16 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _release_device_temporaries():
+    yield
+    try:
+        import gpu_util
+        gpu_util.clear_keep()
+    except Exception:
+        pass

@@ -15,13 +15,28 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_KEEP = []   # device tensors created by dev() stay alive until the test ends: a temporary freed
+             # right after ptr() would be re-used by the next allocation before the launch
+
+
 def dev(t):
-    return t.detach().to(DEV, torch.float32).contiguous()
+    d = t.detach().to(DEV, torch.float32).contiguous()
+    _KEEP.append(d)
+    return d
+
+
+def keep(t):
+    _KEEP.append(t)
+    return t
 
 
 def nhwc(t):
     """NCHW torch tensor -> NHWC-contiguous device buffer."""
     return dev(t.permute(0, 2, 3, 1).contiguous())
+
+
+def clear_keep():
+    del _KEEP[:]
 
 
 def from_nhwc(t, N, C, H, W):

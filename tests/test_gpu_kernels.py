@@ -121,7 +121,7 @@ def test_relayout():
 @pytest.mark.parametrize("M,K,N,act", [(7, 10, 256, _lib.ACT_RELU), (130, 512, 256, _lib.ACT_RELU),
                                         (33, 256, 20, _lib.ACT_NONE), (64, 1000, 1000, _lib.ACT_LEAKY02),
                                         (256, 10, 1000, _lib.ACT_LEAKY02), (100, 1000, 2, _lib.ACT_NONE),
-                                        (1, 256, 512, _lib.ACT_RELU)])
+                                        (1, 256, 512, _lib.ACT_RELU), (1024, 512, 256, _lib.ACT_RELU), (700, 256, 20, _lib.ACT_NONE)])
 def test_linear(M, K, N, act):
     x = _rand(M, K, seed=1)
     w = _rand(N, K, seed=2, scale=1 / math.sqrt(K))
@@ -137,9 +137,14 @@ def test_linear(M, K, N, act):
     pre.backward(dy.double())
     dyd = dev(dy)
     dw, db = torch.full((N, K), 7.0, device=DEV), torch.full((N,), 7.0, device=DEV)
-    call("dvae_linear_wgrad", ptr(xd), ptr(dyd), ptr(dw), ptr(db), M, K, N, stream())
+    call("dvae_linear_wgrad", ptr(xd), ptr(dyd), ptr(dw), ptr(db), M, K, N, None, stream())
     check(dw, wr.grad, what="linear wgrad")
     check(db, br.grad, what="linear bias grad")
+    ws = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), device=DEV)      # split-batch schedule
+    dw2, db2 = torch.full((N, K), 7.0, device=DEV), torch.full((N,), 7.0, device=DEV)
+    call("dvae_linear_wgrad", ptr(xd), ptr(dyd), ptr(dw2), ptr(db2), M, K, N, ptr(ws), stream())
+    check(dw2, wr.grad, what="linear wgrad (split)")
+    check(db2, br.grad, what="linear bias grad (split)")
     xact = _rand(M, K, seed=5)
     for mact in (_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_LEAKY02):
         dx = torch.empty(M, K, device=DEV)
@@ -263,7 +268,7 @@ def test_permute_dims_and_disc_losses():
     z = _rand(B, D, seed=1)
     perms = torch.stack([torch.randperm(B, generator=torch.Generator().manual_seed(d)) for d in range(D)])
     out = torch.empty(B, D, device=DEV)
-    call("dvae_permute_dims", ptr(dev(z)), ptr(perms.to(DEV)), ptr(out), B, D, stream())
+    call("dvae_permute_dims", ptr(dev(z)), ptr(keep(perms.to(DEV))), ptr(out), B, D, stream())
     assert torch.equal(out.cpu(), O.permute_dims(z, list(perms)))
     Bh = 50
     lg = _rand(2 * Bh, 2, seed=2, scale=3)

@@ -10,11 +10,12 @@ mkdir -p gpurun_out
 echo "== rocm-smi" ; rocm-smi --showproductname 2>/dev/null | head -8
 echo "== host: $(nproc) cpus"
 echo "== pytest -m gpu"
-timeout 1200 python -m pytest tests -m gpu -q --timeout=300 -x --no-header ${PYTEST_ARGS:-} > gpurun_out/pytest.log 2>&1
+timeout 1200 python -m pytest tests -m gpu -q --timeout=300 --no-header ${PYTEST_ARGS:-} > gpurun_out/pytest.log 2>&1
 echo "pytest exit: $?" | tee -a gpurun_out/pytest.log
-tail -n 45 gpurun_out/pytest.log
+grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/pytest.log | head -60
+echo "---- first failure detail"; grep -n -m1 -A12 "^E  " gpurun_out/pytest.log | cut -c1-300
 echo "== smoke"
-timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -n 5 | tee gpurun_out/smoke.log
+timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -n 12 | cut -c1-400 | tee gpurun_out/smoke.log
 echo "== bench"
 timeout 600 python bench.py --steps ${BENCH_STEPS:-20} --warmup 5 2>&1 | tail -n 3 | tee gpurun_out/bench.log
 if [ "${DO_PROF:-1}" = "1" ]; then
@@ -22,6 +23,5 @@ if [ "${DO_PROF:-1}" = "1" ]; then
   rm -rf gpurun_out/prof
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o prof -- python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$REPO/gpurun_out/prof.log" 2>&1)
   tail -n 3 gpurun_out/prof.log
-  f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1)
-  if [ -n "$f" ]; then head -n 40 "$f" | cut -c1-200; fi
+  python tools/prof_summary.py gpurun_out/prof/prof_results.db 13 | head -40
 fi
