@@ -119,17 +119,17 @@ int dvae_relayout(const float* src, int src_layout, float* dst, int N, int C, in
   return launch_relayout(src, src_layout, dst, N, C, H, W, (hipStream_t)stream);
 }
 
-int dvae_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act,
+int dvae_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, float* ws,
                     void* stream) {
   DVAE_CHECK_ARG(x && w && y && M > 0 && K > 0 && N > 0);
   DVAE_CHECK_ARG(act == DVAE_ACT_NONE || act == DVAE_ACT_RELU || act == DVAE_ACT_LEAKY02);
-  return launch_linear_fwd(x, w, b, y, M, K, N, act, (hipStream_t)stream);
+  return launch_linear_fwd(x, w, b, y, M, K, N, act, ws, dvae_conv_wgrad_ws_floats(), (hipStream_t)stream);
 }
 
 int dvae_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
-                      void* stream) {
+                      float* ws, void* stream) {
   DVAE_CHECK_ARG(dy && w && dx && M > 0 && K > 0 && N > 0);
-  return launch_linear_dgrad(dy, w, x_act, act, dx, M, K, N, (hipStream_t)stream);
+  return launch_linear_dgrad(dy, w, x_act, act, dx, M, K, N, ws, dvae_conv_wgrad_ws_floats(), (hipStream_t)stream);
 }
 
 int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, float* ws,

@@ -89,10 +89,10 @@ size_t wgrad32_ws_floats();
 size_t wgrad_thin_ws_floats();
 int launch_relayout(const float* src, int src_layout, float* dst, int N, int C, int H, int W, hipStream_t s);
 
-int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act,
-                      hipStream_t s);
+int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, float* ws,
+                      size_t ws_floats, hipStream_t s);
 int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
-                        hipStream_t s);
+                        float* ws, size_t ws_floats, hipStream_t s);
 int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, float* ws,
                         size_t ws_floats, hipStream_t s);
 

@@ -180,7 +180,7 @@ __device__ __forceinline__ float epilogue_act(float v, int act) {
 
 // ---- down: big -> small ------------------------------------------------------------------
 #define SEL4(v, g, j) ((g) == 0 ? (v)[j] : (g) == 1 ? (v)[4 + (j)] : (g) == 2 ? (v)[8 + (j)] : (v)[12 + (j)])
-template <int HS>
+template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, const float* __restrict__ w,
                                                 const float* __restrict__ bias, const float* __restrict__ mask,
                                                 float* __restrict__ out, int N, int act, int n_units) {
@@ -231,27 +231,85 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[(((mt * 4 + (e >> 2)) * 4 + kh) * 4 + (e & 3)) * 64 + lane] = acc[e];
     __syncthreads();
-    const long P0 = (long)unit * G::U + mt * 32;
+    // epilogue: this wave owns D-fragment rows j + 8*kh + 4*h (j = 0..3) of its M-tile.  Mask
+    // loads are issued together before any store (no load->wait->store chains).
+    const long P0 = (long)unit * G::U + mt * 32 + 8 * kh + 4 * h;
+    float vals[4], mv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float v = SEL4(acc, kh, j);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         if (s != kh) v += red[(((mt * 4 + kh) * 4 + s) * 4 + j) * 64 + lane];
-      const int row = j + 8 * kh + 4 * h;      // D-fragment row of register e = 4*kh + j
-      const long pix = P0 + row;
-      if (pix < npix) {
-        const long o = pix * 32 + i;
-        v = epilogue_act(v + bv, act);
-        if (mask) v = mask[o] > 0.f ? v : 0.f;
-        out[o] = v;
+      vals[j] = v;
+    }
+    const bool full = P0 - 4 * h - 8 * kh - mt * 32 + G::U <= npix;   // wave-uniform: whole unit inside the tensor
+    if (full) {
+      if (MASK) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mv[j] = mask[(P0 + j) * 32 + i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = epilogue_act(vals[j] + bv, act);
+        if (MASK) v = mv[j] > 0.f ? v : 0.f;
+        out[(P0 + j) * 32 + i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long pix = P0 + j;
+        if (pix < npix) {
+          float v = epilogue_act(vals[j] + bv, act);
+          if (MASK) v = mask[pix * 32 + i] > 0.f ? v : 0.f;
+          out[pix * 32 + i] = v;
+        }
       }
     }
   }
 }
 
 // ---- up: small -> big --------------------------------------------------------------------
+// output offsets of the 16 D-fragment rows of this wave's (class, M-tile) for a given unit
 template <int HS>
+__device__ __forceinline__ void up_offsets(long (&offs)[16], int unit, int mt, int py, int px, int h, int i) {
+  using G = Geo<HS>;
+  const long P0 = (long)unit * G::U;
+  const int n0 = (int)(P0 / (HS * HS));
+  const int sy0 = (int)(P0 % (HS * HS)) / HS;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int rowp = (e & 3) + 8 * (e >> 2) + 4 * h;
+    const int pp = mt * 32 + rowp;
+    const int im = pp / (G::R * HS), mm = (pp / HS) % G::R, ll = pp % HS;
+    const int by = 2 * (sy0 + mm) + py, bx = 2 * ll + px;
+    offs[e] = (((long)(n0 + im) * G::HB + by) * G::HB + bx) * 32 + i;
+  }
+}
+
+template <int HS>
+__device__ __forceinline__ void up_store(const float (&vals)[16], float* __restrict__ out, int unit, int N, int mt,
+                                         int py, int px, int h, int i) {
+  using G = Geo<HS>;
+  long offs[16];
+  up_offsets<HS>(offs, unit, mt, py, px, h, i);
+  const int n0 = (int)(((long)unit * G::U) / (HS * HS));
+  if (n0 + G::IMGS <= N) {          // wave-uniform: the whole unit lies inside the tensor
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[offs[e]] = vals[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int im = (mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) / (G::R * HS);
+      if (n0 + im < N) out[offs[e]] = vals[e];
+    }
+  }
+}
+
+// Software pipeline per workgroup:  [LDS tile(u) <- regs] | barrier | issue loads tile(u+1), mask(u) |
+// store results(u-1) | MFMA(u) | results(u) -> regs.  The global stores of unit u-1 and the loads
+// of unit u+1 are a whole MFMA phase old when the next iteration waits on vmcnt.
+template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, const float* __restrict__ w,
                                               const float* __restrict__ bias, const float* __restrict__ mask,
                                               float* __restrict__ out, int N, int act, int n_units) {
@@ -273,12 +331,26 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
   if (unit < n_units) load_small_halo<HS>(pf, sd, small, unit, N);
   stage_weights<false>(w, wl, tid);
   const float bv = bias ? bias[i] : 0.f;
+  float vals[16];
+  int prev_unit = -1;
 
   for (; unit < n_units; unit += gridDim.x) {
     __syncthreads();  // previous unit's reads of st are complete
     store_small_halo<HS>(pf, sd, st);
     __syncthreads();
     if (unit + (int)gridDim.x < n_units) load_small_halo<HS>(pf, sd, small, unit + gridDim.x, N);
+    float mv[16];
+    if (MASK) {       // prefetch the ReLU mask of this unit (consumed after the MFMA phase)
+      long offs[16];
+      up_offsets<HS>(offs, unit, mt, py, px, h, i);
+      const int n0 = (int)(((long)unit * G::U) / (HS * HS));
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int im = (mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) / (G::R * HS);
+        mv[e] = (G::IMGS == 1 || n0 + im < N) ? mask[offs[e]] : 0.f;
+      }
+    }
+    if (prev_unit >= 0) up_store<HS>(vals, out, prev_unit, N, mt, py, px, h, i);
 
     f32x16 acc;
 #pragma unroll
@@ -303,24 +375,15 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
         }
       }
     }
-    const long P0 = (long)unit * G::U;
-    const int n0 = (int)(P0 / (HS * HS));
-    const int sy0 = (int)(P0 % (HS * HS)) / HS;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int rowp = (e & 3) + 8 * (e >> 2) + 4 * h;
-      const int pp = mt * 32 + rowp;
-      const int im = pp / (G::R * HS), mm = (pp / HS) % G::R, ll = pp % HS;
-      const int n = n0 + im;
-      if (n < N) {
-        const int by = 2 * (sy0 + mm) + py, bx = 2 * ll + px;
-        const long o = (((long)n * G::HB + by) * G::HB + bx) * 32 + i;
-        float v = epilogue_act(acc[e] + bv, act);
-        if (mask) v = mask[o] > 0.f ? v : 0.f;
-        out[o] = v;
-      }
+      float v = epilogue_act(acc[e] + bv, act);
+      if (MASK) v = mv[e] > 0.f ? v : 0.f;
+      vals[e] = v;
     }
+    prev_unit = unit;
   }
+  if (prev_unit >= 0) up_store<HS>(vals, out, prev_unit, N, mt, py, px, h, i);
 }
 
 // ---- wgrad ---------------------------------------------------------------------------------
@@ -408,8 +471,17 @@ __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict_
   __shared__ float red[4][64];
   const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + o;             // (tap, cs, cb)
-  float v = 0.f;
-  for (int g = gq; g < nblk; g += 4) v += ws[(long)g * 16384 + idx];
+  // 8 independent partial sums keep 8 loads in flight per lane (the loop is latency-bound otherwise)
+  float pv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) pv[u] = 0.f;
+  int g = gq;
+  for (; g + 28 < nblk; g += 32) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pv[u] += ws[(long)(g + 4 * u) * 16384 + idx];
+  }
+  for (; g < nblk; g += 4) pv[0] += ws[(long)g * 16384 + idx];
+  float v = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
   red[gq][o] = v;
   __syncthreads();
   if (gq == 0) {
@@ -451,8 +523,13 @@ static int launch_down_t(const ConvArgs& a, hipStream_t s) {
   const int grid = n_units < 256 ? n_units : 256;
   const size_t lds = (16384 + G::BIG_FLOATS + 8192) * sizeof(float);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_down32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL(k_down32<HS>, dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_down32<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_down32<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (a.mask) hipLaunchKernelGGL((k_down32<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  else hipLaunchKernelGGL((k_down32<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -464,8 +541,13 @@ static int launch_up_t(const ConvArgs& a, hipStream_t s) {
   const int grid = n_units < 256 ? n_units : 256;
   const size_t lds = (16384 + G::SH_FLOATS) * sizeof(float);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_up32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL(k_up32<HS>, dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_up32<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_up32<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (a.mask) hipLaunchKernelGGL((k_up32<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  else hipLaunchKernelGGL((k_up32<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

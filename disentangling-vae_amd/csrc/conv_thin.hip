@@ -43,7 +43,7 @@ __device__ __forceinline__ void stage_big_thin(const float* __restrict__ big, fl
 }
 
 // ---- down_thin: big NCHW [N,C,64,64] -> small NHWC [N,32,32,32] ----------------------------
-template <int C>
+template <int C, bool MASK>
 __global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big, const float* __restrict__ w,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    float* __restrict__ out, int N, int act) {
@@ -71,15 +71,20 @@ __global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[kk], acc, 0, 0, 0);
   }
   const float bv = bias ? bias[i] : 0.f;
-  if (n < N) {
+  if (n < N) {   // block-uniform
+    const long rowbase = ((((long)n * 32 + sy0 + sy_l) * 32)) * 32 + i;
+    float mv[16];
+    if (MASK) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mv[e] = mask[rowbase + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32];
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int sx = (e & 3) + 8 * (e >> 2) + 4 * h;
-      const long o = ((((long)n * 32 + sy0 + sy_l) * 32) + sx) * 32 + i;
       float v = acc[e] + bv;
       if (act == DVAE_ACT_RELU) v = v > 0.f ? v : 0.f;
-      if (mask) v = mask[o] > 0.f ? v : 0.f;
-      out[o] = v;
+      if (MASK) v = mv[e] > 0.f ? v : 0.f;
+      out[rowbase + sx * 32] = v;
     }
   }
 }
@@ -262,24 +267,37 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const float* __restrict__ bi
   }
 }
 
+// 16 outputs x 16 partial-groups per workgroup; 8 loads in flight per lane; fixed summation order
 template <int C>
 __global__ __launch_bounds__(256) void k_wgrad_thin_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                            float* __restrict__ db, int bias_from_big, int nblk) {
   constexpr int NT = (16 * C + 31) / 32;
   constexpr int STRIDE = NT * 1024 + 32 + NT * 32;
-  __shared__ float red[4][64];
-  const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  __shared__ float red[16][16];
+  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
   // dw[cs][cb][tap] : element idx = cs * 16C + nidx, nidx = cb*16 + tap
-  const int idx = blockIdx.x * 64 + o;
-  float v = 0.f;
+  const int idx = blockIdx.x * 16 + o;
+  float pv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) pv[u] = 0.f;
   if (idx < 32 * 16 * C) {
     const int cs = idx / (16 * C), nidx = idx % (16 * C);
     const int off = (nidx >> 5) * 1024 + cs * 32 + (nidx & 31);
-    for (int g = gq; g < nblk; g += 4) v += ws[(long)g * STRIDE + off];
+    int g = gq;
+    for (; g + 112 < nblk; g += 128) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pv[u] += ws[(long)(g + 16 * u) * STRIDE + off];
+    }
+    for (; g < nblk; g += 16) pv[0] += ws[(long)g * STRIDE + off];
   }
-  red[gq][o] = v;
+  red[gq][o] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
   __syncthreads();
-  if (gq == 0 && idx < 32 * 16 * C) dw[idx] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+  if (gq == 0 && idx < 32 * 16 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][o];
+    dw[idx] = t;
+  }
   if (db && blockIdx.x == 0) {
     __syncthreads();
     // bias sums: slot [0,32) = sum of the small side per cs; slots 32.. = per (cb,tap) column sums of the big side
@@ -320,8 +338,13 @@ int launch_down_thin(const ConvArgs& a, hipStream_t s) {
   if (!thin_applicable(a) || a.big_layout != DVAE_NCHW || a.out_layout != DVAE_NHWC) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
   const int grid = a.N * 8;
-  if (a.Cb == 1) hipLaunchKernelGGL(k_down_thin<1>, dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
-  else hipLaunchKernelGGL(k_down_thin<3>, dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
+  if (a.Cb == 1) {
+    if (a.mask) hipLaunchKernelGGL((k_down_thin<1, true>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
+    else hipLaunchKernelGGL((k_down_thin<1, false>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
+  } else {
+    if (a.mask) hipLaunchKernelGGL((k_down_thin<3, true>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
+    else hipLaunchKernelGGL((k_down_thin<3, false>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
+  }
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -343,11 +366,11 @@ int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db
   if (Cb == 1) {
     hipLaunchKernelGGL(k_wgrad_thin<1>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(8), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(32), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   } else {
     hipLaunchKernelGGL(k_wgrad_thin<3>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(24), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(96), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   }
   DVAE_CHECK_LAUNCH();
   return 0;

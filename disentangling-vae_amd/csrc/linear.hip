@@ -125,19 +125,75 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
   }
 }
 
-int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act,
-                      hipStream_t s) {
-  hipLaunchKernelGGL((k_gemm<true, false>), gemm_grid(M, N), dim3(256), 0, s, x, (long)K, 1L, w, 1L, (long)K, y,
-                     (long)N, M, N, K, b, act, (const float*)nullptr, 0, (float*)nullptr, K);
+// y = act(sum_z partial_z + bias) * act'(mask): epilogue of the split-K schedule for fwd / dgrad
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict__ ws, int S, int M, int N,
+                                                         float* __restrict__ c, const float* __restrict__ bias, int act,
+                                                         const float* __restrict__ mask, int mask_act) {
+  const long n = (long)M * N;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = 0.f;
+    for (int z = 0; z < S; ++z) v += ws[z * n + i];
+    if (bias) v += bias[i % N];
+    if (act == DVAE_ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (act == DVAE_ACT_LEAKY02) v = v > 0.f ? v : 0.2f * v;
+    if (mask) {
+      const float mv = mask[i];
+      if (mask_act == DVAE_ACT_RELU) v = mv > 0.f ? v : 0.f;
+      else if (mask_act == DVAE_ACT_LEAKY02) v = mv > 0.f ? v : 0.2f * v;
+    }
+    c[i] = v;
+  }
+}
+
+// number of contraction slices: fill the chip when the output has few 64x64 tiles
+static int pick_split(int tiles, int Kc, size_t out_elems, float* ws, size_t ws_floats) {
+  int S = 1;
+  if (!ws) return 1;
+  while (S < 16 && tiles * S < 256 && Kc / (S * 2) >= 64) S *= 2;
+  while (S > 1 && (size_t)S * (out_elems + 4096) > ws_floats) S /= 2;
+  return S;
+}
+
+int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, float* ws,
+                      size_t ws_floats, hipStream_t s) {
+  const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
+  const int S = pick_split(tiles, K, (size_t)M * N, ws, ws_floats);
+  if (S == 1) {
+    hipLaunchKernelGGL((k_gemm<true, false>), gemm_grid(M, N), dim3(256), 0, s, x, (long)K, 1L, w, 1L, (long)K, y,
+                       (long)N, M, N, K, b, act, (const float*)nullptr, 0, (float*)nullptr, K);
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
+  const int klen = ((K + S - 1) / S + GK - 1) / GK * GK;
+  hipLaunchKernelGGL((k_gemm<true, false>), gemm_grid(M, N, S), dim3(256), 0, s, x, (long)K, 1L, w, 1L, (long)K, ws,
+                     (long)N, M, N, K, (const float*)nullptr, 0, (const float*)nullptr, 0, (float*)nullptr, klen);
+  DVAE_CHECK_LAUNCH();
+  long n = (long)M * N;
+  int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(k_splitk_epilogue, dim3(grid), dim3(256), 0, s, ws, S, M, N, y, b, act, (const float*)nullptr, 0);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
 
 int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
-                        hipStream_t s) {
+                        float* ws, size_t ws_floats, hipStream_t s) {
   // dx[M,K] = dy[M,N] w[N,K]: contraction length N
-  hipLaunchKernelGGL((k_gemm<true, true>), gemm_grid(M, K), dim3(256), 0, s, dy, (long)N, 1L, w, (long)K, 1L, dx,
-                     (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, (float*)nullptr, N);
+  const int tiles = ((M + GT - 1) / GT) * ((K + GT - 1) / GT);
+  const int S = pick_split(tiles, N, (size_t)M * K, ws, ws_floats);
+  if (S == 1) {
+    hipLaunchKernelGGL((k_gemm<true, true>), gemm_grid(M, K), dim3(256), 0, s, dy, (long)N, 1L, w, (long)K, 1L, dx,
+                       (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, (float*)nullptr, N);
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
+  const int klen = ((N + S - 1) / S + GK - 1) / GK * GK;
+  hipLaunchKernelGGL((k_gemm<true, true>), gemm_grid(M, K, S), dim3(256), 0, s, dy, (long)N, 1L, w, (long)K, 1L, ws,
+                     (long)K, M, K, N, (const float*)nullptr, 0, (const float*)nullptr, 0, (float*)nullptr, klen);
+  DVAE_CHECK_LAUNCH();
+  long n = (long)M * K;
+  int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(k_splitk_epilogue, dim3(grid), dim3(256), 0, s, ws, S, M, K, dx, (const float*)nullptr, 0, x_act,
+                     x_act ? act : 0);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

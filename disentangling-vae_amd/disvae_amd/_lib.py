@@ -35,8 +35,8 @@ SIGNATURES = {
     "dvae_convT4s2_wgrad": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "dvae_conv_wgrad_ws_floats": [],
     "dvae_relayout": [_p, _i, _p, _i, _i, _i, _i, _p],
-    "dvae_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "dvae_linear_dgrad": [_p, _p, _p, _i, _p, _i, _i, _i, _p],
+    "dvae_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
+    "dvae_linear_dgrad": [_p, _p, _p, _i, _p, _i, _i, _i, _p, _p],
     "dvae_linear_wgrad": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dvae_reparam_kl_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],

@@ -157,6 +157,7 @@ class VAEEngine:
     def encode(self, x, buf, n=None):
         """x[B,C,H,W] (NCHW) -> buf.ml[B,2D] (interleaved mu/logvar)."""
         s = _stream()
+        ws = ptr(self._ws)
         B = x.shape[0] if n is None else n
         c, H, _ = self.img_size
         src, src_layout, cin, h = x, NCHW, c, H
@@ -166,11 +167,11 @@ class VAEEngine:
             src, src_layout, cin, h = act, NHWC, HID, h // 2
         call("dvae_relayout", ptr(src), NHWC, ptr(buf.a_flat), B, HID, 4, 4, s)
         call("dvae_linear_fwd", ptr(buf.a_flat), ptr(self.p("encoder.lin1.weight")), ptr(self.p("encoder.lin1.bias")),
-             ptr(buf.h1), B, HID * 16, HIDDEN_DIM, ACT_RELU, s)
+             ptr(buf.h1), B, HID * 16, HIDDEN_DIM, ACT_RELU, ws, s)
         call("dvae_linear_fwd", ptr(buf.h1), ptr(self.p("encoder.lin2.weight")), ptr(self.p("encoder.lin2.bias")),
-             ptr(buf.h2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, s)
+             ptr(buf.h2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, ws, s)
         call("dvae_linear_fwd", ptr(buf.h2), ptr(self.p("encoder.mu_logvar_gen.weight")),
-             ptr(self.p("encoder.mu_logvar_gen.bias")), ptr(buf.ml), B, HIDDEN_DIM, 2 * self.latent_dim, ACT_NONE, s)
+             ptr(self.p("encoder.mu_logvar_gen.bias")), ptr(buf.ml), B, HIDDEN_DIM, 2 * self.latent_dim, ACT_NONE, ws, s)
 
     def reparam(self, buf, eps, kl_dim=None, coef=None, n=None):
         B = buf.B if n is None else n
@@ -180,14 +181,15 @@ class VAEEngine:
     def decode(self, z, buf, n=None):
         """z[B,D] -> buf.recon[B,C,H,W] (NCHW, post-sigmoid)."""
         s = _stream()
+        ws = ptr(self._ws)
         B = z.shape[0] if n is None else n
         D = self.latent_dim
         call("dvae_linear_fwd", ptr(z), ptr(self.p("decoder.lin1.weight")), ptr(self.p("decoder.lin1.bias")),
-             ptr(buf.d1), B, D, HIDDEN_DIM, ACT_RELU, s)
+             ptr(buf.d1), B, D, HIDDEN_DIM, ACT_RELU, ws, s)
         call("dvae_linear_fwd", ptr(buf.d1), ptr(self.p("decoder.lin2.weight")), ptr(self.p("decoder.lin2.bias")),
-             ptr(buf.d2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, s)
+             ptr(buf.d2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, ws, s)
         call("dvae_linear_fwd", ptr(buf.d2), ptr(self.p("decoder.lin3.weight")), ptr(self.p("decoder.lin3.bias")),
-             ptr(buf.d3), B, HIDDEN_DIM, HID * 16, ACT_RELU, s)
+             ptr(buf.d3), B, HIDDEN_DIM, HID * 16, ACT_RELU, ws, s)
         call("dvae_relayout", ptr(buf.d3), NCHW, ptr(buf.d3n), B, HID, 4, 4, s)
         src, h = buf.d3n, 4
         for name, act in zip(self.dec_names, buf.dec_act):
@@ -223,15 +225,15 @@ class VAEEngine:
         call("dvae_linear_wgrad", ptr(buf.d2), ptr(buf.gd3), ptr(self.g("decoder.lin3.weight")),
              ptr(self.g("decoder.lin3.bias")), B, HIDDEN_DIM, HID * 16, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
-             B, HIDDEN_DIM, HID * 16, s)
+             B, HIDDEN_DIM, HID * 16, ws, s)
         call("dvae_linear_wgrad", ptr(buf.d1), ptr(buf.gd2), ptr(self.g("decoder.lin2.weight")),
              ptr(self.g("decoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
-             B, HIDDEN_DIM, HIDDEN_DIM, s)
+             B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
         call("dvae_linear_wgrad", ptr(z), ptr(buf.gd1), ptr(self.g("decoder.lin1.weight")),
              ptr(self.g("decoder.lin1.bias")), B, D, HIDDEN_DIM, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
-             B, D, HIDDEN_DIM, s)
+             B, D, HIDDEN_DIM, ws, s)
 
     def encode_backward(self, x, buf, n=None):
         """buf.dml (grad w.r.t. the interleaved mu/logvar output) -> encoder weight grads."""
@@ -242,15 +244,15 @@ class VAEEngine:
         call("dvae_linear_wgrad", ptr(buf.h2), ptr(buf.dml), ptr(self.g("encoder.mu_logvar_gen.weight")),
              ptr(self.g("encoder.mu_logvar_gen.bias")), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
         call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
-             ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, s)
+             ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
         call("dvae_linear_wgrad", ptr(buf.h1), ptr(buf.gh2), ptr(self.g("encoder.lin2.weight")),
              ptr(self.g("encoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
-             B, HIDDEN_DIM, HIDDEN_DIM, s)
+             B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
         call("dvae_linear_wgrad", ptr(buf.a_flat), ptr(buf.gh1), ptr(self.g("encoder.lin1.weight")),
              ptr(self.g("encoder.lin1.bias")), B, HID * 16, HIDDEN_DIM, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
-             ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, s)
+             ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, ws, s)
         last = len(self.enc_names) - 1
         call("dvae_relayout", ptr(buf.ga_flat), NCHW, ptr(buf.enc_gact[last]), B, HID, 4, 4, s)
         for k in range(last, -1, -1):

@@ -76,7 +76,7 @@ class Discriminator(nn.Module):
             layer.bias.grad = self._arena.view(n + ".bias", grad=True)
 
     # ---- raw (non-autograd) engine used by FactorKLoss ------------------------------------
-    def _buffers(self, M):
+    def _act_buffers(self, M):
         b = self._acts.get(M)
         if b is None:
             dev = self._arena.flat.device
@@ -98,12 +98,12 @@ class Discriminator(nn.Module):
         if self._arena.flat.device.type != "cuda":
             raise _lib.DvaeHipError("the native Discriminator computes only on an MI355X (no CPU fallback)")
         s = torch.cuda.current_stream().cuda_stream
-        b = self._buffers(M)
+        b = self._act_buffers(M)
         x = z
         for i, n in enumerate(self._layer_names):
             act = ACT_LEAKY02 if i < 5 else ACT_NONE
             call("dvae_linear_fwd", ptr(x), ptr(self._arena.view(n + ".weight")), ptr(self._arena.view(n + ".bias")),
-                 ptr(b["h"][i]), M, self.dims[i], self.dims[i + 1], act, s)
+                 ptr(b["h"][i]), M, self.dims[i], self.dims[i + 1], act, ptr(self._ws()), s)
             x = b["h"][i]
         return x
 
@@ -112,7 +112,7 @@ class Discriminator(nn.Module):
         rows < M restricts to the first `rows` samples (dgrad-only chain of quirk Q1).
         Returns the gradient w.r.t. z ([rows, latent])."""
         s = torch.cuda.current_stream().cuda_stream
-        b = self._buffers(M)
+        b = self._act_buffers(M)
         R = M if rows is None else rows
         dy = g_logits
         for i in range(5, -1, -1):
@@ -123,7 +123,7 @@ class Discriminator(nn.Module):
                      ptr(self._arena.view(n + ".bias", grad=True)), R, self.dims[i], self.dims[i + 1], ptr(self._ws()), s)
             gx = b[chain][i]
             call("dvae_linear_dgrad", ptr(dy), ptr(self._arena.view(n + ".weight")), None if i == 0 else ptr(x_in),
-                 ACT_LEAKY02 if i > 0 else ACT_NONE, ptr(gx), R, self.dims[i], self.dims[i + 1], s)
+                 ACT_LEAKY02 if i > 0 else ACT_NONE, ptr(gx), R, self.dims[i], self.dims[i + 1], ptr(self._ws()), s)
             dy = gx
         return dy
 

@@ -82,13 +82,15 @@ size_t dvae_conv_wgrad_ws_floats(void);
 int dvae_relayout(const float* src, int src_layout, float* dst, int N, int C, int H, int W, void* stream);
 
 /* ---- nn.Linear: encoders.py:63-67,81-86; decoders.py:53-55,71-73; discriminator.py:51-68 --
- * y[M,N] = act(x[M,K] w[N,K]^T + b[N]);  act in {none, relu, leaky 0.2}.                    */
+ * y[M,N] = act(x[M,K] w[N,K]^T + b[N]);  act in {none, relu, leaky 0.2}.
+ * ws (all three, may be NULL): the dvae_conv_wgrad_ws_floats() workspace; enables the
+ * split-contraction schedule for layers with few output tiles (fixed-order, deterministic). */
 int dvae_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N,
-                    int act, void* stream);
+                    int act, float* ws, void* stream);
 /* dx[M,K] = dy[M,N] w[N,K], times act'(x_act) when x_act != NULL (x_act = the post-activation
  * input of this layer, i.e. the ReLU / LeakyReLU backward of the previous layer fused in). */
 int dvae_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx,
-                      int M, int K, int N, void* stream);
+                      int M, int K, int N, float* ws, void* stream);
 /* dw[N,K] = dy^T x ; db[N] = column sums of dy (db may be NULL).  ws (may be NULL): the
  * dvae_conv_wgrad_ws_floats() workspace, enables the split-batch (split-K) schedule for layers
  * with few output tiles (fixed-order reduction, deterministic).                              */
