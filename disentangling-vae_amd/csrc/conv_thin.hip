@@ -18,65 +18,99 @@ namespace dvae {
 #define TB_ROW 68                 // floats per row
 #define TB_PLANE (TB_ROWS * TB_ROW + 16)
 
-// stage big rows [2*sy0-1, 2*sy0+8] of image n, channels [0,C), zero padded.  256 threads:
-// 64 consecutive threads read one 256-byte image row (coalesced), 4 (channel,row) pairs in flight;
-// no integer div/mod by runtime values.
+// Big rows [2*sy0-1, 2*sy0+8] of image n, channels [0,C), zero padded.  256 threads: 64 consecutive
+// threads read one 256-byte image row (coalesced), 4 (channel,row) pairs per pass.  Loads are
+// UNCONDITIONAL (address clamped, value zeroed afterwards) so that the compiler issues them
+// back to back instead of one branch + wait per element; load and LDS-store are separate so the
+// next unit can be prefetched into registers during the MFMA phase.
 template <int C>
-__device__ __forceinline__ void stage_big_thin(const float* __restrict__ big, float* bt, int n, int sy0, bool valid,
-                                               int tid) {
+struct BigThinRegs { float v[(C * TB_ROWS + 3) / 4]; };
+
+template <int C>
+__device__ __forceinline__ void load_big_thin(BigThinRegs<C>& r, const float* __restrict__ big, int n, int sy0,
+                                              bool valid, int tid) {
+  const int tx = tid & 63, ty = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < (C * TB_ROWS + 3) / 4; ++k) {
+    const int pr = ty + 4 * k;
+    const int cb = pr / TB_ROWS, rr = pr - cb * TB_ROWS;
+    const int by = 2 * sy0 - 1 + rr;
+    const bool ok = valid && pr < C * TB_ROWS && by >= 0 && by < 64;
+    const long off = ok ? ((((long)n * C + cb) * 64 + by) * 64 + tx) : 0;
+    const float v = big[off];
+    r.v[k] = ok ? v : 0.f;
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void store_big_thin(const BigThinRegs<C>& r, float* bt, int tid) {
   const int tx = tid & 63, ty = tid >> 6;
   const int pc = tx + 1;
   const int dst_col = (pc & 1) * TB_PAR + (pc >> 1);
 #pragma unroll
-  for (int pr = ty; pr < C * TB_ROWS; pr += 4) {
-    const int cb = pr / TB_ROWS, r = pr - cb * TB_ROWS;
-    const int by = 2 * sy0 - 1 + r;
-    float v = 0.f;
-    if (valid && by >= 0 && by < 64) v = big[(((long)n * C + cb) * 64 + by) * 64 + tx];
-    bt[cb * TB_PLANE + r * TB_ROW + dst_col] = v;
+  for (int k = 0; k < (C * TB_ROWS + 3) / 4; ++k) {
+    const int pr = ty + 4 * k;
+    if (pr < C * TB_ROWS) {
+      const int cb = pr / TB_ROWS, rr = pr - cb * TB_ROWS;
+      bt[cb * TB_PLANE + rr * TB_ROW + dst_col] = r.v[k];
+    }
   }
   if (tid < C * TB_ROWS * 2) {   // the two zero-padding columns pc = 0 and pc = 65
     const int pr = tid >> 1, side = tid & 1;
-    const int cb = pr / TB_ROWS, r = pr - cb * TB_ROWS;
-    bt[cb * TB_PLANE + r * TB_ROW + (side ? (TB_PAR + 32) : 0)] = 0.f;
+    const int cb = pr / TB_ROWS, rr = pr - cb * TB_ROWS;
+    bt[cb * TB_PLANE + rr * TB_ROW + (side ? (TB_PAR + 32) : 0)] = 0.f;
   }
 }
 
 // ---- down_thin: big NCHW [N,C,64,64] -> small NHWC [N,32,32,32] ----------------------------
+// persistent workgroups (4 waves = 4 small rows of 32 pixels per unit); weights go through LDS
+// once per workgroup (coalesced read, transposed [k][cs] image) into 8*C VGPRs per lane; the
+// next unit's big tile is prefetched into registers during the MFMA phase.
 template <int C, bool MASK>
 __global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big, const float* __restrict__ w,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
-                                                   float* __restrict__ out, int N, int act) {
+                                                   float* __restrict__ out, int N, int act, int n_units) {
   __shared__ float bt[C * TB_PLANE];
+  __shared__ float wT[16 * C * 32];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int unit = blockIdx.x;          // (n, quad of 4 small rows)
-  const int n = unit >> 3, sy0 = (unit & 7) * 4;
-  // B operand: w[cs = i][k], k = cb*16 + kh*4 + kw = 2*kk + h
-  float wreg[8 * C];
-#pragma unroll
-  for (int kk = 0; kk < 8 * C; ++kk) wreg[kk] = w[i * (16 * C) + 2 * kk + h];
-  stage_big_thin<C>(big, bt, n, sy0, n < N, tid);
-  __syncthreads();
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const int sy_l = wv;  // this wave's small row inside the unit; lane i = sx
-#pragma unroll
-  for (int kk = 0; kk < 8 * C; ++kk) {
-    // k = 2kk + h : kw = (2kk+h)&3 -> {2*(kk&1) + h}, kh = (kk>>1)&3, cb = kk>>3
-    const int kwb = (kk & 1);              // kw = 2*kwb + h  -> par = h, cw = sx + kwb
-    const int kh = (kk >> 1) & 3, cb = kk >> 3;
-    const float a = bt[cb * TB_PLANE + (2 * sy_l + kh) * TB_ROW + h * TB_PAR + i + kwb];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[kk], acc, 0, 0, 0);
+  for (int e = tid; e < 32 * 16 * C; e += 256) {       // w[cs][k] -> wT[k][cs]
+    const int cs = e / (16 * C), k = e - cs * (16 * C);
+    wT[k * 32 + cs] = w[e];
   }
+  BigThinRegs<C> pf;
+  int unit = blockIdx.x;
+  if (unit < n_units) load_big_thin<C>(pf, big, unit >> 3, (unit & 7) * 4, true, tid);
+  __syncthreads();
+  float wreg[8 * C];                                     // B operand: w[cs = i][k = 2*kk + h]
+#pragma unroll
+  for (int kk = 0; kk < 8 * C; ++kk) wreg[kk] = wT[(2 * kk + h) * 32 + i];
   const float bv = bias ? bias[i] : 0.f;
-  if (n < N) {   // block-uniform
+  const int sy_l = wv;  // this wave's small row inside the unit; lane i = sx
+
+  for (; unit < n_units; unit += gridDim.x) {
+    const int n = unit >> 3, sy0 = (unit & 7) * 4;
+    __syncthreads();                                     // previous unit's LDS reads are complete
+    store_big_thin<C>(pf, bt, tid);
+    __syncthreads();
+    const int nu = unit + gridDim.x;
+    if (nu < n_units) load_big_thin<C>(pf, big, nu >> 3, (nu & 7) * 4, true, tid);
     const long rowbase = ((((long)n * 32 + sy0 + sy_l) * 32)) * 32 + i;
     float mv[16];
     if (MASK) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mv[e] = mask[rowbase + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8 * C; ++kk) {
+      // k = 2kk + h : kw = 2*(kk&1) + h -> par = h, cw = sx + (kk&1); kh = (kk>>1)&3; cb = kk>>3
+      const int kwb = (kk & 1);
+      const int kh = (kk >> 1) & 3, cb = kk >> 3;
+      const float a = bt[cb * TB_PLANE + (2 * sy_l + kh) * TB_ROW + h * TB_PAR + i + kwb];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wreg[kk], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -102,22 +136,32 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
   const int unit = blockIdx.x;
   const int n = unit >> 3, sy0 = (unit & 7) * 4;
   {
-    const int chunk = tid & 7, cg = tid >> 3;   // 16 columns per pass, 8 chunks of 16 bytes per pixel
+    // 16 columns per pass, 8 chunks of 16 bytes per pixel; all loads first (unconditional, clamped
+    // address), then the swizzled LDS stores
+    const int chunk = tid & 7, cg = tid >> 3;
+    f32x4 tv[UT_ROWS * 3];
 #pragma unroll
     for (int row = 0; row < UT_ROWS; ++row) {
       const int sy = sy0 - 1 + row;
 #pragma unroll
       for (int cp = 0; cp < 3; ++cp) {
         const int col = cp * 16 + cg;
-        if (col < UT_COLS) {
-          const int sx = col - 1;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (n < N && sy >= 0 && sy < 32 && sx >= 0 && sx < 32)
-            v = *reinterpret_cast<const f32x4*>(small + ((((long)n * 32 + sy) * 32) + sx) * 32 + chunk * 4);
-          *reinterpret_cast<f32x4*>(st + (row * UT_COLS + col) * 32 + ((chunk ^ ((col >> 1) & 7)) << 2)) = v;
-        }
+        const int sx = col - 1;
+        const bool ok = n < N && col < UT_COLS && sy >= 0 && sy < 32 && sx >= 0 && sx < 32;
+        const long off = ok ? (((((long)n * 32 + sy) * 32) + sx) * 32 + chunk * 4) : 0;
+        f32x4 v = *reinterpret_cast<const f32x4*>(small + off);
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        tv[row * 3 + cp] = v;
       }
     }
+#pragma unroll
+    for (int row = 0; row < UT_ROWS; ++row)
+#pragma unroll
+      for (int cp = 0; cp < 3; ++cp) {
+        const int col = cp * 16 + cg;
+        if (col < UT_COLS)
+          *reinterpret_cast<f32x4*>(st + (row * UT_COLS + col) * 32 + ((chunk ^ ((col >> 1) & 7)) << 2)) = tv[row * 3 + cp];
+      }
   }
   __syncthreads();
   const int m = tid >> 5, l = tid & 31;
@@ -201,20 +245,24 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const float* __restrict__ bi
     const int cb = bval[t] ? (nidx >> 4) : 0, kh = (nidx >> 2) & 3, kw = nidx & 3;
     boff[t] = cb * TB_PLANE + kh * TB_ROW + (kw & 1) * TB_PAR + (kw >> 1);
   }
-  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-    const int n = unit >> 3, sy0 = (unit & 7) * 4;
-    __syncthreads();
-    stage_big_thin<C>(big, bt, n, sy0, n < N, tid);
-    {
-      const float* src = small + ((((long)n * 32 + sy0) * 32)) * 32;  // 128 pixels x 32 ch contiguous
+  BigThinRegs<C> pfb;
+  f32x4 pfs[4];
+  auto load_unit = [&](int u) {
+    const int n = u >> 3, sy0 = (u & 7) * 4;
+    load_big_thin<C>(pfb, big, n, sy0, true, tid);
+    const float* src = small + ((((long)n * 32 + sy0) * 32)) * 32;  // 128 pixels x 32 ch contiguous
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < N) v = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
-        *reinterpret_cast<f32x4*>(sp + (tid + k * 256) * 4) = v;
-      }
-    }
+    for (int k = 0; k < 4; ++k) pfs[k] = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
+  };
+  int unit = blockIdx.x;
+  if (unit < n_units) load_unit(unit);
+  for (; unit < n_units; unit += gridDim.x) {
     __syncthreads();
+    store_big_thin<C>(pfb, bt, tid);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(sp + (tid + k * 256) * 4) = pfs[k];
+    __syncthreads();
+    if (unit + (int)gridDim.x < n_units) load_unit(unit + gridDim.x);
     // wave wv handles small row sy_l = wv (32 pixels = 16 k-steps)
 #pragma unroll 4
     for (int t = 0; t < 16; ++t) {
@@ -337,13 +385,14 @@ static bool thin_applicable(const ConvArgs& a) {
 int launch_down_thin(const ConvArgs& a, hipStream_t s) {
   if (!thin_applicable(a) || a.big_layout != DVAE_NCHW || a.out_layout != DVAE_NHWC) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
-  const int grid = a.N * 8;
+  const int n_units = a.N * 8;
+  const int grid = n_units < 1536 ? n_units : 1536;     // 6 resident workgroups per CU
   if (a.Cb == 1) {
-    if (a.mask) hipLaunchKernelGGL((k_down_thin<1, true>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
-    else hipLaunchKernelGGL((k_down_thin<1, false>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
+    if (a.mask) hipLaunchKernelGGL((k_down_thin<1, true>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+    else hipLaunchKernelGGL((k_down_thin<1, false>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
   } else {
-    if (a.mask) hipLaunchKernelGGL((k_down_thin<3, true>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
-    else hipLaunchKernelGGL((k_down_thin<3, false>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act);
+    if (a.mask) hipLaunchKernelGGL((k_down_thin<3, true>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+    else hipLaunchKernelGGL((k_down_thin<3, false>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
   }
   DVAE_CHECK_LAUNCH();
   return 0;

@@ -11,7 +11,7 @@ def load(name):
 
 
 def tensor_digest(t, n_samples=24):
-    f = t.detach().double().cpu().flatten()
+    f = t.detach().cpu().double().flatten()
     idx = torch.linspace(0, f.numel() - 1, min(n_samples, f.numel())).long()
     return np.concatenate([[f.sum().item(), f.abs().sum().item()], f[idx].numpy()])
 

@@ -81,6 +81,15 @@ def test_fused_step_vs_oracle(loss, img, B, rec_dist):
         pre = O.clone_params(orc.params, requires_grad=True)
         st = O.LossState(rec_dist=rec_dist, steps_anneal=HP["reg_anneal"]); st.n_train_steps = orc.state.n_train_steps
         ref_loss, ref_logs, ref_grads, ref_outs = O.train_iteration_grads(loss, hp, st, pre, data, eps)
+        if step == 0:
+            # gradient reference = the fp64 oracle: the fp32 torch-CPU arithmetic itself differs from fp64
+            # by up to ~10x the gradient tolerance (ReLU units flipping at rounding level, see
+            # tools/debug_step.py), the HIP engine agrees with fp64 to ~1e-6 relative
+            pre64 = O.clone_params(orc.params, dtype=torch.float64, requires_grad=True)
+            st64 = O.LossState(rec_dist=rec_dist, steps_anneal=HP["reg_anneal"]); st64.n_train_steps = orc.state.n_train_steps
+            _, _, grads64, _ = O.train_iteration_grads(loss, hp, st64, pre64, data.double(), eps.double())
+            for k, p in model.named_parameters():
+                pass
         orc.train_iteration(data, eps=eps)
         storer = defaultdict(list)
         out = loss_f.fused_step(dev(data), model, opt, storer, eps=dev(eps))
@@ -93,6 +102,9 @@ def test_fused_step_vs_oracle(loss, img, B, rec_dist):
             check(buf.z, ref_outs["z"], what="z")
             check(buf.recon, ref_outs["recon"], what="recon")
         _compare_grads(model, ref_grads, "%s step %d" % (loss, step), first)
+        if first:
+            for k, p in model.named_parameters():   # tight check against fp64
+                check(p.grad, grads64[k], rtol=1e-3, atol_rel=1e-4, what="%s grad vs fp64 %s" % (loss, k))
         if step == 0:
             assert list(storer.keys()) == list(ref_logs.keys()), (list(storer.keys()), list(ref_logs.keys()))
             for k in ref_logs:
@@ -164,8 +176,10 @@ def test_trainer_vs_reference_golden(name, loss, img, B, steps):
     g = load(name)
     rec_dist = name.split("_")[-1] if name.endswith(("gaussian", "laplace")) else "bernoulli"
     model, opt, loss_f = _native(loss, img, int(g["seed"]), int(g["n_data"]), float(g["lr"]), rec_dist)
-    for k, v in model.state_dict().items():
-        np.testing.assert_array_equal(tensor_digest(v), g["init_digest/" + k], err_msg=k)
+    for k, v in model.state_dict().items():   # same seed -> identical weights (sums: thread-count dependent order)
+        d = tensor_digest(v)
+        np.testing.assert_array_equal(d[2:], g["init_digest/" + k][2:], err_msg=k)
+        np.testing.assert_allclose(d[:2], g["init_digest/" + k][:2], rtol=1e-12, err_msg=k)
     gen = torch.Generator().manual_seed(int(g["seed"]) + 1)
     for s in range(steps):
         data = torch.rand((B,) + tuple(img), generator=gen)
@@ -194,7 +208,9 @@ def test_factor_vs_reference_golden(name, img):
     g = load(name)
     model, opt, loss_f = _native("factor", img, int(g["seed"]), int(g["n_data"]), float(g["lr"]))
     for k, v in loss_f.discriminator.state_dict().items():
-        np.testing.assert_array_equal(tensor_digest(v), g["dinit_digest/" + k], err_msg=k)
+        d = tensor_digest(v)
+        np.testing.assert_array_equal(d[2:], g["dinit_digest/" + k][2:], err_msg=k)
+        np.testing.assert_allclose(d[:2], g["dinit_digest/" + k][:2], rtol=1e-12, err_msg=k)
     gen = torch.Generator().manual_seed(int(g["seed"]) + 1)
     for s in range(2):
         data = torch.rand((8,) + tuple(img), generator=gen)
