@@ -15,6 +15,7 @@
 // The big-side tile is stored in LDS split by column parity ([row][par][col/2][32ch]) with the
 // 16-byte channel chunks XOR-swizzled, so that the stride-2 im2col reads of a lane group fall
 // on distinct banks.
+#include <stdlib.h>
 #include "common.h"
 
 namespace dvae {
@@ -269,6 +270,97 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
   }
 }
 
+// ---- down, version 2 (HS = 16, 8): no K-split ---------------------------------------------
+// 8 waves = 4 M-tiles of 16 pixels x 2 halves of the 32 output channels on v_mfma_f32_16x16x4_f32
+// (two independent accumulator chains: the instruction's 40-cycle dependent latency exceeds its
+// 32-cycle issue interval).  Every wave runs the full K = 512, so there is no cross-wave
+// reduction and no reduction buffer; the LDS that frees up double-buffers the activation tile:
+// one barrier per unit, and a wave that finishes its MFMAs writes the NEXT tile while the other
+// waves are still computing.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int HS, bool MASK>
+__global__ __launch_bounds__(512) void k_down32v2(const float* __restrict__ big, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, const float* __restrict__ mask,
+                                                  float* __restrict__ out, int N, int act, int n_units) {
+  using G = Geo<HS>;
+  static_assert(G::IMGS == 1, "v2 assumes one image per unit");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                          // 16384 floats
+  float* bt0 = smem + 16384;                 // G::BIG_FLOATS
+  float* bt1 = bt0 + G::BIG_FLOATS;          // G::BIG_FLOATS
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int mt = wv >> 1, nh = wv & 1;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int p = mt * 16 + i16;
+  const int sy_l = (p / HS) % G::R, sx = p % HS;
+  const int co = nh * 16 + i16;
+
+  SlotDesc<G::BIG_NPF> sd;
+  init_big_slots<HS>(sd, tid);
+  f32x4 pf[G::BIG_NPF];
+  int unit = blockIdx.x;
+  const int stride = gridDim.x;
+  if (unit < n_units) load_big<HS>(pf, sd, big, unit, N);
+  stage_weights<true>(w, wl, tid);
+  const float bv = bias ? bias[co] : 0.f;
+  if (unit < n_units) store_big<HS>(pf, sd, bt0);
+  __syncthreads();
+  if (unit + stride < n_units) load_big<HS>(pf, sd, big, unit + stride, N);
+  int buf = 0;
+
+  for (; unit < n_units; unit += stride) {
+    const float* bt = buf ? bt1 : bt0;
+    // this wave's 4 output rows (pixels) x 16 channels: D row = 4*kq + reg, col = i16
+    const long obase = ((long)unit * G::U + mt * 16 + 4 * kq) * 32 + co;
+    float mv[4];
+    if (MASK) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mv[r] = mask[obase + r * 32];
+    }
+    f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+      const int r = 2 * sy_l + kh;
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) {
+        const int par = kw & 1, cw = sx + (kw >> 1);
+        const float* arow = bt + ((r * 2 + par) * G::CW + cw) * 32;
+        const int sw = swz_big<HS>(r, cw);
+        const float* brow = wl + ((kh * 4 + kw) * 8) * 128 + co * 4;
+        {
+          const int chunk = kq;
+          f32x4 a = *reinterpret_cast<const f32x4*>(arow + ((chunk ^ sw) << 2));
+          f32x4 b = *reinterpret_cast<const f32x4*>(brow + chunk * 128);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc0, 0, 0, 0);
+        }
+        {
+          const int chunk = 4 + kq;
+          f32x4 a = *reinterpret_cast<const f32x4*>(arow + ((chunk ^ sw) << 2));
+          f32x4 b = *reinterpret_cast<const f32x4*>(brow + chunk * 128);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+        }
+      }
+    }
+    // hand over to the next unit: its tile (prefetched during the MFMAs) goes to the other buffer
+    if (unit + stride < n_units) store_big<HS>(pf, sd, buf ? bt0 : bt1);
+    __syncthreads();
+    if (unit + 2 * stride < n_units) load_big<HS>(pf, sd, big, unit + 2 * stride, N);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = epilogue_act(acc0[r] + acc1[r] + bv, act);
+      if (MASK) v = mv[r] > 0.f ? v : 0.f;
+      out[obase + r * 32] = v;
+    }
+    buf ^= 1;
+  }
+}
+
 // ---- up: small -> big --------------------------------------------------------------------
 // output offsets of the 16 D-fragment rows of this wave's (class, M-tile) for a given unit
 template <int HS>
@@ -517,6 +609,24 @@ size_t wgrad32_ws_floats() { return (size_t)WG_MAX_BLOCKS * 16384 + (size_t)WG_M
 static int units_for(int N, int HS) { return (int)(((long)N * HS * HS + 63) / 64); }
 
 template <int HS>
+static int launch_down_v2(const ConvArgs& a, hipStream_t s) {
+  using G = Geo<HS>;
+  const int n_units = units_for(a.N, HS);     // HS*HS is a multiple of 64: every unit is complete
+  const int grid = n_units < 256 ? n_units : 256;
+  const size_t lds = (16384 + 2 * G::BIG_FLOATS) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_down32v2<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_down32v2<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (a.mask) hipLaunchKernelGGL((k_down32v2<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  else hipLaunchKernelGGL((k_down32v2<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int HS>
 static int launch_down_t(const ConvArgs& a, hipStream_t s) {
   using G = Geo<HS>;
   const int n_units = units_for(a.N, HS);
@@ -576,9 +686,10 @@ static bool mfma32_applicable(int Cb, int Cs, int Hs, int Ws, int l0, int l1, in
 int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
   if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.big_layout, a.out_layout, DVAE_NHWC)) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
+  static const bool v1 = getenv("DVAE_DOWN_V1") != nullptr;   // A/B switch: K-split 32x32x2 kernel
   switch (a.Hs) {
-    case 16: return launch_down_t<16>(a, s);
-    case 8: return launch_down_t<8>(a, s);
+    case 16: return v1 ? launch_down_t<16>(a, s) : launch_down_v2<16>(a, s);
+    case 8: return v1 ? launch_down_t<8>(a, s) : launch_down_v2<8>(a, s);
     default: return launch_down_t<4>(a, s);
   }
 }
