@@ -105,10 +105,10 @@ int launch_recon_loss(const float* recon, const float* target, long n, int dist,
                       float* g, int wrt_logit, hipStream_t s);
 int launch_sigmoid_bwd(const float* gy, const float* y, float* out, long n, hipStream_t s);
 int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, int D, int row0, int Bl, int is_mss,
-                      const float* log_w, float* rowstats, hipStream_t s);
+                      const float* log_w, float* tmp, float* rowstats, hipStream_t s);
 int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const float* rowstats, int Bg, int D, int row0,
-                      int Bl, int is_mss, const float* log_w, const float* coef, float* dz, float* dmu, float* dlv,
-                      hipStream_t s);
+                      int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz, float* dmu,
+                      float* dlv, hipStream_t s);
 int launch_permute_dims(const float* z, const int64_t* perm, float* out, int B, int D, hipStream_t s);
 int launch_disc_losses(const float* lg, int Bh, const float* coef, float* sums, float* g_dtc, float* g_tc,
                        hipStream_t s);

@@ -557,27 +557,27 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
   }
 }
 
-// 256 workgroups x (64 outputs x 4 partial-groups): coalesced 256-byte rows, fixed summation order
+// 1024 workgroups x (16 outputs x 16 partial-groups), 8 loads in flight per lane, fixed order
 __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                         float* __restrict__ db, int bias_from_big, int nblk) {
-  __shared__ float red[4][64];
-  const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;             // (tap, cs, cb)
-  // 8 independent partial sums keep 8 loads in flight per lane (the loop is latency-bound otherwise)
+  __shared__ float red[16][16];
+  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + o;             // (tap, cs, cb)
   float pv[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) pv[u] = 0.f;
   int g = gq;
-  for (; g + 28 < nblk; g += 32) {
+  for (; g + 112 < nblk; g += 128) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) pv[u] += ws[(long)(g + 4 * u) * 16384 + idx];
+    for (int u = 0; u < 8; ++u) pv[u] += ws[(long)(g + 16 * u) * 16384 + idx];
   }
-  for (; g < nblk; g += 4) pv[0] += ws[(long)g * 16384 + idx];
-  float v = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
-  red[gq][o] = v;
+  for (; g < nblk; g += 16) pv[0] += ws[(long)g * 16384 + idx];
+  red[gq][o] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
   __syncthreads();
   if (gq == 0) {
-    v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][o];
     const int tap = idx >> 10, cs = (idx >> 5) & 31, cb = idx & 31;
     dw[(cs * 32 + cb) * 16 + tap] = v;
   }
@@ -586,8 +586,8 @@ __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict_
     const float* wsb = ws + (long)WG_MAX_BLOCKS * 16384;
     const int c = threadIdx.x & 31, part = threadIdx.x >> 5;   // 8 partial groups
     float b = 0.f;
-    for (int g = part; g < nblk; g += 8) {
-      const float* q = wsb + (long)g * 160;
+    for (int g2 = part; g2 < nblk; g2 += 8) {
+      const float* q = wsb + (long)g2 * 160;
       if (bias_from_big) b += (q[32 + c] + q[64 + c]) + (q[96 + c] + q[128 + c]);
       else b += q[c];
     }
@@ -673,7 +673,7 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units);
   DVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(256), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(1024), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

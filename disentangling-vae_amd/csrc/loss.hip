@@ -130,27 +130,43 @@ __device__ __forceinline__ float log_w_ij(int i, int j, int Bg, float lN, float 
   return lM;
 }
 
-// online logsumexp state merge
+// online logsumexp (branch-free push: the wave never diverges; __expf = v_exp_f32(x*log2e))
 __device__ __forceinline__ void lse_push(float& m, float& s, float v) {
-  if (v > m) { s = s * expf(m - v) + 1.f; m = v; }
-  else s += expf(v - m);
+  const float mn = fmaxf(m, v);
+  s = s * __expf(m - mn) + __expf(v - mn);
+  m = mn;
 }
 __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
-  if (m2 > m) { s = s * expf(m - m2) + s2; m = m2; }
-  else if (m2 > -INFINITY) { s += s2 * expf(m2 - m); }
+  if (m2 > m) { s = s * __expf(m - m2) + s2; m = m2; }
+  else if (m2 > -INFINITY) { s += s2 * __expf(m2 - m); }
 }
 
-#define TC_MAXD 16
+// per-column constants of the Gaussian log-density, TRANSPOSED ([D][Bg]) so that the lanes of a wave
+// (consecutive columns j) read 256 contiguous bytes:  muT = mu, cT = -0.5 (log 2pi + logvar),
+// ivT = exp(-logvar)   (math.py:48-50)
+__global__ void k_btcvae_prep(const float* __restrict__ mu, const float* __restrict__ lv, int Bg, int D,
+                              float* __restrict__ tmp) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)Bg * D) return;
+  const int j = idx / D, d = idx % D;
+  const float l = lv[idx];
+  tmp[(long)d * Bg + j] = mu[idx];
+  tmp[(long)(D + d) * Bg + j] = -0.5f * (LOG2PI + l);
+  tmp[(long)(2 * D + d) * Bg + j] = expf(-l);
+}
+
 // one wave per row i; 4 rows per workgroup; columns j strided over lanes
 template <int D>
 __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z, const float* __restrict__ mu,
-                                                    const float* __restrict__ lv, int Bg, int row0, int Bl, int is_mss,
+                                                    const float* __restrict__ lv, const float* __restrict__ tmp,
+                                                    int Bg, int row0, int Bl, int is_mss,
                                                     const float* __restrict__ log_w, float* __restrict__ rowstats) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int il = blockIdx.x * 4 + wv;
   if (il >= Bl) return;
   const int i = row0 + il;
   const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
+  const float* muT = tmp; const float* cT = tmp + (long)D * Bg; const float* ivT = tmp + (long)2 * D * Bg;
   float zi[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) zi[d] = z[(long)i * D + d];
@@ -162,9 +178,8 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
     float S = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const float m = mu[(long)j * D + d], l = lv[(long)j * D + d];
-      const float diff = zi[d] - m;
-      const float ld = (-0.5f * (LOG2PI + l) - 0.5f * (diff * diff * expf(-l))) + lw;
+      const float diff = zi[d] - muT[(long)d * Bg + j];
+      const float ld = (cT[(long)d * Bg + j] - 0.5f * (diff * diff * ivT[(long)d * Bg + j])) + lw;
       S += ld;
       lse_push(md[d], sd[d], ld);
     }
@@ -204,7 +219,8 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
 // row pass: dz[i] (one wave per local row i)
 template <int D>
 __global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict__ z, const float* __restrict__ mu,
-                                                         const float* __restrict__ lv, const float* __restrict__ rowstats,
+                                                         const float* __restrict__ lv, const float* __restrict__ tmp,
+                                                         const float* __restrict__ rowstats,
                                                          int Bg, int row0, int Bl, int is_mss,
                                                          const float* __restrict__ log_w, const float* __restrict__ coef,
                                                          float* __restrict__ dz) {
@@ -216,6 +232,7 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict
   const float alpha = coef[DVAE_C_ALPHA], beta = coef[DVAE_C_BETA], gam = coef[DVAE_C_GAMMA] * coef[DVAE_C_ANNEAL];
   const float invB = 1.f / (float)Bg;
   const float cP = (beta - alpha) * invB, cQ = (gam - beta) * invB;
+  const float* muT = tmp; const float* cT = tmp + (long)D * Bg; const float* ivT = tmp + (long)2 * D * Bg;
   const float* rs = rowstats + (long)il * 16;
   const float lqz = rs[1];
   float zi[D], lse[D], g[D];
@@ -227,17 +244,16 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict
     float S = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const float m = mu[(long)j * D + d], l = lv[(long)j * D + d];
-      const float iv = expf(-l);
-      const float diff = zi[d] - m;
+      const float iv = ivT[(long)d * Bg + j];
+      const float diff = zi[d] - muT[(long)d * Bg + j];
       r[d] = diff * iv;
-      ld[d] = (-0.5f * (LOG2PI + l) - 0.5f * (diff * diff * iv)) + lw;
+      ld[d] = (cT[(long)d * Bg + j] - 0.5f * (diff * diff * iv)) + lw;
       S += ld[d];
     }
-    const float P = expf(S - lqz);
+    const float P = __expf(S - lqz);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const float G = cP * P + cQ * expf(ld[d] - lse[d]);
+      const float G = cP * P + cQ * __expf(ld[d] - lse[d]);
       g[d] -= G * r[d];
     }
   }
@@ -286,10 +302,10 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_cols(const float* __restrict
       ld[d] = (-0.5f * (LOG2PI + lj[d]) - 0.5f * (diff[d] * diff[d] * ivj[d])) + lw;
       S += ld[d];
     }
-    const float P = expf(S - rs[1]);
+    const float P = __expf(S - rs[1]);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const float G = cP * P + cQ * expf(ld[d] - rs[4 + d]);
+      const float G = cP * P + cQ * __expf(ld[d] - rs[4 + d]);
       gm[d] += G * r[d];
       gl[d] += G * (-0.5f + 0.5f * r[d] * diff[d]);
     }
@@ -463,19 +479,22 @@ int launch_recon_loss(const float* recon, const float* target, long n, int dist,
 }
 
 int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, int D, int row0, int Bl, int is_mss,
-                      const float* log_w, float* rowstats, hipStream_t s) {
-  dim3 grid((Bl + 3) / 4), block(256);
-  if (D == 10) hipLaunchKernelGGL(k_btcvae_fwd<10>, grid, block, 0, s, z, mu, lv, Bg, row0, Bl, is_mss, log_w, rowstats);
-  else return 1;
+                      const float* log_w, float* tmp, float* rowstats, hipStream_t s) {
+  if (D != 10) return 1;
+  const long n = (long)Bg * D;
+  hipLaunchKernelGGL(k_btcvae_prep, dim3((n + 255) / 256), dim3(256), 0, s, mu, lv, Bg, D, tmp);
+  DVAE_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_btcvae_fwd<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, Bg, row0, Bl, is_mss, log_w,
+                     rowstats);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
 
 int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const float* rowstats, int Bg, int D, int row0,
-                      int Bl, int is_mss, const float* log_w, const float* coef, float* dz, float* dmu, float* dlv,
-                      hipStream_t s) {
+                      int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz, float* dmu,
+                      float* dlv, hipStream_t s) {
   if (D != 10) return 1;
-  hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
+  hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
                      is_mss, log_w, coef, dz);
   DVAE_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_btcvae_bwd_cols<10>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,

@@ -42,8 +42,8 @@ SIGNATURES = {
     "dvae_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_recon_loss": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
     "dvae_sigmoid_bwd": [_p, _p, _p, _l, _p],
-    "dvae_btcvae_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
-    "dvae_btcvae_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "dvae_btcvae_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "dvae_btcvae_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "dvae_permute_dims": [_p, _p, _p, _i, _i, _p],
     "dvae_disc_losses": [_p, _i, _p, _p, _p, _p, _p],
     "dvae_loss_pack": [_p, _p, _i, _p, _i, _p, _p, _p],

@@ -205,16 +205,17 @@ class _BtcvaeFn(torch.autograd.Function):
         B, D = z.shape
         scratch.set_log_w(B, n_data)
         rowstats = torch.empty(B, 16, dtype=torch.float32, device=z.device)
+        tmp = torch.empty(3 * D, B, dtype=torch.float32, device=z.device)
         call("dvae_btcvae_fwd", ptr(z), ptr(mu), ptr(logvar), B, D, 0, B, int(is_mss), ptr(scratch.log_w),
-             ptr(rowstats), _stream())
+             ptr(tmp), ptr(rowstats), _stream())
         s = rowstats[:, :4].sum(0) / B   # log_pz, log_qz, log_prod_qzi, log_q_zCx
-        ctx.save_for_backward(z, mu, logvar, rowstats)
+        ctx.save_for_backward(z, mu, logvar, rowstats, tmp)
         ctx.is_mss, ctx.scratch = is_mss, scratch
         return torch.stack((s[3] - s[1], s[1] - s[2], s[2] - s[0]))
 
     @staticmethod
     def backward(ctx, gout):
-        z, mu, logvar, rowstats = ctx.saved_tensors
+        z, mu, logvar, rowstats, tmp = ctx.saved_tensors
         B, D = z.shape
         # d(a*mi + b*tc + c*dw)/d(.) with (alpha, beta, gamma*anneal) = (a, b, c)
         a, b, c = [float(v) for v in gout.tolist()]
@@ -223,7 +224,7 @@ class _BtcvaeFn(torch.autograd.Function):
         coef = coef.to(z.device)
         dz, dmu, dlv = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
         call("dvae_btcvae_bwd", ptr(z), ptr(mu), ptr(logvar), ptr(rowstats), B, D, 0, B, int(ctx.is_mss),
-             ptr(ctx.scratch.log_w), ptr(coef), ptr(dz), ptr(dmu), ptr(dlv), _stream())
+             ptr(ctx.scratch.log_w), ptr(coef), ptr(tmp), ptr(dz), ptr(dmu), ptr(dlv), _stream())
         return dz, dmu, dlv, None, None, None
 
 
@@ -307,8 +308,9 @@ class _SingleOptimizerLoss(BaseLoss):
                 zg, mug, lvg = self.comm.all_gather_latents(buf.z, buf.mu, buf.logvar)
             sc.set_log_w(Bg, self.n_data)
             rowstats = sc.latent("rowstats", B, 16)
+            tc_tmp = sc.latent("tc_tmp", 3 * D, Bg)
             call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Bg, D, rank * B, B, int(self.is_mss), ptr(sc.log_w),
-                 ptr(rowstats), s)
+                 ptr(tc_tmp), ptr(rowstats), s)
         call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
         if world > 1:
             self.comm.all_reduce(sc.packed)
@@ -319,7 +321,7 @@ class _SingleOptimizerLoss(BaseLoss):
                 dz_x = sc.latent("dz_tc", B, D)
                 dmu_all, dlv_all = sc.latent("dmu_all", Bg, D), sc.latent("dlv_all", Bg, D)
                 call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Bg, D, rank * B, B,
-                     int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), s)
+                     int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(tc_tmp), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), s)
                 if world > 1:
                     dmu_x, dlv_x = self.comm.reduce_scatter_cols(dmu_all, dlv_all)
                 else:

@@ -124,15 +124,18 @@ int dvae_sigmoid_bwd(const float* grad_y, const float* y, float* out, long n, vo
  * z,mu,logvar: [Bg,D] (the whole -- global -- batch); this call evaluates rows
  * [row0,row0+Bl).  log_w = {log(1/N), log(strat), log(1/M)} in fp32 as the reference
  * computes them (math.py:66-73), ignored when is_mss == 0.
- * rowstats[Bl,16]: log_pz, log_qz, log_prod_qzi, log_q_zCx, lse_d[0..D-1].                  */
+ * rowstats[Bl,16]: log_pz, log_qz, log_prod_qzi, log_q_zCx, lse_d[0..D-1].
+ * tmp[3*Bg*D]: scratch filled by fwd with the transposed per-column constants (mu, -0.5(log
+ * 2pi + logvar), exp(-logvar)) and re-read by bwd: pass the same buffer to both.             */
 int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg, int D, int row0,
-                    int Bl, int is_mss, const float* log_w, float* rowstats, void* stream);
+                    int Bl, int is_mss, const float* log_w, float* tmp, float* rowstats, void* stream);
 /* gradient of alpha*mi + beta*tc + anneal*gamma*dw_kl (means over Bg rows) restricted to
  * rows [row0,row0+Bl): dz[Bl,D] (local rows), dmu_all/dlv_all[Bg,D] (column sums over the
  * local rows; reduce over ranks when the batch is sharded).                                 */
 int dvae_btcvae_bwd(const float* z, const float* mu, const float* logvar, const float* rowstats,
                     int Bg, int D, int row0, int Bl, int is_mss, const float* log_w,
-                    const float* coef, float* dz, float* dmu_all, float* dlv_all, void* stream);
+                    const float* coef, const float* tmp, float* dz, float* dmu_all, float* dlv_all,
+                    void* stream);
 
 /* ---- FactorVAE pieces: losses.py:261-265,293-295,483-508 ----------------------------------*/
 /* out[b,d] = z[perm[d*B+b], d]; perm int64 [D,B] (torch.randperm per latent dim).          */

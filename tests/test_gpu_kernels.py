@@ -229,8 +229,9 @@ def test_btcvae_fwd_bwd(B, n_data, mss):
     from disvae_amd.utils.math import log_importance_weights
     lw = torch.zeros(4); lw[:3] = log_importance_weights(B, n_data)
     rs = torch.empty(B, 16, device=DEV)
+    tmp = torch.empty(3 * D, B, device=DEV)
     zd, mud, lvd, lwd = dev(z), dev(mu), dev(lv), dev(lw)
-    call("dvae_btcvae_fwd", ptr(zd), ptr(mud), ptr(lvd), B, D, 0, B, int(mss), ptr(lwd), ptr(rs), stream())
+    call("dvae_btcvae_fwd", ptr(zd), ptr(mud), ptr(lvd), B, D, 0, B, int(mss), ptr(lwd), ptr(tmp), ptr(rs), stream())
     ref = O.btcvae_log_densities(z.double(), mu.double(), lv.double(), n_data, mss)
     for k, nm in enumerate(["log_pz", "log_qz", "log_prod_qzi", "log_q_zCx"]):
         check(rs[:, k], ref[k], rtol=2e-6, atol_rel=2e-6, what=nm)
@@ -240,14 +241,14 @@ def test_btcvae_fwd_bwd(B, n_data, mss):
     # row-sharded evaluation gives the same rows (data-parallel path)
     half = B // 2
     rs2 = torch.empty(B - half, 16, device=DEV)
-    call("dvae_btcvae_fwd", ptr(zd), ptr(mud), ptr(lvd), B, D, half, B - half, int(mss), ptr(lwd), ptr(rs2), stream())
+    call("dvae_btcvae_fwd", ptr(zd), ptr(mud), ptr(lvd), B, D, half, B - half, int(mss), ptr(lwd), ptr(tmp), ptr(rs2), stream())
     assert torch.equal(rs2.cpu()[:, :14], rs[half:].cpu()[:, :14])
     # backward of alpha*mi + beta*tc + anneal*gamma*dw
     alpha, beta, gamma, anneal = 1.0, 6.4, 1.5, 0.37
     coef = torch.zeros(_lib.NCOEF)
     coef[_lib.C_ALPHA], coef[_lib.C_BETA], coef[_lib.C_GAMMA], coef[_lib.C_ANNEAL] = alpha, beta, gamma, anneal
     dz, dmu, dlv = (torch.empty(B, D, device=DEV) for _ in range(3))
-    call("dvae_btcvae_bwd", ptr(zd), ptr(mud), ptr(lvd), ptr(rs), B, D, 0, B, int(mss), ptr(lwd), ptr(dev(coef)),
+    call("dvae_btcvae_bwd", ptr(zd), ptr(mud), ptr(lvd), ptr(rs), B, D, 0, B, int(mss), ptr(lwd), ptr(dev(coef)), ptr(tmp),
          ptr(dz), ptr(dmu), ptr(dlv), stream())
     zr, mr, lr = (t.double().requires_grad_(True) for t in (z, mu, lv))
     mi, tc, dw = O.btcvae_terms(zr, mr, lr, n_data, mss)
@@ -258,9 +259,9 @@ def test_btcvae_fwd_bwd(B, n_data, mss):
     # sharded backward: column sums add up, row grads are the local rows
     dza, dma, dla = (torch.empty(half, D, device=DEV), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV))
     dzb, dmb, dlb = (torch.empty(B - half, D, device=DEV), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV))
-    call("dvae_btcvae_bwd", ptr(zd), ptr(mud), ptr(lvd), ptr(rs), B, D, 0, half, int(mss), ptr(lwd), ptr(dev(coef)),
+    call("dvae_btcvae_bwd", ptr(zd), ptr(mud), ptr(lvd), ptr(rs), B, D, 0, half, int(mss), ptr(lwd), ptr(dev(coef)), ptr(tmp),
          ptr(dza), ptr(dma), ptr(dla), stream())
-    call("dvae_btcvae_bwd", ptr(zd), ptr(mud), ptr(lvd), ptr(rs2), B, D, half, B - half, int(mss), ptr(lwd), ptr(dev(coef)),
+    call("dvae_btcvae_bwd", ptr(zd), ptr(mud), ptr(lvd), ptr(rs2), B, D, half, B - half, int(mss), ptr(lwd), ptr(dev(coef)), ptr(tmp),
          ptr(dzb), ptr(dmb), ptr(dlb), stream())
     check(torch.cat((dza, dzb)), zr.grad, rtol=2e-4, atol_rel=1e-5, what="sharded dz")
     check(dma + dmb, mr.grad, rtol=2e-4, atol_rel=1e-5, what="sharded dmu")

@@ -17,6 +17,7 @@ echo "---- first failure detail"; grep -n -m1 -A12 "^E  " gpurun_out/pytest.log 
 echo "== smoke"
 timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -n 12 | cut -c1-400 | tee gpurun_out/smoke.log
 if [ "${DO_DEBUG:-0}" = "1" ]; then echo "== debug_step"; timeout 300 python tools/debug_step.py 8 2>&1 | tail -n 80 | tee gpurun_out/debug_step.log; fi
+if [ "${DO_KBENCH:-0}" = "1" ]; then echo "== kbench"; timeout 300 python tools/kbench.py 1024 2>&1 | grep -v amdgpu.ids | tee gpurun_out/kbench.log; echo "== kbench (DVAE_DOWN_V1)"; DVAE_DOWN_V1=1 timeout 300 python tools/kbench.py 1024 2>&1 | grep -E "conv fwd|convT dgrad" | tee gpurun_out/kbench_v1.log; fi
 echo "== bench"
 timeout 600 python bench.py --steps ${BENCH_STEPS:-20} --warmup 5 2>&1 | tail -n 3 | tee gpurun_out/bench.log
 if [ "${DO_PROF:-1}" = "1" ]; then

@@ -1,0 +1,79 @@
+"""Per-kernel micro-benchmark through the C-ABI (HIP events on torch's current stream).
+usage: python tools/kbench.py [B]   -> one line per kernel: us per launch, TFLOP/s (algorithmic), GB/s (algorithmic)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "disentangling-vae_amd")):
+    sys.path.insert(0, p)
+import torch
+from disvae_amd import _lib
+from disvae_amd._lib import call, ptr, NCHW, NHWC
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+dev = "cuda"
+s = torch.cuda.current_stream().cuda_stream
+ws = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), device=dev)
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def report(name, us, flops, bytes_):
+    print("%-34s %8.1f us  %7.1f TFLOP/s  %7.0f GB/s" % (name, us, flops / us / 1e6, bytes_ / us / 1e3))
+
+
+for H in (32, 16, 8):        # big side H x H x 32 <-> small side H/2
+    hs = H // 2
+    big = torch.rand(B, H, H, 32, device=dev)
+    small = torch.rand(B, hs, hs, 32, device=dev)
+    w = torch.rand(32, 32, 4, 4, device=dev) - 0.5
+    b = torch.zeros(32, device=dev)
+    dw, db = torch.empty(32, 32, 4, 4, device=dev), torch.empty(32, device=dev)
+    macs = B * hs * hs * 32 * 512
+    nb, ns = big.numel() * 4, small.numel() * 4
+    report("conv fwd   %dx%d->%dx%d" % (H, H, hs, hs), timeit(lambda: call("dvae_conv4s2_fwd", ptr(big), NHWC, ptr(w), ptr(b), ptr(small), NHWC, B, 32, H, H, 32, 1, s)), 2 * macs, nb + ns)
+    report("convT dgrad (down+mask)", timeit(lambda: call("dvae_convT4s2_dgrad", ptr(big), NHWC, ptr(w), ptr(small), ptr(small), NHWC, B, 32, hs, hs, 32, s)), 2 * macs, nb + 2 * ns)
+    report("convT fwd  %dx%d->%dx%d" % (hs, hs, H, H), timeit(lambda: call("dvae_convT4s2_fwd", ptr(small), NHWC, ptr(w), ptr(b), ptr(big), NHWC, B, 32, hs, hs, 32, 1, s)), 2 * macs, nb + ns)
+    report("conv dgrad (up+mask)", timeit(lambda: call("dvae_conv4s2_dgrad", ptr(small), NHWC, ptr(w), ptr(big), ptr(big), NHWC, B, 32, H, H, 32, s)), 2 * macs, 2 * nb + ns)
+    report("conv wgrad (+reduce)", timeit(lambda: call("dvae_conv4s2_wgrad", ptr(big), NHWC, ptr(small), NHWC, ptr(dw), ptr(db), B, 32, H, H, 32, ptr(ws), s)), 2 * macs, nb + ns)
+for C in (3,):
+    x = torch.rand(B, C, 64, 64, device=dev)
+    a1 = torch.rand(B, 32, 32, 32, device=dev)
+    w = torch.rand(32, C, 4, 4, device=dev) - 0.5
+    b = torch.zeros(32, device=dev)
+    bc = torch.zeros(C, device=dev)
+    dw, db = torch.empty(32, C, 4, 4, device=dev), torch.empty(32, device=dev)
+    macs = B * 1024 * 32 * 16 * C
+    nx, na = x.numel() * 4, a1.numel() * 4
+    report("conv1 fwd (down_thin)", timeit(lambda: call("dvae_conv4s2_fwd", ptr(x), NCHW, ptr(w), ptr(b), ptr(a1), NHWC, B, C, 64, 64, 32, 1, s)), 2 * macs, nx + na)
+    report("convT3 dgrad (down_thin+mask)", timeit(lambda: call("dvae_convT4s2_dgrad", ptr(x), NCHW, ptr(w), ptr(a1), ptr(a1), NHWC, B, 32, 32, 32, C, s)), 2 * macs, nx + 2 * na)
+    report("convT3 fwd (up_thin+sigmoid)", timeit(lambda: call("dvae_convT4s2_fwd", ptr(a1), NHWC, ptr(w), ptr(bc), ptr(x), NCHW, B, 32, 32, 32, C, 3, s)), 2 * macs, nx + na)
+    report("conv1 wgrad (wgrad_thin+reduce)", timeit(lambda: call("dvae_conv4s2_wgrad", ptr(x), NCHW, ptr(a1), NHWC, ptr(dw), ptr(db), B, C, 64, 64, 32, ptr(ws), s)), 2 * macs, nx + na)
+    g = torch.empty_like(x)
+    coef = torch.full((8,), 1.0 / B, device=dev)
+    parts = torch.empty(512, device=dev)
+    report("recon_loss (bernoulli)", timeit(lambda: call("dvae_recon_loss", ptr(x), ptr(x), x.numel(), 0, ptr(coef), ptr(parts), ptr(g), 1, s)), 0, 3 * nx)
+for (M, K, N) in ((B, 512, 256), (B, 256, 256), (B, 256, 20), (B, 10, 256), (B, 256, 512), (B, 1000, 1000)):
+    x = torch.rand(M, K, device=dev); w = torch.rand(N, K, device=dev); b = torch.zeros(N, device=dev)
+    y = torch.empty(M, N, device=dev); dx = torch.empty(M, K, device=dev); dwt = torch.empty(N, K, device=dev)
+    fl = 2.0 * M * K * N
+    report("linear fwd   %dx%dx%d" % (M, K, N), timeit(lambda: call("dvae_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, N, 1, ptr(ws), s)), fl, 4 * (M * K + N * K + M * N))
+    report("linear dgrad", timeit(lambda: call("dvae_linear_dgrad", ptr(y), ptr(w), ptr(x), 1, ptr(dx), M, K, N, ptr(ws), s)), fl, 4 * (M * K + N * K + M * N))
+    report("linear wgrad", timeit(lambda: call("dvae_linear_wgrad", ptr(x), ptr(y), ptr(dwt), ptr(b), M, K, N, ptr(ws), s)), fl, 4 * (M * K + N * K + M * N))
+D = 10
+z = torch.randn(B, D, device=dev); mu = torch.randn(B, D, device=dev); lv = torch.randn(B, D, device=dev) * 0.5
+lw = torch.tensor([-12.0, -7.0, -6.9, 0.0], device=dev); rs = torch.empty(B, 16, device=dev); tmp = torch.empty(3 * D, B, device=dev)
+coef = torch.tensor([1.0 / B, 0.5, 6.4, 1.0, 1.0, 0, 0, 0], device=dev)
+dz, dm, dl = (torch.empty(B, D, device=dev) for _ in range(3))
+report("btcvae fwd B=%d" % B, timeit(lambda: call("dvae_btcvae_fwd", ptr(z), ptr(mu), ptr(lv), B, D, 0, B, 1, ptr(lw), ptr(tmp), ptr(rs), s)), 30.0 * B * B * D, 0)
+report("btcvae bwd (rows+cols)", timeit(lambda: call("dvae_btcvae_bwd", ptr(z), ptr(mu), ptr(lv), ptr(rs), B, D, 0, B, 1, ptr(lw), ptr(coef), ptr(tmp), ptr(dz), ptr(dm), ptr(dl), s)), 60.0 * B * B * D, 0)
