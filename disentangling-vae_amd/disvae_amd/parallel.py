@@ -27,23 +27,32 @@ class Comm:
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # gloo (CPU test backend) cannot all_gather device tensors: stage those through the host
+        self._host_gather = dist.get_backend(group) == "gloo"
 
     def all_reduce(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def all_gather_rows(self, t):
-        """t[B, D] on every rank -> [world*B, D] in rank order."""
+    def _all_gather(self, t):
         t = t.contiguous()
+        if self._host_gather and t.is_cuda:
+            h = t.cpu()
+            out = [torch.empty_like(h) for _ in range(self.world_size)]
+            dist.all_gather(out, h, group=self.group)
+            return [o.to(t.device) for o in out]
         out = [torch.empty_like(t) for _ in range(self.world_size)]
         dist.all_gather(out, t, group=self.group)
-        return torch.cat(out, dim=0)
+        return out
+
+    def all_gather_rows(self, t):
+        """t[B, D] on every rank -> [world*B, D] in rank order."""
+        return torch.cat(self._all_gather(t), dim=0)
 
     def all_gather_latents(self, z, mu, logvar):
         """(z, mu, logvar) local [B, D] -> global [world*B, D] each (one collective)."""
         packed = torch.stack((z, mu, logvar)).contiguous()           # [3, B, D]
-        out = [torch.empty_like(packed) for _ in range(self.world_size)]
-        dist.all_gather(out, packed, group=self.group)
+        out = self._all_gather(packed)
         g = torch.stack(out, dim=1)                                   # [3, world, B, D]
         g = g.reshape(3, -1, z.shape[1]).contiguous()
         return g[0], g[1], g[2]

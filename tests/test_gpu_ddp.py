@@ -1,0 +1,116 @@
+"""-m gpu: the PRODUCT data-parallel path (fused_step / call_optimize with a communicator) with
+world_size = 2.  Both ranks share the single GPU of the test box, so the transport is gloo (RCCL
+refuses two ranks on one device); the sharding logic, kernels and collectives' call sites are the
+ones used with nccl on 2/4/8 GPUs.  Reference = the same engine run single-process on the global
+batch: sharded gradients / losses / updated weights must agree to fp32 rounding."""
+import os
+import socket
+from collections import defaultdict
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HP = dict(rec_dist="bernoulli", reg_anneal=10000, betaH_B=4, betaB_initC=0, betaB_finC=25, betaB_G=1000,
+          factor_G=6.4, latent_dim=10, lr_disc=1e-4, btcvae_A=1, btcvae_B=6.4, btcvae_G=1)
+IMG = (3, 64, 64)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(loss, lr):
+    from disvae_amd.models.vae import init_specific_model
+    from disvae_amd.models.losses import get_loss_f
+    torch.manual_seed(1234)
+    model = init_specific_model("Burgess", IMG, 10)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    loss_f = get_loss_f(loss, n_data=202599, device=torch.device("cuda"), **HP)
+    model.to("cuda").train()
+    return model, opt, loss_f
+
+
+def _worker(rank, world, port, loss, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for p in (root, os.path.join(root, "disentangling-vae_amd"), os.path.join(root, "tests")):
+            sys.path.insert(0, p)
+        from disvae_amd import parallel
+        parallel.init_process_group_from_env("gloo")
+        torch.cuda.set_device(0)
+        lr = 1e-4 if loss == "factor" else 5e-4
+        Bl = 12
+        gen = torch.Generator().manual_seed(5)
+        data_g = torch.rand((world * Bl,) + IMG, generator=gen)
+        D = 10
+        # ---- single-process reference on the global batch (every rank computes it; deterministic) ----
+        m0, o0, l0 = _make(loss, lr)
+        if loss == "factor":
+            half = world * Bl // 2
+            eps1, eps2 = torch.randn(half, D, generator=gen), torch.randn(half, D, generator=gen)
+            perms = torch.stack([torch.randperm(half, generator=gen) for _ in range(D)])
+            # global tensor = [data1 of all ranks ; data2 of all ranks]: rank r owns rows r*h..(r+1)*h of each half
+            out0 = l0.call_optimize(data_g.cuda(), m0, o0, defaultdict(list), noise=(eps1.cuda(), eps2.cuda(), perms))
+        else:
+            eps = torch.randn(world * Bl, D, generator=gen)
+            out0 = l0.fused_step(data_g.cuda(), m0, o0, defaultdict(list), eps=eps.cuda())
+        ref_loss = out0.item()
+        ref_grad = m0.arena.grad.clone()
+        ref_param = m0.arena.flat.clone()
+        # ---- sharded run ----
+        m1, o1, l1 = _make(loss, lr)
+        comm = parallel.data_parallel(m1, l1)
+        assert comm.world_size == world
+        st = defaultdict(list)
+        if loss == "factor":
+            hl = Bl // 2
+            sl = slice(rank * hl, (rank + 1) * hl)
+            local = torch.cat((data_g[:half][sl], data_g[half:][sl]))
+            out1 = l1.call_optimize(local.cuda(), m1, o1, st, noise=(eps1[sl].cuda(), eps2[sl].cuda(), perms))
+            dref = l0.discriminator.arena
+            d1 = l1.discriminator.arena
+            derr = ((d1.grad - dref.grad).abs().max() / dref.grad.abs().max()).item()
+            assert derr < 2e-5, "disc grad err %.3e" % derr
+            assert (d1.flat - dref.flat).abs().max().item() <= 2.5 * HP["lr_disc"]
+        else:
+            sl = slice(rank * Bl, (rank + 1) * Bl)
+            out1 = l1.fused_step(data_g[sl].cuda(), m1, o1, st, eps=eps[sl].cuda())
+        err = ((m1.arena.grad - ref_grad).abs().max() / ref_grad.abs().max()).item()
+        assert err < 2e-5, "grad err %.3e" % err
+        assert abs(out1.item() - ref_loss) <= 2e-6 * abs(ref_loss), (out1.item(), ref_loss)
+        assert (m1.arena.flat - ref_param).abs().max().item() <= 2.5 * lr
+        assert st["loss"] and abs(st["loss"][0] - ref_loss) <= 2e-6 * abs(ref_loss)
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        try:
+            torch.distributed.destroy_process_group()
+        except Exception:
+            pass
+
+
+@pytest.mark.parametrize("loss", ["btcvae", "VAE", "factor"])
+def test_sharded_step_matches_global_batch(loss):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, loss, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=280) for _ in range(world)]
+    for p_ in procs:
+        p_.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)

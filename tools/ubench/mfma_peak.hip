@@ -1,0 +1,57 @@
+// Sustained fp32 MFMA issue-rate micro-benchmark (calibrates the roofline denominator on the box).
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_peak.hip -o tools/ubench/mfma_peak && ./mfma_peak
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NACC>
+__global__ __launch_bounds__(512) void k32(float* out, int iters, float a, float b) {
+  f32x16 acc[NACC];
+  for (int k = 0; k < NACC; ++k) for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[k], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int k = 0; k < NACC; ++k) for (int e = 0; e < 16; ++e) s += acc[k][e];
+  if (s == 12345.f) out[threadIdx.x] = s;
+}
+template <int NACC>
+__global__ __launch_bounds__(512) void k16(float* out, int iters, float a, float b) {
+  f32x4 acc[NACC];
+  for (int k = 0; k < NACC; ++k) for (int e = 0; e < 4; ++e) acc[k][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int k = 0; k < NACC; ++k) for (int e = 0; e < 4; ++e) s += acc[k][e];
+  if (s == 12345.f) out[threadIdx.x] = s;
+}
+
+template <typename F> static double run(F launch, double flops) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  launch(); hipDeviceSynchronize();
+  hipEventRecord(e0); for (int r = 0; r < 5; ++r) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return flops * 5 / (ms * 1e-3) / 1e12;
+}
+
+int main() {
+  float* out; hipMalloc(&out, 4096);
+  const int iters = 2000;
+  for (int threads : {256, 512}) {
+    const int waves = threads / 64;
+    const double n32 = 256.0 * waves * iters * 8;
+    printf("32x32x2 f32, %d waves/CU, 1 acc : %.1f TFLOP/s\n", waves, run([&] { hipLaunchKernelGGL(k32<1>, dim3(256), dim3(threads), 0, 0, out, iters, 1.f, 2.f); }, n32 * 1 * 4096));
+    printf("32x32x2 f32, %d waves/CU, 2 acc : %.1f TFLOP/s\n", waves, run([&] { hipLaunchKernelGGL(k32<2>, dim3(256), dim3(threads), 0, 0, out, iters, 1.f, 2.f); }, n32 * 2 * 4096));
+    printf("16x16x4 f32, %d waves/CU, 1 acc : %.1f TFLOP/s\n", waves, run([&] { hipLaunchKernelGGL(k16<1>, dim3(256), dim3(threads), 0, 0, out, iters, 1.f, 2.f); }, n32 * 1 * 2048));
+    printf("16x16x4 f32, %d waves/CU, 2 acc : %.1f TFLOP/s\n", waves, run([&] { hipLaunchKernelGGL(k16<2>, dim3(256), dim3(threads), 0, 0, out, iters, 1.f, 2.f); }, n32 * 2 * 2048));
+  }
+  return 0;
+}
