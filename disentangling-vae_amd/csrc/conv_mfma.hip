@@ -317,36 +317,41 @@ __global__ __launch_bounds__(512) void k_down32v2(const float* __restrict__ big,
 #pragma unroll
       for (int r = 0; r < 4; ++r) mv[r] = mask[obase + r * 32];
     }
-    f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // 4 independent accumulator chains (index = ci % 4): consecutive MFMAs never depend on each
+    // other (16x16x4: 40-cycle dependent latency vs 32-cycle issue, plus the issue-slot cliff for
+    // back-to-back dependent MFMAs with other instructions in between)
+    f32x4v acc[4];
 #pragma unroll
-    for (int kh = 0; kh < 4; ++kh) {
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // operands of tap t+1 are read from LDS before the 8 MFMAs of tap t are issued (register
+    // ping-pong); sched_group_barrier pins that order so the LDS latency hides under the MFMAs
+    f32x4 A0[2], B0[2], A1[2], B1[2];
+    auto rd = [&](int tap, int slot) {
+      const int kh = tap >> 2, kw = tap & 3;
       const int r = 2 * sy_l + kh;
+      const int par = kw & 1, cw = sx + (kw >> 1);
+      const float* arow = bt + ((r * 2 + par) * G::CW + cw) * 32;
+      const int sw = swz_big<HS>(r, cw);
+      const float* brow = wl + (tap * 8) * 128 + co * 4;
+      A0[slot] = *reinterpret_cast<const f32x4*>(arow + ((kq ^ sw) << 2));
+      B0[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128);
+      A1[slot] = *reinterpret_cast<const f32x4*>(arow + (((4 + kq) ^ sw) << 2));
+      B1[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128);
+    };
+    rd(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // prologue: the reads of tap 0
 #pragma unroll
-      for (int kw = 0; kw < 4; ++kw) {
-        const int par = kw & 1, cw = sx + (kw >> 1);
-        const float* arow = bt + ((r * 2 + par) * G::CW + cw) * 32;
-        const int sw = swz_big<HS>(r, cw);
-        const float* brow = wl + ((kh * 4 + kw) * 8) * 128 + co * 4;
-        {
-          const int chunk = kq;
-          f32x4 a = *reinterpret_cast<const f32x4*>(arow + ((chunk ^ sw) << 2));
-          f32x4 b = *reinterpret_cast<const f32x4*>(brow + chunk * 128);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc0, 0, 0, 0);
-        }
-        {
-          const int chunk = 4 + kq;
-          f32x4 a = *reinterpret_cast<const f32x4*>(arow + ((chunk ^ sw) << 2));
-          f32x4 b = *reinterpret_cast<const f32x4*>(brow + chunk * 128);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
-        }
-      }
+    for (int t = 0; t < 16; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < 16) rd(t + 1, cur ^ 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B0[cur][j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B1[cur][j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads (next tap)
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMAs (this tap)
     }
+    const f32x4v acc0 = acc[0] + acc[1], acc1 = acc[2] + acc[3];
     // hand over to the next unit: its tile (prefetched during the MFMAs) goes to the other buffer
     if (unit + stride < n_units) store_big<HS>(pf, sd, buf ? bt0 : bt1);
     __syncthreads();
@@ -444,29 +449,37 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
     }
     if (prev_unit >= 0) up_store<HS>(vals, out, prev_unit, N, mt, py, px, h, i);
 
-    f32x16 acc;
+    // 4 independent accumulator chains (index = ci % 4), summed after the K loop
+    f32x16 accs[4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int ty = 0; ty < 2; ++ty) {
-      const int kh = 1 - py + 2 * ty;
-      const int row = m + (py - ty) + 1;
+      for (int e = 0; e < 16; ++e) accs[c][e] = 0.f;
+    // 16 groups g = (ty, tx, q) of 4 MFMAs; operands of group g+1 are read before group g issues
+    f32x4 Av[2], Bv[2];
+    auto rd = [&](int g, int slot) {
+      const int ty = g >> 3, tx = (g >> 2) & 1, q = g & 3;
+      const int kh = 1 - py + 2 * ty, kw = 1 - px + 2 * tx;
+      const int row = m + (py - ty) + 1, col = l + (px - tx) + 1;
+      const float* arow = st + ((img_l * G::SROWS + row) * G::SCOLS + col) * 32;
+      const int sw = swz_small<HS>(row, col);
+      const float* brow = wl + ((kh * 4 + kw) * 8) * 128 + i * 4;
+      const int chunk = 2 * q + h;
+      Av[slot] = *reinterpret_cast<const f32x4*>(arow + ((chunk ^ sw) << 2));
+      Bv[slot] = *reinterpret_cast<const f32x4*>(brow + chunk * 128);
+    };
+    rd(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // prologue: the reads of group 0
 #pragma unroll
-      for (int tx = 0; tx < 2; ++tx) {
-        const int kw = 1 - px + 2 * tx;
-        const int col = l + (px - tx) + 1;
-        const float* arow = st + ((img_l * G::SROWS + row) * G::SCOLS + col) * 32;
-        const int sw = swz_small<HS>(row, col);
-        const float* brow = wl + ((kh * 4 + kw) * 8) * 128 + i * 4;
+    for (int g = 0; g < 16; ++g) {
+      const int cur = g & 1;
+      if (g + 1 < 16) rd(g + 1, cur ^ 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int chunk = 2 * q + h;
-          f32x4 a = *reinterpret_cast<const f32x4*>(arow + ((chunk ^ sw) << 2));
-          f32x4 b = *reinterpret_cast<const f32x4*>(brow + chunk * 128);
-          MFMA4(acc, a, b)
-        }
-      }
+      for (int j = 0; j < 4; ++j) accs[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(Av[cur][j], Bv[cur][j], accs[j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads (next group)
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMAs (this group)
     }
+    const f32x16 acc = (accs[0] + accs[1]) + (accs[2] + accs[3]);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       float v = epilogue_act(acc[e] + bv, act);
@@ -495,9 +508,9 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
   init_big_slots<HS>(sd, tid);
   f32x4 pf[G::BIG_NPF];
   f32x4 pfs;
-  f32x16 acc0, acc1;
+  f32x16 acc0, acc1, acc2, acc3;   // taps (kh, 2*kwb) / (kh, 2*kwb+1), even / odd k-steps
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; }
   float sumS = 0.f, sumB0 = 0.f, sumB1 = 0.f;
 
   int unit = blockIdx.x;
@@ -517,23 +530,40 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
     __syncthreads();
     if (unit + (int)gridDim.x < n_units) { load_big<HS>(pf, sd, big, unit + gridDim.x, N); load_sp(unit + gridDim.x); }
 
-#pragma unroll 8
-    for (int t = 0; t < 32; ++t) {
-      const int p = 2 * t + h;
-      const int img_l = p / (G::R * HS), sy_l = (p / HS) % G::R, sx = p % HS;
-      const float a = sp[p * 32 + i];
-      const int r = 2 * sy_l + kh;
-      const int cw = sx + kwb;
-      const float* b0p = bt + (((img_l * G::BROWS + r) * 2 + 0) * G::CW + cw) * 32;
-      const int sw = swz_big<HS>(r, cw);
-      const int off = (((i >> 2) ^ sw) << 2) + (i & 3);
-      const float b0 = b0p[off];
-      const float b1 = b0p[G::CW * 32 + off];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-      sumS += a; sumB0 += b0; sumB1 += b1;
+    // 16 groups of 2 k-steps (4 pixels): 6 LDS reads + 4 MFMAs; the reads of group g+1 are issued
+    // before the MFMAs of group g (register ping-pong, order pinned by sched_group_barrier)
+    float av[2][2], b0v[2][2], b1v[2][2];
+    auto rd = [&](int g, int slot) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = 2 * (2 * g + u) + h;
+        const int img_l = p / (G::R * HS), sy_l = (p / HS) % G::R, sx = p % HS;
+        av[slot][u] = sp[p * 32 + i];
+        const int r = 2 * sy_l + kh;
+        const int cw = sx + kwb;
+        const float* b0p = bt + (((img_l * G::BROWS + r) * 2 + 0) * G::CW + cw) * 32;
+        const int sw = swz_big<HS>(r, cw);
+        const int off = (((i >> 2) ^ sw) << 2) + (i & 3);
+        b0v[slot][u] = b0p[off];
+        b1v[slot][u] = b0p[G::CW * 32 + off];
+      }
+    };
+    rd(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int cur = g & 1;
+      if (g + 1 < 16) rd(g + 1, cur ^ 1);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][0], b0v[cur][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][0], b1v[cur][0], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][1], b0v[cur][1], acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][1], b1v[cur][1], acc3, 0, 0, 0);
+      sumS += av[cur][0] + av[cur][1]; sumB0 += b0v[cur][0] + b0v[cur][1]; sumB1 += b1v[cur][0] + b1v[cur][1];
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // 6 DS reads (next group)
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMAs (this group)
     }
   }
+  acc0 += acc2; acc1 += acc3;
   // partial results of this workgroup
   float* wsw = ws + (long)blockIdx.x * 16384;
   const int tap0 = kh * 4 + 2 * kwb;
@@ -585,12 +615,20 @@ __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict_
     __syncthreads();
     const float* wsb = ws + (long)WG_MAX_BLOCKS * 16384;
     const int c = threadIdx.x & 31, part = threadIdx.x >> 5;   // 8 partial groups
-    float b = 0.f;
-    for (int g2 = part; g2 < nblk; g2 += 8) {
-      const float* q = wsb + (long)g2 * 160;
-      if (bias_from_big) b += (q[32 + c] + q[64 + c]) + (q[96 + c] + q[128 + c]);
-      else b += q[c];
+    // 4 independent accumulators: the loads of 4 partial blocks are in flight together
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int g2 = part; g2 < nblk; g2 += 32) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int gg = g2 + 8 * u;
+        if (gg < nblk) {
+          const float* q = wsb + (long)gg * 160;
+          if (bias_from_big) bq[u] += (q[32 + c] + q[64 + c]) + (q[96 + c] + q[128 + c]);
+          else bq[u] += q[c];
+        }
+      }
     }
+    const float b = (bq[0] + bq[1]) + (bq[2] + bq[3]);
     float* rb = &red[0][0];
     rb[part * 32 + c] = b;
     __syncthreads();

@@ -350,18 +350,28 @@ __global__ __launch_bounds__(256) void k_wgrad_thin_reduce(const float* __restri
     __syncthreads();
     // bias sums: slot [0,32) = sum of the small side per cs; slots 32.. = per (cb,tap) column sums of the big side
     const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
-    float b = 0.f;
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};   // 4 partial blocks in flight per lane
     if (!bias_from_big) {
-      for (int g = part; g < nblk; g += 8) b += ws[(long)g * STRIDE + NT * 1024 + c];
+      for (int g = part; g < nblk; g += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (g + 8 * u < nblk) bq[u] += ws[(long)(g + 8 * u) * STRIDE + NT * 1024 + c];
+      }
     } else if (c < C) {
       // every big pixel appears exactly once under taps (kh,kw) in {1,2}x{1,2}
       const int t5 = c * 16 + 5, t6 = c * 16 + 6, t9 = c * 16 + 9, t10 = c * 16 + 10;
-      for (int g = part; g < nblk; g += 8) {
-        const float* q = ws + (long)g * STRIDE + NT * 1024 + 32;
-        b += (q[(t5 >> 5) * 32 + (t5 & 31)] + q[(t6 >> 5) * 32 + (t6 & 31)]) +
-             (q[(t9 >> 5) * 32 + (t9 & 31)] + q[(t10 >> 5) * 32 + (t10 & 31)]);
+      for (int g = part; g < nblk; g += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (g + 8 * u < nblk) {
+            const float* q = ws + (long)(g + 8 * u) * STRIDE + NT * 1024 + 32;
+            bq[u] += (q[(t5 >> 5) * 32 + (t5 & 31)] + q[(t6 >> 5) * 32 + (t6 & 31)]) +
+                     (q[(t9 >> 5) * 32 + (t9 & 31)] + q[(t10 >> 5) * 32 + (t10 & 31)]);
+          }
+        }
       }
     }
+    const float b = (bq[0] + bq[1]) + (bq[2] + bq[3]);
     float* rb = &red[0][0];
     rb[part * 32 + c] = b;
     __syncthreads();
