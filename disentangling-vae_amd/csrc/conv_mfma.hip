@@ -58,12 +58,12 @@ struct SlotDesc {
   int rimg[NPF];   // row-in-tile | (image-in-unit << 8) | (column valid << 16)
 };
 
-template <int HS>
-__device__ __forceinline__ void init_big_slots(SlotDesc<Geo<HS>::BIG_NPF>& d, int tid) {
+template <int HS, int NTHR = 512, int NPF = Geo<HS>::BIG_NPF>
+__device__ __forceinline__ void init_big_slots(SlotDesc<NPF>& d, int tid) {
   using G = Geo<HS>;
 #pragma unroll
-  for (int k = 0; k < G::BIG_NPF; ++k) {
-    int s = tid + k * 512;
+  for (int k = 0; k < NPF; ++k) {
+    int s = tid + k * NTHR;
     d.lds[k] = -1; d.gofs[k] = 0; d.rimg[k] = 0;
     if (s < G::BIG_SLOTS) {
       int chunk = s & 7;
@@ -79,8 +79,8 @@ __device__ __forceinline__ void init_big_slots(SlotDesc<Geo<HS>::BIG_NPF>& d, in
   }
 }
 
-template <int HS>
-__device__ __forceinline__ void load_big(f32x4 (&pf)[Geo<HS>::BIG_NPF], const SlotDesc<Geo<HS>::BIG_NPF>& d,
+template <int HS, int NPF = Geo<HS>::BIG_NPF>
+__device__ __forceinline__ void load_big(f32x4 (&pf)[NPF], const SlotDesc<NPF>& d,
                                          const float* __restrict__ big, int unit, int N) {
   using G = Geo<HS>;
   const long P0 = (long)unit * G::U;
@@ -88,7 +88,7 @@ __device__ __forceinline__ void load_big(f32x4 (&pf)[Geo<HS>::BIG_NPF], const Sl
   const int sy0 = (int)(P0 % (HS * HS)) / HS;
   const float* base = big + ((long)n0 * G::HB + 2 * sy0) * G::HB * 32;
 #pragma unroll
-  for (int k = 0; k < G::BIG_NPF; ++k) {
+  for (int k = 0; k < NPF; ++k) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int r = d.rimg[k] & 0xff, img = (d.rimg[k] >> 8) & 0xff;
     const int by = 2 * sy0 - 1 + r;
@@ -98,12 +98,11 @@ __device__ __forceinline__ void load_big(f32x4 (&pf)[Geo<HS>::BIG_NPF], const Sl
   }
 }
 
-template <int HS>
-__device__ __forceinline__ void store_big(const f32x4 (&pf)[Geo<HS>::BIG_NPF], const SlotDesc<Geo<HS>::BIG_NPF>& d,
+template <int HS, int NPF = Geo<HS>::BIG_NPF>
+__device__ __forceinline__ void store_big(const f32x4 (&pf)[NPF], const SlotDesc<NPF>& d,
                                           float* bt) {
-  using G = Geo<HS>;
 #pragma unroll
-  for (int k = 0; k < G::BIG_NPF; ++k)
+  for (int k = 0; k < NPF; ++k)
     if (d.lds[k] >= 0) *reinterpret_cast<f32x4*>(bt + d.lds[k]) = pf[k];
 }
 
@@ -366,6 +365,116 @@ __global__ __launch_bounds__(512) void k_down32v2(const float* __restrict__ big,
   }
 }
 
+// ---- down, version 3 (HS = 16, 8): wave-specialised ---------------------------------------
+// Waves 0-3 (one per SIMD) do nothing but MFMAs: each owns 16 pixels x all 32 output channels of the
+// unit (256 v_mfma_f32_16x16x4_f32, 8 independent accumulator chains, operands prefetched one tap
+// ahead).  Waves 4-7 are loaders: they fetch the tile of unit u+2 from HBM into registers and write
+// the tile of unit u+1 into the idle LDS buffer while the compute waves run.  One barrier per unit;
+// the matrix pipe only idles for the barrier + 8 stores per lane.
+template <int HS, bool MASK>
+__global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, const float* __restrict__ mask,
+                                                  float* __restrict__ out, int N, int act, int n_units) {
+  using G = Geo<HS>;
+  static_assert(G::IMGS == 1, "one image per unit");
+  constexpr int LNPF = (G::BIG_SLOTS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                          // 16384 floats
+  float* bt0 = smem + 16384;
+  float* bt1 = bt0 + G::BIG_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_compute = wv < 4;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int p = (wv & 3) * 16 + i16;
+  const int sy_l = (p / HS) % G::R, sx = p % HS;
+  const int stride = gridDim.x;
+
+  SlotDesc<LNPF> sd;
+  f32x4 pf[LNPF];
+  const int ltid = tid - 256;
+  if (!is_compute) init_big_slots<HS, 256, LNPF>(sd, ltid);
+  int unit = blockIdx.x;
+  if (!is_compute && unit < n_units) load_big<HS, LNPF>(pf, sd, big, unit, N);
+  stage_weights<true>(w, wl, tid);
+  if (!is_compute && unit < n_units) store_big<HS, LNPF>(pf, sd, bt0);
+  __syncthreads();
+  if (!is_compute && unit + stride < n_units) load_big<HS, LNPF>(pf, sd, big, unit + stride, N);
+  const float bv0 = bias ? bias[i16] : 0.f, bv1 = bias ? bias[16 + i16] : 0.f;
+  int buf = 0;
+  if (is_compute) __builtin_amdgcn_s_setprio(1);
+
+  for (; unit < n_units; unit += stride) {
+    const float* bt = buf ? bt1 : bt0;
+    const long obase = ((long)unit * G::U + (wv & 3) * 16 + 4 * kq) * 32 + i16;
+    f32x4v acc[2][4];
+    float mv[2][4];
+    if (is_compute) {
+      if (MASK) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mv[nh][r] = mask[obase + r * 32 + nh * 16];
+      }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[nh][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      f32x4 A0[2], A1[2], B00[2], B01[2], B10[2], B11[2];
+      auto rd = [&](int tap, int slot) {
+        const int kh = tap >> 2, kw = tap & 3;
+        const int r = 2 * sy_l + kh;
+        const int par = kw & 1, cw = sx + (kw >> 1);
+        const float* arow = bt + ((r * 2 + par) * G::CW + cw) * 32;
+        const int sw = swz_big<HS>(r, cw);
+        const float* brow = wl + (tap * 8) * 128 + i16 * 4;
+        A0[slot] = *reinterpret_cast<const f32x4*>(arow + ((kq ^ sw) << 2));
+        A1[slot] = *reinterpret_cast<const f32x4*>(arow + (((4 + kq) ^ sw) << 2));
+        B00[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128);
+        B01[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128 + 64);
+        B10[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128);
+        B11[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128 + 64);
+      };
+      rd(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < 16) rd(t + 1, cur ^ 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B00[cur][j], acc[0][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B01[cur][j], acc[1][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B10[cur][j], acc[0][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B11[cur][j], acc[1][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // 6 DS reads (next tap)
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMAs (this tap)
+      }
+    } else {
+      // loader: tile u+1 (in registers since the previous unit) -> the idle buffer
+      if (unit + stride < n_units) store_big<HS, LNPF>(pf, sd, buf ? bt0 : bt1);
+    }
+    __syncthreads();
+    if (is_compute) {
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const f32x4v a = (acc[nh][0] + acc[nh][1]) + (acc[nh][2] + acc[nh][3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = epilogue_act(a[r] + (nh ? bv1 : bv0), act);
+          if (MASK) v = mv[nh][r] > 0.f ? v : 0.f;
+          out[obase + r * 32 + nh * 16] = v;
+        }
+      }
+    } else {
+      if (unit + 2 * stride < n_units) load_big<HS, LNPF>(pf, sd, big, unit + 2 * stride, N);
+    }
+    buf ^= 1;
+  }
+}
+
 // ---- up: small -> big --------------------------------------------------------------------
 // output offsets of the 16 D-fragment rows of this wave's (class, M-tile) for a given unit
 template <int HS>
@@ -493,6 +602,9 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
 
 // ---- wgrad ---------------------------------------------------------------------------------
 #define WG_MAX_BLOCKS 256
+// stride between per-workgroup partial buffers: NOT a multiple of 64 KB, so that the reduce kernel's
+// loads of one output across all partials spread over HBM channels instead of hammering one
+#define WG_STRIDE (16384 + 320)
 template <int HS>
 __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, const float* __restrict__ small,
                                                  float* __restrict__ ws, int N, int n_units) {
@@ -565,7 +677,7 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
   }
   acc0 += acc2; acc1 += acc3;
   // partial results of this workgroup
-  float* wsw = ws + (long)blockIdx.x * 16384;
+  float* wsw = ws + (long)blockIdx.x * WG_STRIDE;
   const int tap0 = kh * 4 + 2 * kwb;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
@@ -573,7 +685,7 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
     wsw[(tap0 * 32 + cs) * 32 + i] = acc0[e];
     wsw[((tap0 + 1) * 32 + cs) * 32 + i] = acc1[e];
   }
-  float* wsb = ws + (long)WG_MAX_BLOCKS * 16384 + (long)blockIdx.x * 160;
+  float* wsb = wsw + 16384;   // 160 bias floats follow the 16384 weight partials
   sumS += __shfl_xor(sumS, 32, 64);
   sumB0 += __shfl_xor(sumB0, 32, 64);
   sumB1 += __shfl_xor(sumB1, 32, 64);
@@ -587,9 +699,40 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
   }
 }
 
+// bias gradient: 2 workgroups x (16 channels x 16 partial-groups)
+__device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws, float* __restrict__ db,
+                                                    int bias_from_big, int nblk, int blk) {
+  __shared__ float red[16][16];
+  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const int c = blk * 16 + o;
+  const float* wsb = ws + 16384;
+  float pv[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int g = gq; g < nblk; g += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int gg = g + 16 * u;
+      const float* q = wsb + (long)(gg < nblk ? gg : 0) * WG_STRIDE;
+      float v = bias_from_big ? (q[32 + c] + q[64 + c]) + (q[96 + c] + q[128 + c]) : q[c];
+      pv[u] += gg < nblk ? v : 0.f;
+    }
+  }
+  red[gq][o] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+  __syncthreads();
+  if (gq == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][o];
+    db[c] = t;
+  }
+}
+
 // 1024 workgroups x (16 outputs x 16 partial-groups), 8 loads in flight per lane, fixed order
 __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                         float* __restrict__ db, int bias_from_big, int nblk) {
+  if (blockIdx.x >= 1024) {                          // the last two workgroups reduce the bias gradient
+    if (db) wgrad32_bias_reduce(ws, db, bias_from_big, nblk, blockIdx.x - 1024);
+    return;
+  }
   __shared__ float red[16][16];
   const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + o;             // (tap, cs, cb)
@@ -599,9 +742,9 @@ __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict_
   int g = gq;
   for (; g + 112 < nblk; g += 128) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) pv[u] += ws[(long)(g + 16 * u) * 16384 + idx];
+    for (int u = 0; u < 8; ++u) pv[u] += ws[(long)(g + 16 * u) * WG_STRIDE + idx];
   }
-  for (; g < nblk; g += 16) pv[0] += ws[(long)g * 16384 + idx];
+  for (; g < nblk; g += 16) pv[0] += ws[(long)g * WG_STRIDE + idx];
   red[gq][o] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
   __syncthreads();
   if (gq == 0) {
@@ -611,37 +754,9 @@ __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict_
     const int tap = idx >> 10, cs = (idx >> 5) & 31, cb = idx & 31;
     dw[(cs * 32 + cb) * 16 + tap] = v;
   }
-  if (db && blockIdx.x == 0) {
-    __syncthreads();
-    const float* wsb = ws + (long)WG_MAX_BLOCKS * 16384;
-    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;   // 8 partial groups
-    // 4 independent accumulators: the loads of 4 partial blocks are in flight together
-    float bq[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int g2 = part; g2 < nblk; g2 += 32) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int gg = g2 + 8 * u;
-        if (gg < nblk) {
-          const float* q = wsb + (long)gg * 160;
-          if (bias_from_big) bq[u] += (q[32 + c] + q[64 + c]) + (q[96 + c] + q[128 + c]);
-          else bq[u] += q[c];
-        }
-      }
-    }
-    const float b = (bq[0] + bq[1]) + (bq[2] + bq[3]);
-    float* rb = &red[0][0];
-    rb[part * 32 + c] = b;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-      float t = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t += rb[k * 32 + threadIdx.x];
-      db[threadIdx.x] = t;
-    }
-  }
 }
 
-size_t wgrad32_ws_floats() { return (size_t)WG_MAX_BLOCKS * 16384 + (size_t)WG_MAX_BLOCKS * 160; }
+size_t wgrad32_ws_floats() { return (size_t)WG_MAX_BLOCKS * WG_STRIDE; }
 
 // ---- launchers -----------------------------------------------------------------------------
 static int units_for(int N, int HS) { return (int)(((long)N * HS * HS + 63) / 64); }
@@ -660,6 +775,24 @@ static int launch_down_v2(const ConvArgs& a, hipStream_t s) {
   }
   if (a.mask) hipLaunchKernelGGL((k_down32v2<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
   else hipLaunchKernelGGL((k_down32v2<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int HS>
+static int launch_down_ws(const ConvArgs& a, hipStream_t s) {
+  using G = Geo<HS>;
+  const int n_units = units_for(a.N, HS);
+  const int grid = n_units < 256 ? n_units : 256;
+  const size_t lds = (16384 + 2 * G::BIG_FLOATS) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_down32ws<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_down32ws<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  else hipLaunchKernelGGL((k_down32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -711,7 +844,7 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units);
   DVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(1024), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(1024 + 2), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -724,10 +857,13 @@ static bool mfma32_applicable(int Cb, int Cs, int Hs, int Ws, int l0, int l1, in
 int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
   if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.big_layout, a.out_layout, DVAE_NHWC)) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
-  static const bool v1 = getenv("DVAE_DOWN_V1") != nullptr;   // A/B switch: K-split 32x32x2 kernel
+  // A/B switches: DVAE_DOWN_V1 = K-split 32x32x2 kernel, DVAE_DOWN_V2 = 8 symmetric waves;
+  // default = wave-specialised (4 MFMA waves + 4 loader waves)
+  static const bool v1 = getenv("DVAE_DOWN_V1") != nullptr;
+  static const bool v2 = getenv("DVAE_DOWN_V2") != nullptr;
   switch (a.Hs) {
-    case 16: return v1 ? launch_down_t<16>(a, s) : launch_down_v2<16>(a, s);
-    case 8: return v1 ? launch_down_t<8>(a, s) : launch_down_v2<8>(a, s);
+    case 16: return v1 ? launch_down_t<16>(a, s) : v2 ? launch_down_v2<16>(a, s) : launch_down_ws<16>(a, s);
+    case 8: return v1 ? launch_down_t<8>(a, s) : v2 ? launch_down_v2<8>(a, s) : launch_down_ws<8>(a, s);
     default: return launch_down_t<4>(a, s);
   }
 }

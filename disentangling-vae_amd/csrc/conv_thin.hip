@@ -315,12 +315,56 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const float* __restrict__ bi
   }
 }
 
+// bias gradient of the thin layers: (16 channels x 16 partial-groups) per workgroup
+template <int C>
+__device__ __forceinline__ void wgrad_thin_bias_reduce(const float* __restrict__ ws, float* __restrict__ db,
+                                                       int bias_from_big, int nblk, int blk) {
+  constexpr int NT = (16 * C + 31) / 32;
+  constexpr int STRIDE = NT * 1024 + 32 + NT * 32;
+  __shared__ float redb[16][16];
+  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const int c = blk * 16 + o;
+  const int nout = bias_from_big ? C : 32;
+  // slot [0,32) = sum of the small side per cs; slots 32.. = per (cb,tap) column sums of the big side, of which
+  // taps (kh,kw) in {1,2}x{1,2} cover every big pixel exactly once
+  const int cc = c < nout ? c : 0;
+  const int t5 = cc * 16 + 5, t6 = cc * 16 + 6, t9 = cc * 16 + 9, t10 = cc * 16 + 10;
+  float pv[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int g = gq; g < nblk; g += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int gg = g + 16 * u;
+      const float* q = ws + (long)(gg < nblk ? gg : 0) * STRIDE + NT * 1024;
+      float v;
+      if (bias_from_big)
+        v = (q[32 + (t5 >> 5) * 32 + (t5 & 31)] + q[32 + (t6 >> 5) * 32 + (t6 & 31)]) +
+            (q[32 + (t9 >> 5) * 32 + (t9 & 31)] + q[32 + (t10 >> 5) * 32 + (t10 & 31)]);
+      else
+        v = q[cc];
+      pv[u] += gg < nblk ? v : 0.f;
+    }
+  }
+  redb[gq][o] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+  __syncthreads();
+  if (gq == 0 && c < nout) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += redb[k][o];
+    db[c] = t;
+  }
+}
+
 // 16 outputs x 16 partial-groups per workgroup; 8 loads in flight per lane; fixed summation order
 template <int C>
 __global__ __launch_bounds__(256) void k_wgrad_thin_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                            float* __restrict__ db, int bias_from_big, int nblk) {
   constexpr int NT = (16 * C + 31) / 32;
   constexpr int STRIDE = NT * 1024 + 32 + NT * 32;
+  constexpr int NB = (32 * 16 * C + 15) / 16;        // workgroups reducing dw; two more reduce db
+  if ((int)blockIdx.x >= NB) {
+    if (db) wgrad_thin_bias_reduce<C>(ws, db, bias_from_big, nblk, blockIdx.x - NB);
+    return;
+  }
   __shared__ float red[16][16];
   const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
   // dw[cs][cb][tap] : element idx = cs * 16C + nidx, nidx = cb*16 + tap
@@ -345,43 +389,6 @@ __global__ __launch_bounds__(256) void k_wgrad_thin_reduce(const float* __restri
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][o];
     dw[idx] = t;
-  }
-  if (db && blockIdx.x == 0) {
-    __syncthreads();
-    // bias sums: slot [0,32) = sum of the small side per cs; slots 32.. = per (cb,tap) column sums of the big side
-    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
-    float bq[4] = {0.f, 0.f, 0.f, 0.f};   // 4 partial blocks in flight per lane
-    if (!bias_from_big) {
-      for (int g = part; g < nblk; g += 32) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (g + 8 * u < nblk) bq[u] += ws[(long)(g + 8 * u) * STRIDE + NT * 1024 + c];
-      }
-    } else if (c < C) {
-      // every big pixel appears exactly once under taps (kh,kw) in {1,2}x{1,2}
-      const int t5 = c * 16 + 5, t6 = c * 16 + 6, t9 = c * 16 + 9, t10 = c * 16 + 10;
-      for (int g = part; g < nblk; g += 32) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (g + 8 * u < nblk) {
-            const float* q = ws + (long)(g + 8 * u) * STRIDE + NT * 1024 + 32;
-            bq[u] += (q[(t5 >> 5) * 32 + (t5 & 31)] + q[(t6 >> 5) * 32 + (t6 & 31)]) +
-                     (q[(t9 >> 5) * 32 + (t9 & 31)] + q[(t10 >> 5) * 32 + (t10 & 31)]);
-          }
-        }
-      }
-    }
-    const float b = (bq[0] + bq[1]) + (bq[2] + bq[3]);
-    float* rb = &red[0][0];
-    rb[part * 32 + c] = b;
-    __syncthreads();
-    const int nout = bias_from_big ? C : 32;
-    if ((int)threadIdx.x < nout) {
-      float t = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t += rb[k * 32 + threadIdx.x];
-      db[threadIdx.x] = t;
-    }
   }
 }
 
@@ -425,11 +432,11 @@ int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db
   if (Cb == 1) {
     hipLaunchKernelGGL(k_wgrad_thin<1>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(32), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(32 + 2), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   } else {
     hipLaunchKernelGGL(k_wgrad_thin<3>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(96), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(96 + 2), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   }
   DVAE_CHECK_LAUNCH();
   return 0;
