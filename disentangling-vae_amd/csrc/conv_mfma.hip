@@ -159,11 +159,20 @@ __device__ __forceinline__ void store_small_halo(const f32x4 (&pf)[Geo<HS>::SH_N
 // and n the output channel.  KC_IS_CB: down (contract over cb, n = cs); else up (contract cs).
 template <bool KC_IS_CB>
 __device__ __forceinline__ void stage_weights(const float* __restrict__ w, float* wl, int tid) {
-  for (int idx = tid; idx < 16384; idx += 512) {
-    int cs = idx >> 9, cb = (idx >> 4) & 31, tap = idx & 15;
-    int kc = KC_IS_CB ? cb : cs;
-    int n = KC_IS_CB ? cs : cb;
-    wl[((tap * 8 + (kc >> 2)) * 32 + n) * 4 + (kc & 3)] = w[idx];
+  // all 8 float4 loads of a thread are issued before the first LDS write: ONE memory latency per
+  // workgroup instead of one per loop iteration (the staging is on every launch's critical path)
+  f32x4 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(w + (tid + k * 512) * 4);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = (tid + k * 512) * 4;            // (cs, cb, tap..tap+3)
+    const int cs = idx >> 9, cb = (idx >> 4) & 31, tap = idx & 15;
+    const int kc = KC_IS_CB ? cb : cs;
+    const int n = KC_IS_CB ? cs : cb;
+    float* dst = wl + (((kc >> 2) * 32 + n) * 4 + (kc & 3));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[(tap + j) * 1024] = v[k][j];
   }
 }
 
@@ -374,9 +383,11 @@ __global__ __launch_bounds__(512) void k_down32v2(const float* __restrict__ big,
 template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ mask,
-                                                  float* __restrict__ out, int N, int act, int n_units) {
+                                                  float* __restrict__ out, int N, int act_flags, int n_units) {
   using G = Geo<HS>;
   static_assert(G::IMGS == 1, "one image per unit");
+  const int act = act_flags & 0xff;
+  const int abl = act_flags >> 8;   // timing-ablation flags (DVAE_ABLATE, debugging only; results invalid)
   constexpr int LNPF = (G::BIG_SLOTS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                          // 16384 floats
@@ -435,6 +446,7 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
         B10[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128);
         B11[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128 + 64);
       };
+      if (!(abl & 8)) {
       rd(0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
@@ -452,9 +464,10 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // 6 DS reads (next tap)
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMAs (this tap)
       }
+      }
     } else {
       // loader: tile u+1 (in registers since the previous unit) -> the idle buffer
-      if (unit + stride < n_units) store_big<HS, LNPF>(pf, sd, buf ? bt0 : bt1);
+      if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pf, sd, buf ? bt0 : bt1);
     }
     __syncthreads();
     if (is_compute) {
@@ -465,11 +478,11 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
         for (int r = 0; r < 4; ++r) {
           float v = epilogue_act(a[r] + (nh ? bv1 : bv0), act);
           if (MASK) v = mv[nh][r] > 0.f ? v : 0.f;
-          out[obase + r * 32 + nh * 16] = v;
+          if (!(abl & 4)) out[obase + r * 32 + nh * 16] = v;
         }
       }
     } else {
-      if (unit + 2 * stride < n_units) load_big<HS, LNPF>(pf, sd, big, unit + 2 * stride, N);
+      if (unit + 2 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pf, sd, big, unit + 2 * stride, N);
     }
     buf ^= 1;
   }
@@ -791,8 +804,10 @@ static int launch_down_ws(const ConvArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_down32ws<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
-  else hipLaunchKernelGGL((k_down32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  static const int abl = getenv("DVAE_ABLATE") ? atoi(getenv("DVAE_ABLATE")) : 0;
+  const int af = a.act | (abl << 8);
+  if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
+  else hipLaunchKernelGGL((k_down32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -74,9 +74,16 @@ __global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big
   __shared__ float wT[16 * C * 32];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  for (int e = tid; e < 32 * 16 * C; e += 256) {       // w[cs][k] -> wT[k][cs]
-    const int cs = e / (16 * C), k = e - cs * (16 * C);
-    wT[k * 32 + cs] = w[e];
+  {                                                      // w[cs][k] -> wT[k][cs]; loads first, then LDS writes
+    float wv[2 * C];
+#pragma unroll
+    for (int r = 0; r < 2 * C; ++r) wv[r] = w[tid + r * 256];
+#pragma unroll
+    for (int r = 0; r < 2 * C; ++r) {
+      const int e = tid + r * 256;
+      const int cs = e / (16 * C), k = e - cs * (16 * C);
+      wT[k * 32 + cs] = wv[r];
+    }
   }
   BigThinRegs<C> pf;
   int unit = blockIdx.x;
