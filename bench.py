@@ -43,10 +43,19 @@ def flops_per_image_train(C):
     return 6 * macs - 2 * conv[0]
 
 
+# HBM traffic of ONE launch of the dominant kernel at B = 1024, from rocprofv3 PMC passes over this
+# same command (profiles/r01_run6_pmc_summary.md): FETCH_SIZE 7.81e4 KiB (x2: the gfx950 counter
+# reports half of a wide coalesced streaming read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
+# 3.28e4 KiB = 160.0 MB + 33.6 MB.  Algorithmic bytes: 134.2 MB in + 33.6 MB out (the extra 19 % of
+# reads are the 2-row halos of the 64-pixel units).
+PMC_TRAFFIC_BYTES_B1024 = 2 * 7.81e4 * 1024 + 3.28e4 * 1024
+
+
 def dominant_kernel_roofline(B, device):
-    """HIP-event timing of the dominant kernel of the step (conv2 forward shape: the
-    32->32 channel, 32x32 -> 16x16 'down' MFMA kernel k_down32<16>, also used by the
-    convT2 dgrad) on the stream the engine launches on (torch's current stream)."""
+    """HIP-event timing of the dominant kernel of the step -- k_down32ws<16>: the 32->32 channel,
+    32x32 -> 16x16 'down' MFMA kernel that runs conv2 forward and the convT2 dgrad (largest
+    share of GPU time in profiles/r01_run9_kernel_stats.md) -- launched through the C-ABI on the
+    stream the engine uses (torch's current stream)."""
     from disvae_amd import _lib
     from disvae_amd._lib import call, ptr
     x = torch.rand(B, 32, 32, 32, device=device)
@@ -64,11 +73,13 @@ def dominant_kernel_roofline(B, device):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    flops = 2.0 * 4194304 * B              # algorithmic: 2 x MACs/img x images per launch
+    flops = 2.0 * 4194304 * B              # algorithmic: 2 x MACs/img of conv2 x images per launch
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_down32<16> (conv2 fwd / convT2 dgrad)", "achieved": round(achieved, 2),
-            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-            "us_per_launch": round(ms * 1e3, 2), "traffic": None}
+    return {"bound": "mfma", "kernel": "k_down32ws<16> (conv2 fwd / convT2 dgrad), %d images per launch" % B,
+            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "us_per_launch": round(ms * 1e3, 2),
+            "algorithmic_bytes": 167772160.0 * B / 1024,
+            "traffic": round(PMC_TRAFFIC_BYTES_B1024 * B / 1024) if B == 1024 else None}
 
 
 def cpu_baseline(loss, img, B, iters=6, warm=2):
