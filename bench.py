@@ -156,8 +156,9 @@ def main():
     lr = 1e-4 if args.loss == "factor" else 5e-4
     torch.manual_seed(1234)
     model = init_specific_model("Burgess", img, 10).to(device)
-    # torch.optim.Adam as in main.py:208; fused=True = the single-kernel multi-tensor variant
-    optimizer = torch.optim.Adam(model.parameters(), lr=lr, fused=True)
+    # torch.optim.Adam as in main.py:208, fused=True = torch's single-kernel multi-tensor variant, on the
+    # parameter arena viewed as ONE tensor (element-wise identical to Adam over the 28 state_dict views)
+    optimizer = torch.optim.Adam(model.flat_parameters(), lr=lr, fused=True)
     loss_f = get_loss_f(args.loss, n_data=202599, device=device, lr_disc=1e-5, **HP)
     import logging
     trainer = Trainer(model, optimizer, loss_f, device=device, logger=logging.getLogger("bench"),

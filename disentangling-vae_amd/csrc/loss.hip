@@ -10,17 +10,18 @@ namespace dvae {
 #define LOG2PI 1.8378770664093453f
 
 // ---- reparam + KL ----------------------------------------------------------------------------
-// single workgroup: B*D elements, D <= 16 per-dim sums
-__global__ __launch_bounds__(1024) void k_reparam_kl_fwd(const float* __restrict__ ml, const float* __restrict__ eps,
-                                                         float* __restrict__ mu, float* __restrict__ logvar,
-                                                         float* __restrict__ z, float* __restrict__ kl_dim,
-                                                         const float* __restrict__ coef, int B, int D) {
-  __shared__ float red[16][16];
+// elementwise part over B*D threads; the per-dim KL sums go through per-workgroup partials
+// ([64][16] floats, fixed order) and a one-wave finishing kernel
+#define RK_BLOCKS 64
+__global__ __launch_bounds__(256) void k_reparam_kl_fwd(const float* __restrict__ ml, const float* __restrict__ eps,
+                                                        float* __restrict__ mu, float* __restrict__ logvar,
+                                                        float* __restrict__ z, float* __restrict__ kl_part, int B, int D) {
+  __shared__ float red[4][16];
   const int tid = threadIdx.x;
   float kl[16];
 #pragma unroll
   for (int d = 0; d < 16; ++d) kl[d] = 0.f;
-  for (int b = tid; b < B; b += blockDim.x) {
+  for (int b = blockIdx.x * 256 + tid; b < B; b += gridDim.x * 256) {
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
       if (d < D) {
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(1024) void k_reparam_kl_fwd(const float* __restrict
       }
     }
   }
-  if (!kl_dim) return;
+  if (!kl_part) return;
   const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
   for (int d = 0; d < 16; ++d) {
@@ -42,11 +43,16 @@ __global__ __launch_bounds__(1024) void k_reparam_kl_fwd(const float* __restrict
     if (lane == 0) red[wv][d] = v;
   }
   __syncthreads();
-  if (tid < D) {
+  if (tid < 16) kl_part[blockIdx.x * 16 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+__global__ void k_reparam_kl_finish(const float* __restrict__ kl_part, int nblk, float* __restrict__ kl_dim,
+                                    const float* __restrict__ coef, int D) {
+  const int d = threadIdx.x;
+  if (d < 16) {
     float v = 0.f;
-    const int nw = blockDim.x >> 6;
-    for (int w = 0; w < nw; ++w) v += red[w][tid];
-    kl_dim[tid] = v * coef[DVAE_C_INV_B];
+    for (int g = 0; g < nblk; ++g) v += kl_part[g * 16 + d];
+    kl_dim[d] = d < D ? v * coef[DVAE_C_INV_B] : 0.f;
   }
 }
 
@@ -155,15 +161,16 @@ __global__ void k_btcvae_prep(const float* __restrict__ mu, const float* __restr
   tmp[(long)(2 * D + d) * Bg + j] = expf(-l);
 }
 
-// one wave per row i; 4 rows per workgroup; columns j strided over lanes
+// one workgroup (4 waves) per row i: the columns j are split over the 4 waves x 64 lanes, so the
+// serial online-logsumexp chain per lane is Bg/256 long (the kernel is latency-, not throughput-bound)
 template <int D>
 __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z, const float* __restrict__ mu,
                                                     const float* __restrict__ lv, const float* __restrict__ tmp,
                                                     int Bg, int row0, int Bl, int is_mss,
                                                     const float* __restrict__ log_w, float* __restrict__ rowstats) {
+  __shared__ float red[4][2 * (D + 1)];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int il = blockIdx.x * 4 + wv;
-  if (il >= Bl) return;
+  const int il = blockIdx.x;
   const int i = row0 + il;
   const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
   const float* muT = tmp; const float* cT = tmp + (long)D * Bg; const float* ivT = tmp + (long)2 * D * Bg;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
   float mS = -INFINITY, sS = 0.f, md[D], sd[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) { md[d] = -INFINITY; sd[d] = 0.f; }
-  for (int j = lane; j < Bg; j += 64) {
+  for (int j = threadIdx.x; j < Bg; j += 256) {
     const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
     float S = 0.f;
 #pragma unroll
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
     }
     lse_push(mS, sS, S);
   }
-  // wave reduction of the (max, sum) pairs
+  // wave reduction of the (max, sum) pairs, then the 4 waves through LDS
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     float m2 = __shfl_xor(mS, o, 64), s2 = __shfl_xor(sS, o, 64);
@@ -197,6 +204,18 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
     }
   }
   if (lane == 0) {
+    red[wv][0] = mS; red[wv][1] = sS;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { red[wv][2 + 2 * d] = md[d]; red[wv][3 + 2 * d] = sd[d]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) {
+      lse_merge(mS, sS, red[w2][0], red[w2][1]);
+#pragma unroll
+      for (int d = 0; d < D; ++d) lse_merge(md[d], sd[d], red[w2][2 + 2 * d], red[w2][3 + 2 * d]);
+    }
     float* rs = rowstats + (long)il * 16;
     float log_pz = 0.f, log_qzCx = 0.f, log_prod = 0.f;
 #pragma unroll
@@ -454,9 +473,16 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
 // ---- launchers -------------------------------------------------------------------------------
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                           const float* coef, int B, int D, hipStream_t s) {
-  int threads = B >= 1024 ? 1024 : ((B + 63) / 64) * 64;
-  hipLaunchKernelGGL(k_reparam_kl_fwd, dim3(1), dim3(threads), 0, s, ml, eps, mu, logvar, z, kl_dim, coef, B, D);
+  // kl_dim[16..16+RK_BLOCKS*16) is used as scratch for the per-workgroup partial sums
+  int blocks = (B + 255) / 256;
+  if (blocks > RK_BLOCKS) blocks = RK_BLOCKS;
+  float* part = kl_dim ? kl_dim + 16 : nullptr;
+  hipLaunchKernelGGL(k_reparam_kl_fwd, dim3(blocks), dim3(256), 0, s, ml, eps, mu, logvar, z, part, B, D);
   DVAE_CHECK_LAUNCH();
+  if (kl_dim) {
+    hipLaunchKernelGGL(k_reparam_kl_finish, dim3(1), dim3(64), 0, s, part, blocks, kl_dim, coef, D);
+    DVAE_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -484,7 +510,7 @@ int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, 
   const long n = (long)Bg * D;
   hipLaunchKernelGGL(k_btcvae_prep, dim3((n + 255) / 256), dim3(256), 0, s, mu, lv, Bg, D, tmp);
   DVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_btcvae_fwd<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, Bg, row0, Bl, is_mss, log_w,
+  hipLaunchKernelGGL(k_btcvae_fwd<10>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, Bg, row0, Bl, is_mss, log_w,
                      rowstats);
   DVAE_CHECK_LAUNCH();
   return 0;

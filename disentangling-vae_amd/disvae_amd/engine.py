@@ -132,6 +132,8 @@ class VAEEngine:
         self.dec_sizes = [8 << i for i in range(len(self.dec_names))]         # output H of each hidden convT
         self._bufs = {}
         self._ws = None
+        self._ws_side = None
+        self._side = None      # side HIP stream: the FC weight-gradient GEMMs run beside the dgrad chain
 
     @property
     def device(self):
@@ -151,7 +153,21 @@ class VAEEngine:
         if self._ws is None or self._ws.device != self.device:
             n = _lib.lib().dvae_conv_wgrad_ws_floats()
             self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._ws_side = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._side = torch.cuda.Stream(device=self.device)
         return b
+
+    # ---- fork / join of the side stream (weight-gradient GEMMs of the FC layers) ----------------
+    def _side_wgrad(self, x, dy, dw, db, M, K, N):
+        """dw, db <- wgrad(x, dy) on the side stream, ordered after everything enqueued so far on
+        the current stream (the small GEMM then overlaps with the dgrad chain that continues on it)."""
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        call("dvae_linear_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(db), M, K, N, ptr(self._ws_side),
+             self._side.cuda_stream)
+
+    def _join_side(self):
+        torch.cuda.current_stream().wait_stream(self._side)
 
     # ------------------------------------------------------------------ forward
     def encode(self, x, buf, n=None):
@@ -222,18 +238,16 @@ class VAEEngine:
                  NHWC, B, HID, h, h, couts[k], s)
             dy, dy_layout = gx, NHWC
         call("dvae_relayout", ptr(buf.gd3n), NHWC, ptr(buf.gd3), B, HID, 4, 4, s)
-        call("dvae_linear_wgrad", ptr(buf.d2), ptr(buf.gd3), ptr(self.g("decoder.lin3.weight")),
-             ptr(self.g("decoder.lin3.bias")), B, HIDDEN_DIM, HID * 16, ws, s)
+        self._side_wgrad(buf.d2, buf.gd3, self.g("decoder.lin3.weight"), self.g("decoder.lin3.bias"), B, HIDDEN_DIM, HID * 16)
         call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
              B, HIDDEN_DIM, HID * 16, ws, s)
-        call("dvae_linear_wgrad", ptr(buf.d1), ptr(buf.gd2), ptr(self.g("decoder.lin2.weight")),
-             ptr(self.g("decoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
+        self._side_wgrad(buf.d1, buf.gd2, self.g("decoder.lin2.weight"), self.g("decoder.lin2.bias"), B, HIDDEN_DIM, HIDDEN_DIM)
         call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
              B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
-        call("dvae_linear_wgrad", ptr(z), ptr(buf.gd1), ptr(self.g("decoder.lin1.weight")),
-             ptr(self.g("decoder.lin1.bias")), B, D, HIDDEN_DIM, ws, s)
+        self._side_wgrad(z, buf.gd1, self.g("decoder.lin1.weight"), self.g("decoder.lin1.bias"), B, D, HIDDEN_DIM)
         call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
              B, D, HIDDEN_DIM, ws, s)
+        self._join_side()
 
     def encode_backward(self, x, buf, n=None):
         """buf.dml (grad w.r.t. the interleaved mu/logvar output) -> encoder weight grads."""
@@ -241,16 +255,13 @@ class VAEEngine:
         B = x.shape[0] if n is None else n
         c, H, _ = self.img_size
         ws = ptr(self._ws)
-        call("dvae_linear_wgrad", ptr(buf.h2), ptr(buf.dml), ptr(self.g("encoder.mu_logvar_gen.weight")),
-             ptr(self.g("encoder.mu_logvar_gen.bias")), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
+        self._side_wgrad(buf.h2, buf.dml, self.g("encoder.mu_logvar_gen.weight"), self.g("encoder.mu_logvar_gen.bias"), B, HIDDEN_DIM, 2 * self.latent_dim)
         call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
              ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
-        call("dvae_linear_wgrad", ptr(buf.h1), ptr(buf.gh2), ptr(self.g("encoder.lin2.weight")),
-             ptr(self.g("encoder.lin2.bias")), B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
+        self._side_wgrad(buf.h1, buf.gh2, self.g("encoder.lin2.weight"), self.g("encoder.lin2.bias"), B, HIDDEN_DIM, HIDDEN_DIM)
         call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
              B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
-        call("dvae_linear_wgrad", ptr(buf.a_flat), ptr(buf.gh1), ptr(self.g("encoder.lin1.weight")),
-             ptr(self.g("encoder.lin1.bias")), B, HID * 16, HIDDEN_DIM, ws, s)
+        self._side_wgrad(buf.a_flat, buf.gh1, self.g("encoder.lin1.weight"), self.g("encoder.lin1.bias"), B, HID * 16, HIDDEN_DIM)
         call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
              ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, ws, s)
         last = len(self.enc_names) - 1
@@ -268,3 +279,4 @@ class VAEEngine:
             if k > 0:
                 call("dvae_conv4s2_dgrad", ptr(dy), NHWC, ptr(self.p("encoder.%s.weight" % name)), ptr(x_in),
                      ptr(buf.enc_gact[k - 1]), NHWC, B, cin, h_in, h_in, HID, s)
+        self._join_side()

@@ -70,7 +70,7 @@ class _Scratch:
         self.scal = f(_lib.NSCAL)
         self.packed = f(_lib.NPACK)
         self.partials = f(_lib.REC_NPART)
-        self.kl_dim = f(16)
+        self.kl_dim = f(16 + 64 * 16)   # DVAE_KL_FLOATS: per-dim KL + partial-sum scratch
         self.disc_sums = f(4)
         self.log_w = f(4)
         self._log_w_key = None
@@ -180,7 +180,7 @@ class _KLFn(torch.autograd.Function):
         ml = torch.stack((mu, logvar), dim=-1).reshape(B, 2 * D).contiguous()
         scratch.set_coef(INV_B=1.0 / B)
         tmp = torch.empty(3, B, D, dtype=torch.float32, device=mu.device)
-        kl_dim = torch.empty(16, dtype=torch.float32, device=mu.device)
+        kl_dim = torch.empty(16 + 64 * 16, dtype=torch.float32, device=mu.device)
         call("dvae_reparam_kl_fwd", ptr(ml), None, ptr(tmp[0]), ptr(tmp[1]), ptr(tmp[2]), ptr(kl_dim),
              ptr(scratch.coef), B, D, _stream())
         ctx.save_for_backward(mu, logvar)

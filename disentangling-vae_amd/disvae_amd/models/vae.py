@@ -76,6 +76,8 @@ class VAE(nn.Module):
                                                          self._arena.view(name + ".bias")))
         self._engine = None
         self._fwd_version = 0
+        # the whole arena as ONE (unregistered) Parameter: see flat_parameters()
+        object.__setattr__(self, "_flat_param", nn.Parameter(self._arena.flat))
         self.reset_parameters()
 
     # ---- parameter plumbing -------------------------------------------------------------
@@ -94,6 +96,7 @@ class VAE(nn.Module):
             layer = getattr(getattr(self, half), lname)
             layer.weight.data = self._arena.view(name + ".weight")
             layer.bias.data = self._arena.view(name + ".bias")
+        self._flat_param.data = self._arena.flat
         self._engine = None
 
     def _move(self, device):
@@ -136,8 +139,16 @@ class VAE(nn.Module):
             self._engine = VAEEngine(self.img_size, self.latent_dim, self._arena)
         return self._engine
 
+    def flat_parameters(self):
+        """The parameter arena as a single 1-D Parameter (same storage as ``parameters()``).
+        ``torch.optim.Adam(model.flat_parameters(), ...)`` performs exactly the same element-wise
+        update as ``Adam(model.parameters(), ...)`` (the 16-byte alignment padding has zero
+        gradient and stays zero) in one multi-tensor chunk instead of 28."""
+        return [self._flat_param]
+
     def assign_grads(self):
         """Point every Parameter.grad at its slice of the flat gradient arena."""
+        self._flat_param.grad = self._arena.grad
         for name in self._layer_names:
             half, lname = name.split(".")
             layer = getattr(getattr(self, half), lname)

@@ -100,7 +100,9 @@ int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int
 /* ---- reparameterisation + per-dim Gaussian KL: vae.py:52-71, losses.py:452-480 -----------
  * ml[B,2D] is the interleaved output of mu_logvar_gen (encoders.py:87: mu = ml[:,0::2],
  * logvar = ml[:,1::2]).  z = mu + exp(.5 logvar) eps (eps == NULL: z = mu, eval mode).
- * kl_dim[D] (may be NULL) = coef[INV_B] * sum_b 0.5(-1 - lv + mu^2 + e^lv).                 */
+ * kl_dim (may be NULL): float[DVAE_KL_FLOATS]; [0,D) = coef[INV_B] * sum_b 0.5(-1 - lv + mu^2 + e^lv),
+ * the rest is scratch for the per-workgroup partial sums.                                   */
+#define DVAE_KL_FLOATS (16 + 64 * 16)
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z,
                         float* kl_dim, const float* coef, int B, int D, void* stream);
 /* dml[B,2D] (interleaved) from dz[B,D] and optional direct grads dmu_x/dlv_x[B,D];

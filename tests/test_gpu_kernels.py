@@ -165,7 +165,7 @@ def test_reparam_kl(B):
     coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / B
     mld, epsd, coefd = dev(ml), dev(eps), dev(coef)
     mu, lv, z = (torch.empty(B, D, device=DEV) for _ in range(3))
-    kl = torch.zeros(16, device=DEV)
+    kl = torch.zeros(16 + 64 * 16, device=DEV)
     call("dvae_reparam_kl_fwd", ptr(mld), ptr(epsd), ptr(mu), ptr(lv), ptr(z), ptr(kl), ptr(coefd), B, D, stream())
     m_ref, l_ref = ml.view(B, D, 2).unbind(-1)
     assert torch.equal(mu.cpu(), m_ref) and torch.equal(lv.cpu(), l_ref)
