@@ -380,6 +380,53 @@ __global__ __launch_bounds__(512) void k_down32v2(const float* __restrict__ big,
 // ahead).  Waves 4-7 are loaders: they fetch the tile of unit u+2 from HBM into registers and write
 // the tile of unit u+1 into the idle LDS buffer while the compute waves run.  One barrier per unit;
 // the matrix pipe only idles for the barrier + 8 stores per lane.
+// one unit of MFMA work of a compute wave of k_down32ws: 16 pixels x 32 channels, K = 512
+template <int HS>
+__device__ __forceinline__ void down_ws_mfma(f32x4v (&acc)[2][4], const float* bt, const float* wl, int sy_l, int sx,
+                                             int i16, int kq) {
+  using G = Geo<HS>;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[nh][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  f32x4 A0[2], A1[2], B00[2], B01[2], B10[2], B11[2];
+  auto rd = [&](int tap, int slot) {
+    const int kh = tap >> 2, kw = tap & 3;
+    const int r = 2 * sy_l + kh;
+    const int par = kw & 1, cw = sx + (kw >> 1);
+    const float* arow = bt + ((r * 2 + par) * G::CW + cw) * 32;
+    const int sw = swz_big<HS>(r, cw);
+    const float* brow = wl + (tap * 8) * 128 + i16 * 4;
+    A0[slot] = *reinterpret_cast<const f32x4*>(arow + ((kq ^ sw) << 2));
+    A1[slot] = *reinterpret_cast<const f32x4*>(arow + (((4 + kq) ^ sw) << 2));
+    B00[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128);
+    B01[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128 + 64);
+    B10[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128);
+    B11[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128 + 64);
+  };
+  rd(0, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < 16) rd(t + 1, cur ^ 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B00[cur][j], acc[0][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B01[cur][j], acc[1][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B10[cur][j], acc[0][j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B11[cur][j], acc[1][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // 6 DS reads (next tap)
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMAs (this tap)
+  }
+}
+
+// Waves 0-3 (one per SIMD) do nothing but MFMAs; waves 4-7 are loaders that keep TWO tiles in flight
+// from HBM (units u+2 and u+3 in two register sets) and write tile u+1 into the idle LDS buffer while
+// the compute waves run: the whole chip issues its tile loads in the same few hundred cycles after a
+// barrier, so a single tile of look-ahead (~1 unit time) does not cover the queueing delay.
 template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ mask,
@@ -402,75 +449,37 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
   const int stride = gridDim.x;
 
   SlotDesc<LNPF> sd;
-  f32x4 pf[LNPF];
+  f32x4 pfa[LNPF], pfb[LNPF];      // loader register sets: tiles of the units (u+1, u+3, ..) and (u+2, u+4, ..)
   const int ltid = tid - 256;
   if (!is_compute) init_big_slots<HS, 256, LNPF>(sd, ltid);
   int unit = blockIdx.x;
-  if (!is_compute && unit < n_units) load_big<HS, LNPF>(pf, sd, big, unit, N);
+  if (!is_compute && unit < n_units) load_big<HS, LNPF>(pfa, sd, big, unit, N);
   stage_weights<true>(w, wl, tid);
-  if (!is_compute && unit < n_units) store_big<HS, LNPF>(pf, sd, bt0);
+  if (!is_compute && unit < n_units) store_big<HS, LNPF>(pfa, sd, bt0);
   __syncthreads();
-  if (!is_compute && unit + stride < n_units) load_big<HS, LNPF>(pf, sd, big, unit + stride, N);
-  const float bv0 = bias ? bias[i16] : 0.f, bv1 = bias ? bias[16 + i16] : 0.f;
-  int buf = 0;
-  if (is_compute) __builtin_amdgcn_s_setprio(1);
-
-  for (; unit < n_units; unit += stride) {
-    const float* bt = buf ? bt1 : bt0;
-    const long obase = ((long)unit * G::U + (wv & 3) * 16 + 4 * kq) * 32 + i16;
-    f32x4v acc[2][4];
-    float mv[2][4];
-    if (is_compute) {
+  if (!is_compute) {
+    if (unit + stride < n_units) load_big<HS, LNPF>(pfa, sd, big, unit + stride, N);
+    if (unit + 2 * stride < n_units) load_big<HS, LNPF>(pfb, sd, big, unit + 2 * stride, N);
+  }
+  // The two roles run DISJOINT loops (their registers are never live together); both execute exactly
+  // one s_barrier per unit, so the workgroup barrier pairs them up unit by unit.
+  if (is_compute) {
+    const float bv0 = bias ? bias[i16] : 0.f, bv1 = bias ? bias[16 + i16] : 0.f;
+    __builtin_amdgcn_s_setprio(1);
+    int buf = 0;
+    for (; unit < n_units; unit += stride) {
+      const float* bt = buf ? bt1 : bt0;
+      const long obase = ((long)unit * G::U + (wv & 3) * 16 + 4 * kq) * 32 + i16;
+      f32x4v acc[2][4];
+      float mv[2][4];
       if (MASK) {
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mv[nh][r] = mask[obase + r * 32 + nh * 16];
       }
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[nh][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      f32x4 A0[2], A1[2], B00[2], B01[2], B10[2], B11[2];
-      auto rd = [&](int tap, int slot) {
-        const int kh = tap >> 2, kw = tap & 3;
-        const int r = 2 * sy_l + kh;
-        const int par = kw & 1, cw = sx + (kw >> 1);
-        const float* arow = bt + ((r * 2 + par) * G::CW + cw) * 32;
-        const int sw = swz_big<HS>(r, cw);
-        const float* brow = wl + (tap * 8) * 128 + i16 * 4;
-        A0[slot] = *reinterpret_cast<const f32x4*>(arow + ((kq ^ sw) << 2));
-        A1[slot] = *reinterpret_cast<const f32x4*>(arow + (((4 + kq) ^ sw) << 2));
-        B00[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128);
-        B01[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128 + 64);
-        B10[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128);
-        B11[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128 + 64);
-      };
-      if (!(abl & 8)) {
-      rd(0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < 16) rd(t + 1, cur ^ 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B00[cur][j], acc[0][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B01[cur][j], acc[1][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B10[cur][j], acc[0][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B11[cur][j], acc[1][j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // 6 DS reads (next tap)
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMAs (this tap)
-      }
-      }
-    } else {
-      // loader: tile u+1 (in registers since the previous unit) -> the idle buffer
-      if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pf, sd, buf ? bt0 : bt1);
-    }
-    __syncthreads();
-    if (is_compute) {
+      if (!(abl & 8)) down_ws_mfma<HS>(acc, bt, wl, sy_l, sx, i16, kq);
+      __syncthreads();
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
         const f32x4v a = (acc[nh][0] + acc[nh][1]) + (acc[nh][2] + acc[nh][3]);
@@ -481,10 +490,21 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
           if (!(abl & 4)) out[obase + r * 32 + nh * 16] = v;
         }
       }
-    } else {
-      if (unit + 2 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pf, sd, big, unit + 2 * stride, N);
+      buf ^= 1;
     }
-    buf ^= 1;
+  } else {
+    // loader: registers pfa hold tile u+1, pfb tile u+2 (in flight); alternate
+    while (unit < n_units) {
+      if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pfa, sd, bt1);
+      __syncthreads();
+      if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfa, sd, big, unit + 3 * stride, N);
+      unit += stride;
+      if (unit >= n_units) break;
+      if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pfb, sd, bt0);
+      __syncthreads();
+      if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfb, sd, big, unit + 3 * stride, N);
+      unit += stride;
+    }
   }
 }
 
