@@ -228,10 +228,15 @@ __global__ __launch_bounds__(256) void k_gemm32(const float* __restrict__ a, lon
 }
 
 // small problems (everything in the VAE) go to k_gemm32; large ones (discriminator) to k_gemm
-static inline bool use_small(int M, int N, int Kc) {
-  static const bool off = getenv("DVAE_GEMM_BIG") != nullptr;
+// measured (profiles/r01_run12): k_gemm32 wins only for the forward form with 16-byte loads on both
+// operands (11.2 vs 13.3 us at 1024x512x256); the lane-contiguous dgrad / wgrad forms are slower than the
+// LDS-staged split-K kernel (16.4 vs 14.0, 22.9 vs 14.6 us) -> forward only unless DVAE_GEMM_SMALL=all
+static inline bool use_small(int M, int N, int Kc, bool fwd_vec) {
+  static const char* mode = getenv("DVAE_GEMM_SMALL");
   const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-  return !off && tiles64 < 192 && Kc <= 4096;
+  if (mode && mode[0] == 'n') return false;
+  if (!(tiles64 < 192 && Kc <= 4096)) return false;
+  return fwd_vec || (mode && mode[0] == 'a');
 }
 static inline dim3 grid32(int M, int N) { return dim3((N + 31) / 32, (M + 31) / 32); }
 
@@ -285,7 +290,7 @@ static int pick_split(int tiles, int Kc, size_t out_elems, float* ws, size_t ws_
 
 int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, float* ws,
                       size_t ws_floats, hipStream_t s) {
-  if (use_small(M, N, K)) {
+  if (use_small(M, N, K, K % 4 == 0)) {
     // A = x (k contiguous), B(k,j) = w[j*K + k] (k contiguous)
     if (K % 4 == 0)
       hipLaunchKernelGGL((k_gemm32<true, true>), grid32(M, N), dim3(256), 0, s, x, (long)K, 1L, w, 1L, (long)K, y,
@@ -318,7 +323,7 @@ int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, 
 int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
                         float* ws, size_t ws_floats, hipStream_t s) {
   // dx[M,K] = dy[M,N] w[N,K]: contraction length N
-  if (use_small(M, K, N)) {
+  if (use_small(M, K, N, false)) {
     // A = dy (contraction index n contiguous), B(k=n, j) = w[n*K + j] (j contiguous -> lanes)
     if (N % 4 == 0)
       hipLaunchKernelGGL((k_gemm32<true, false>), grid32(M, K), dim3(256), 0, s, dy, (long)N, 1L, w, (long)K, 1L, dx,
@@ -353,7 +358,7 @@ int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, i
                         size_t ws_floats, hipStream_t s) {
   // dw[N,K] = dy^T[N,M] x[M,K]: contraction length M (the batch); db[n] = sum_m dy[m][n] = row sums of A.
   // Few output tiles + a long contraction: split the batch over gridDim.z and reduce (fixed order).
-  if (use_small(N, K, M)) {
+  if (use_small(N, K, M, false)) {
     // A(i=n, k=m) = dy[m*N + n], B(k=m, j) = x[m*K + j]: both lane-contiguous, contraction over the batch
     hipLaunchKernelGGL((k_gemm32<false, false>), grid32(N, K), dim3(256), 0, s, dy, 1L, (long)N, x, (long)K, 1L, dw,
                        (long)K, N, K, M, (const float*)nullptr, 0, (const float*)nullptr, 0, db);
