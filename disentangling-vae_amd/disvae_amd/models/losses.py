@@ -457,6 +457,9 @@ class FactorKLoss(BaseLoss):
         self.gamma = gamma
         self.device = device
         self.discriminator = Discriminator(**disc_kwargs).to(self.device)
+        optim_kwargs = dict(optim_kwargs)
+        if torch.device(self.device).type == "cuda":
+            optim_kwargs.setdefault("fused", True)   # same Adam arithmetic, one multi-tensor kernel
         self.optimizer_d = torch.optim.Adam(self.discriminator.parameters(), **optim_kwargs)
 
     def __call__(self, *args, **kwargs):
