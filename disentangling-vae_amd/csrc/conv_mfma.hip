@@ -497,12 +497,12 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
     while (unit < n_units) {
       if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pfa, sd, bt1);
       __syncthreads();
-      if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfa, sd, big, (abl & 16) ? (int)blockIdx.x : unit + 3 * stride, N);
+      if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfa, sd, big, unit + 3 * stride, N);
       unit += stride;
       if (unit >= n_units) break;
       if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pfb, sd, bt0);
       __syncthreads();
-      if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfb, sd, big, (abl & 16) ? (int)blockIdx.x : unit + 3 * stride, N);
+      if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfb, sd, big, unit + 3 * stride, N);
       unit += stride;
     }
   }

@@ -15,17 +15,15 @@ namespace dvae {
 #define GK 32
 #define GLD (GT + 1)
 
-template <bool A_KFAST, bool B_JFAST, int GKT>
+template <bool A_KFAST, bool B_JFAST>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a, long sAi, long sAk,
                                               const float* __restrict__ b, long sBk, long sBj,
                                               float* __restrict__ c, long ldc, int M, int N, int K,
                                               const float* __restrict__ bias, int act,
                                               const float* __restrict__ mask, int mask_act,
                                               float* __restrict__ rowsum, int klen) {
-  __shared__ float As[GKT][GLD];
-  __shared__ float Bs[GKT][GLD];
-  constexpr int NL = GT * GKT / 256;   // staged elements per thread and operand
-  constexpr int LK = (GKT == 32) ? 5 : 7;
+  __shared__ float As[GK][GLD];
+  __shared__ float Bs[GK][GLD];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wi = wv >> 1, wj = wv & 1;
   const int i = lane & 31, h = lane >> 5;
@@ -38,15 +36,15 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a, long 
     if (rowsum) rowsum += (long)blockIdx.z * M;
   }
 
-  // per-thread staging registers: a whole GT x GKT slice of each operand is in flight at once
-  float pa[NL], pb[NL];
+  // per-thread staging coordinates: 2048 elements per operand tile / 256 threads = 8 each
+  float pa[8], pb[8];
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
+    for (int r = 0; r < 8; ++r) {
       const int e = tid + r * 256;
       int ai, ak, bk, bj;
-      if (A_KFAST) { ak = e & (GKT - 1); ai = e >> LK; } else { ai = e & (GT - 1); ak = e >> 6; }
-      if (B_JFAST) { bj = e & (GT - 1); bk = e >> 6; } else { bk = e & (GKT - 1); bj = e >> LK; }
+      if (A_KFAST) { ak = e & (GK - 1); ai = e >> 5; } else { ai = e & (GT - 1); ak = e >> 6; }
+      if (B_JFAST) { bj = e & (GT - 1); bk = e >> 6; } else { bk = e & (GK - 1); bj = e >> 5; }
       const int gi = m0 + ai, gka = k0 + ak, gkb = k0 + bk, gj = n0 + bj;
       pa[r] = (gi < M && gka < kend) ? a[gi * sAi + gka * sAk] : 0.f;
       pb[r] = (gkb < kend && gj < N) ? b[gkb * sBk + gj * sBj] : 0.f;
@@ -54,11 +52,11 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a, long 
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
+    for (int r = 0; r < 8; ++r) {
       const int e = tid + r * 256;
       int ai, ak, bk, bj;
-      if (A_KFAST) { ak = e & (GKT - 1); ai = e >> LK; } else { ai = e & (GT - 1); ak = e >> 6; }
-      if (B_JFAST) { bj = e & (GT - 1); bk = e >> 6; } else { bk = e & (GKT - 1); bj = e >> LK; }
+      if (A_KFAST) { ak = e & (GK - 1); ai = e >> 5; } else { ai = e & (GT - 1); ak = e >> 6; }
+      if (B_JFAST) { bj = e & (GT - 1); bk = e >> 6; } else { bk = e & (GK - 1); bj = e >> 5; }
       As[ak][ai] = pa[r];
       Bs[bk][bj] = pb[r];
     }
@@ -71,20 +69,20 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ a, long 
   const bool do_rowsum = rowsum != nullptr && blockIdx.x == 0;
 
   load_tiles(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += GKT) {
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
     __syncthreads();
     store_tiles();
     __syncthreads();
-    if (k0 + GKT < kend) load_tiles(k0 + GKT);
+    if (k0 + GK < kend) load_tiles(k0 + GK);
 #pragma unroll
-    for (int s = 0; s < GKT / 2; ++s) {
+    for (int s = 0; s < GK / 2; ++s) {
       const float av = As[2 * s + h][wi * 32 + i];
       const float bv = Bs[2 * s + h][wj * 32 + i];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
     if (do_rowsum && tid < GT) {
 #pragma unroll
-      for (int k = 0; k < GKT; ++k) rs += As[k][tid];
+      for (int k = 0; k < GK; ++k) rs += As[k][tid];
     }
   }
   if (do_rowsum && tid < GT && m0 + tid < M) rowsum[m0 + tid] = rs;
@@ -285,8 +283,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const float* __restrict
 static int pick_split(int tiles, int Kc, size_t out_elems, float* ws, size_t ws_floats) {
   int S = 1;
   if (!ws) return 1;
-  // whole 128-deep slices per workgroup (loaded in one go): as many slices as the chip can use
-  while (S < 32 && tiles * S < 512 && Kc / (S * 2) >= 128) S *= 2;
+  while (S < 16 && tiles * S < 256 && Kc / (S * 2) >= 64) S *= 2;
   while (S > 1 && (size_t)S * (out_elems + 4096) > ws_floats) S /= 2;
   return S;
 }
@@ -307,13 +304,13 @@ int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, 
   const int tiles = ((M + GT - 1) / GT) * ((N + GT - 1) / GT);
   const int S = pick_split(tiles, K, (size_t)M * N, ws, ws_floats);
   if (S == 1) {
-    hipLaunchKernelGGL((k_gemm<true, false, 32>), gemm_grid(M, N), dim3(256), 0, s, x, (long)K, 1L, w, 1L, (long)K, y,
+    hipLaunchKernelGGL((k_gemm<true, false>), gemm_grid(M, N), dim3(256), 0, s, x, (long)K, 1L, w, 1L, (long)K, y,
                        (long)N, M, N, K, b, act, (const float*)nullptr, 0, (float*)nullptr, K);
     DVAE_CHECK_LAUNCH();
     return 0;
   }
-  const int klen = ((K + S - 1) / S + 127) / 128 * 128;
-  hipLaunchKernelGGL((k_gemm<true, false, 128>), gemm_grid(M, N, S), dim3(256), 0, s, x, (long)K, 1L, w, 1L, (long)K, ws,
+  const int klen = ((K + S - 1) / S + GK - 1) / GK * GK;
+  hipLaunchKernelGGL((k_gemm<true, false>), gemm_grid(M, N, S), dim3(256), 0, s, x, (long)K, 1L, w, 1L, (long)K, ws,
                      (long)N, M, N, K, (const float*)nullptr, 0, (const float*)nullptr, 0, (float*)nullptr, klen);
   DVAE_CHECK_LAUNCH();
   long n = (long)M * N;
@@ -340,13 +337,13 @@ int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int
   const int tiles = ((M + GT - 1) / GT) * ((K + GT - 1) / GT);
   const int S = pick_split(tiles, N, (size_t)M * K, ws, ws_floats);
   if (S == 1) {
-    hipLaunchKernelGGL((k_gemm<true, true, 32>), gemm_grid(M, K), dim3(256), 0, s, dy, (long)N, 1L, w, (long)K, 1L, dx,
+    hipLaunchKernelGGL((k_gemm<true, true>), gemm_grid(M, K), dim3(256), 0, s, dy, (long)N, 1L, w, (long)K, 1L, dx,
                        (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, (float*)nullptr, N);
     DVAE_CHECK_LAUNCH();
     return 0;
   }
-  const int klen = ((N + S - 1) / S + 127) / 128 * 128;
-  hipLaunchKernelGGL((k_gemm<true, true, 128>), gemm_grid(M, K, S), dim3(256), 0, s, dy, (long)N, 1L, w, (long)K, 1L, ws,
+  const int klen = ((N + S - 1) / S + GK - 1) / GK * GK;
+  hipLaunchKernelGGL((k_gemm<true, true>), gemm_grid(M, K, S), dim3(256), 0, s, dy, (long)N, 1L, w, (long)K, 1L, ws,
                      (long)K, M, K, N, (const float*)nullptr, 0, (const float*)nullptr, 0, (float*)nullptr, klen);
   DVAE_CHECK_LAUNCH();
   long n = (long)M * K;
@@ -371,18 +368,18 @@ int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, i
   const int tiles = ((N + GT - 1) / GT) * ((K + GT - 1) / GT);
   int S = 1;
   if (ws) {
-    while (S < 32 && tiles * S < 512 && M / (S * 2) >= 128) S *= 2;
+    while (S < 16 && tiles * S < 256 && M / (S * 2) >= 64) S *= 2;
     while (S > 1 && (size_t)S * ((size_t)N * K + N) > ws_floats) S /= 2;
   }
   if (S == 1) {
-    hipLaunchKernelGGL((k_gemm<false, true, 32>), gemm_grid(N, K), dim3(256), 0, s, dy, 1L, (long)N, x, (long)K, 1L, dw,
+    hipLaunchKernelGGL((k_gemm<false, true>), gemm_grid(N, K), dim3(256), 0, s, dy, 1L, (long)N, x, (long)K, 1L, dw,
                        (long)K, N, K, M, (const float*)nullptr, 0, (const float*)nullptr, 0, db, M);
     DVAE_CHECK_LAUNCH();
     return 0;
   }
-  const int klen = ((M + S - 1) / S + 127) / 128 * 128;
+  const int klen = ((M + S - 1) / S + GK - 1) / GK * GK;
   float* wsb = ws + (size_t)S * N * K;
-  hipLaunchKernelGGL((k_gemm<false, true, 128>), gemm_grid(N, K, S), dim3(256), 0, s, dy, 1L, (long)N, x, (long)K, 1L, ws,
+  hipLaunchKernelGGL((k_gemm<false, true>), gemm_grid(N, K, S), dim3(256), 0, s, dy, 1L, (long)N, x, (long)K, 1L, ws,
                      (long)K, N, K, M, (const float*)nullptr, 0, (const float*)nullptr, 0, db ? wsb : (float*)nullptr, klen);
   DVAE_CHECK_LAUNCH();
   const long n = (long)N * K;
