@@ -109,6 +109,24 @@ int dvae_convT4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_la
                    (hipStream_t)stream);
 }
 
+int dvae_convT4s2_sigmoid_recon_fwd(const float* x, int x_layout, const float* w, const float* b, const float* target,
+                                    float* recon, float* g, int dist, const float* coef, float* partials, int N,
+                                    int Cin, int H, int W, int Cout, void* stream) {
+  DVAE_CHECK_ARG(x && w && target && recon && g && coef && partials && N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
+  DVAE_CHECK_ARG(check_layout(x_layout));
+  DVAE_CHECK_ARG(dist == DVAE_REC_BERNOULLI || dist == DVAE_REC_GAUSSIAN || dist == DVAE_REC_LAPLACE);
+  ConvArgs a{nullptr, 0, x, x_layout, w, b, nullptr, recon, DVAE_NCHW, N, Cout, Cin, H, W, DVAE_ACT_SIGMOID};
+  if (!use_generic_only()) {
+    int r = launch_up_thin_recon(a, target, g, dist, coef, partials, (hipStream_t)stream);
+    if (r <= 0) return r;
+  }
+  int r = run_up(a, (hipStream_t)stream);       // shapes outside the fused kernel: two passes
+  if (r) return r;
+  const long n = (long)N * Cout * 4 * H * W;
+  DVAE_CHECK_ARG(n % 4 == 0);
+  return launch_recon_loss(recon, target, n, dist, coef, partials, g, 1, (hipStream_t)stream);
+}
+
 size_t dvae_conv_wgrad_ws_floats(void) {
   size_t a = wgrad32_ws_floats(), b = wgrad_thin_ws_floats();
   return a > b ? a : b;

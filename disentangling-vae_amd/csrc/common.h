@@ -56,6 +56,35 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// per-element reconstruction likelihood (losses.py:394-449) and its gradient: p = sigmoid output,
+// x = target.  Returns the un-normalised loss term; *gl = dL/dlogit, *gr = dL/dp (un-scaled).
+__device__ __forceinline__ float recon_elem(float p, float x, int dist, float* gl, float* gr) {
+  const float q1 = 1.f - p;
+  const float qq = q1 * p;                       // sigmoid backward factor (1-y)*y
+  float term;
+  if (dist == DVAE_REC_BERNOULLI) {
+    // ATen binary_cross_entropy: (x-1)*max(log1p(-p),-100) - x*max(log(p),-100); backward
+    // (p-x)/max((1-p)*p, 1e-12).  log1p(-p) is evaluated as log(1-p): 1-p is exact for p >= 0.5 and
+    // off by <= 6e-8 (absolute) below; __logf = v_log_f32 * ln2 (~1 ulp), not for denormal inputs.
+    const float lp = p < 1e-30f ? logf(p) : __logf(p);
+    term = (x - 1.f) * fmaxf(__logf(q1), -100.f) - x * fmaxf(lp, -100.f);
+    const float d = p - x;
+    *gl = qq >= 1e-12f ? d : d * 1e12f * qq;     // ((p-x)/max(qq,1e-12)) * qq
+    *gr = d / fmaxf(qq, 1e-12f);
+  } else if (dist == DVAE_REC_GAUSSIAN) {
+    const float d = p * 255.f - x * 255.f;       // mse(255p, 255x, sum) / 255
+    term = d * d / 255.f;
+    *gr = 2.f * d;
+    *gl = *gr * qq;
+  } else {
+    const float d = p - x;                        // 3 * l1(sum)
+    term = 3.f * fabsf(d);
+    *gr = d > 0.f ? 3.f : (d < 0.f ? -3.f : 0.f);
+    *gl = *gr * qq;
+  }
+  return term;
+}
+
 // ---- launchers implemented in the individual .hip files ---------------------------------
 // "down": big[N,Cb,2Hs,2Ws] -> small[N,Cs,Hs,Ws]  (Conv2d fwd, ConvTranspose2d dgrad)
 // "up"  : small -> big                           (ConvTranspose2d fwd, Conv2d dgrad)
@@ -82,6 +111,9 @@ int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* 
 // thin paths (Cb in {1,3}, Cs == 32, big NCHW 64x64 / small NHWC 32x32)
 int launch_down_thin(const ConvArgs& a, hipStream_t s);
 int launch_up_thin(const ConvArgs& a, hipStream_t s);
+// fused convT3 + sigmoid + reconstruction loss (+ dL/dlogit); returns 1 if the shape is not covered
+int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int dist, const float* coef,
+                         float* partials, hipStream_t s);
 int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big,
                       int N, int Cb, int Hs, float* ws, hipStream_t s);
 

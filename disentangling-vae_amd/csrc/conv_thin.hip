@@ -131,98 +131,122 @@ __global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big
 }
 
 // ---- up_thin: small NHWC [N,32,32,32] -> big NCHW [N,C,64,64], bias + act ------------------
-// block = 128 threads = 4 small rows x 32 columns; LDS tile = 6 rows x 34 cols x 32 ch (swizzled)
+// block = 128 threads = 4 small rows x 32 columns; LDS tile = 6 rows x 34 cols x 32 ch (swizzled);
+// persistent over units.  FUSE: the sigmoid output is compared with the target on the spot -- the
+// reconstruction likelihood, its per-workgroup partial sum and dL/dlogit come out of the same pass.
 #define UT_ROWS 6
 #define UT_COLS 34
-template <int C>
+template <int C, bool FUSE>
 __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small, const float* __restrict__ w,
                                                  const float* __restrict__ bias, float* __restrict__ out, int N,
-                                                 int act) {
+                                                 int act, int n_units, const float* __restrict__ target,
+                                                 float* __restrict__ g, int dist, const float* __restrict__ coef,
+                                                 float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) float st[UT_ROWS * UT_COLS * 32];
+  __shared__ float redl[2];
   const int tid = threadIdx.x;
-  const int unit = blockIdx.x;
-  const int n = unit >> 3, sy0 = (unit & 7) * 4;
-  {
-    // 16 columns per pass, 8 chunks of 16 bytes per pixel; all loads first (unconditional, clamped
-    // address), then the swizzled LDS stores
-    const int chunk = tid & 7, cg = tid >> 3;
-    f32x4 tv[UT_ROWS * 3];
-#pragma unroll
-    for (int row = 0; row < UT_ROWS; ++row) {
-      const int sy = sy0 - 1 + row;
-#pragma unroll
-      for (int cp = 0; cp < 3; ++cp) {
-        const int col = cp * 16 + cg;
-        const int sx = col - 1;
-        const bool ok = n < N && col < UT_COLS && sy >= 0 && sy < 32 && sx >= 0 && sx < 32;
-        const long off = ok ? (((((long)n * 32 + sy) * 32) + sx) * 32 + chunk * 4) : 0;
-        f32x4 v = *reinterpret_cast<const f32x4*>(small + off);
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        tv[row * 3 + cp] = v;
-      }
-    }
-#pragma unroll
-    for (int row = 0; row < UT_ROWS; ++row)
-#pragma unroll
-      for (int cp = 0; cp < 3; ++cp) {
-        const int col = cp * 16 + cg;
-        if (col < UT_COLS)
-          *reinterpret_cast<f32x4*>(st + (row * UT_COLS + col) * 32 + ((chunk ^ ((col >> 1) & 7)) << 2)) = tv[row * 3 + cp];
-      }
-  }
-  __syncthreads();
   const int m = tid >> 5, l = tid & 31;
-  float acc[4][C];
+  const float gs = FUSE ? coef[DVAE_C_INV_B] : 0.f;
+  float lsum = 0.f;
+  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const int n = unit >> 3, sy0 = (unit & 7) * 4;
+    __syncthreads();
+    {
+      // 16 columns per pass, 8 chunks of 16 bytes per pixel; all loads first (unconditional, clamped
+      // address), then the swizzled LDS stores
+      const int chunk = tid & 7, cg = tid >> 3;
+      f32x4 tv[UT_ROWS * 3];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+      for (int row = 0; row < UT_ROWS; ++row) {
+        const int sy = sy0 - 1 + row;
 #pragma unroll
-    for (int cb = 0; cb < C; ++cb) acc[c][cb] = 0.f;
+        for (int cp = 0; cp < 3; ++cp) {
+          const int col = cp * 16 + cg;
+          const int sx = col - 1;
+          const bool ok = n < N && col < UT_COLS && sy >= 0 && sy < 32 && sx >= 0 && sx < 32;
+          const long off = ok ? (((((long)n * 32 + sy) * 32) + sx) * 32 + chunk * 4) : 0;
+          f32x4 v = *reinterpret_cast<const f32x4*>(small + off);
+          if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          tv[row * 3 + cp] = v;
+        }
+      }
+#pragma unroll
+      for (int row = 0; row < UT_ROWS; ++row)
+#pragma unroll
+        for (int cp = 0; cp < 3; ++cp) {
+          const int col = cp * 16 + cg;
+          if (col < UT_COLS)
+            *reinterpret_cast<f32x4*>(st + (row * UT_COLS + col) * 32 + ((chunk ^ ((col >> 1) & 7)) << 2)) = tv[row * 3 + cp];
+        }
+    }
+    __syncthreads();
+    float acc[4][C];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int cb = 0; cb < C; ++cb) acc[c][cb] = 0.f;
 
 #pragma unroll 1
-  for (int q = 0; q < 8; ++q) {   // 4 contracted channels per iteration
-    f32x4 x[3][3];
+    for (int q = 0; q < 8; ++q) {   // 4 contracted channels per iteration
+      f32x4 x[3][3];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int row = m + dy, col = l + dx;  // (m + (dy-1)) + 1
-        x[dy][dx] = *reinterpret_cast<const f32x4*>(st + (row * UT_COLS + col) * 32 + ((q ^ ((col >> 1) & 7)) << 2));
+        for (int dx = 0; dx < 3; ++dx) {
+          const int row = m + dy, col = l + dx;  // (m + (dy-1)) + 1
+          x[dy][dx] = *reinterpret_cast<const f32x4*>(st + (row * UT_COLS + col) * 32 + ((q ^ ((col >> 1) & 7)) << 2));
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cs = q * 4 + j;
+#pragma unroll
+        for (int cb = 0; cb < C; ++cb) {
+          const float* wp = w + (cs * C + cb) * 16;   // wave-uniform -> scalar loads
+#pragma unroll
+          for (int kh = 0; kh < 4; ++kh) {
+            // big row by = 2*sy - 1 + kh: py = (kh+1)&1, small row offset dsy = (py + 1 - kh) / 2  in {-1,0,1}
+            const int py = (kh + 1) & 1;
+            const int dsy = (py + 1 - kh) / 2;   // kh=0:+1 (py=1) kh=1:0 (py=0) kh=2:0 (py=1) kh=3:-1 (py=0)
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+              const int px = (kw + 1) & 1;
+              const int dsx = (px + 1 - kw) / 2;
+              acc[py * 2 + px][cb] = fmaf(x[dsy + 1][dsx + 1][j], wp[kh * 4 + kw], acc[py * 2 + px][cb]);
+            }
+          }
+        }
       }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int cs = q * 4 + j;
+    }
+    if (n < N) {
+      const int sy = sy0 + m;
 #pragma unroll
       for (int cb = 0; cb < C; ++cb) {
-        const float* wp = w + (cs * C + cb) * 16;   // wave-uniform -> scalar loads
+        const float bv = bias ? bias[cb] : 0.f;
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-          // big row by = 2*sy - 1 + kh: py = (kh+1)&1, small row offset dsy = (py + 1 - kh) / 2  in {-1,0,1}
-          const int py = (kh + 1) & 1;
-          const int dsy = (py + 1 - kh) / 2;   // kh=0:+1 (py=1) kh=1:0 (py=0) kh=2:0 (py=1) kh=3:-1 (py=0)
-#pragma unroll
-          for (int kw = 0; kw < 4; ++kw) {
-            const int px = (kw + 1) & 1;
-            const int dsx = (px + 1 - kw) / 2;
-            acc[py * 2 + px][cb] = fmaf(x[dsy + 1][dsx + 1][j], wp[kh * 4 + kw], acc[py * 2 + px][cb]);
+        for (int py = 0; py < 2; ++py) {
+          float v0 = acc[py * 2 + 0][cb] + bv, v1 = acc[py * 2 + 1][cb] + bv;
+          if (act == DVAE_ACT_SIGMOID) { v0 = 1.f / (1.f + expf(-v0)); v1 = 1.f / (1.f + expf(-v1)); }
+          else if (act == DVAE_ACT_RELU) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+          const long o = ((((long)n * C + cb) * 64) + 2 * sy + py) * 64 + 2 * l;
+          *reinterpret_cast<float2*>(out + o) = make_float2(v0, v1);
+          if (FUSE) {
+            const float2 xt = *reinterpret_cast<const float2*>(target + o);
+            float gl0, gl1, gr;
+            lsum += recon_elem(v0, xt.x, dist, &gl0, &gr);
+            lsum += recon_elem(v1, xt.y, dist, &gl1, &gr);
+            *reinterpret_cast<float2*>(g + o) = make_float2(gs * gl0, gs * gl1);
           }
         }
       }
     }
   }
-  if (n < N) {
-    const int sy = sy0 + m;
-#pragma unroll
-    for (int cb = 0; cb < C; ++cb) {
-      const float bv = bias ? bias[cb] : 0.f;
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        float v0 = acc[py * 2 + 0][cb] + bv, v1 = acc[py * 2 + 1][cb] + bv;
-        if (act == DVAE_ACT_SIGMOID) { v0 = 1.f / (1.f + expf(-v0)); v1 = 1.f / (1.f + expf(-v1)); }
-        else if (act == DVAE_ACT_RELU) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-        float2 v = make_float2(v0, v1);
-        *reinterpret_cast<float2*>(out + ((((long)n * C + cb) * 64) + 2 * sy + py) * 64 + 2 * l) = v;
-      }
-    }
+  if (FUSE) {
+    const float v = wave_sum(lsum);
+    if ((tid & 63) == 0) redl[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = redl[0] + redl[1];
+    // unused partial slots must read as zero
+    for (int k = gridDim.x + blockIdx.x * 128 + tid; k < DVAE_REC_NPART; k += gridDim.x * 128) partials[k] = 0.f;
   }
 }
 
@@ -424,9 +448,21 @@ int launch_down_thin(const ConvArgs& a, hipStream_t s) {
 
 int launch_up_thin(const ConvArgs& a, hipStream_t s) {
   if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
-  const int grid = a.N * 8;
-  if (a.Cb == 1) hipLaunchKernelGGL(k_up_thin<1>, dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act);
-  else hipLaunchKernelGGL(k_up_thin<3>, dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act);
+  const int n_units = a.N * 8;
+  const int grid = n_units < DVAE_REC_NPART ? n_units : DVAE_REC_NPART;
+  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+  else hipLaunchKernelGGL((k_up_thin<3, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int dist, const float* coef,
+                         float* partials, hipStream_t s) {
+  if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
+  const int n_units = a.N * 8;
+  const int grid = n_units < DVAE_REC_NPART ? n_units : DVAE_REC_NPART;
+  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  else hipLaunchKernelGGL((k_up_thin<3, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -92,31 +92,8 @@ __global__ __launch_bounds__(256) void k_recon_loss(const float* __restrict__ re
     f32x4 gv;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float p = pv[j], x = xv[j];
-      const float q1 = 1.f - p;
-      const float qq = q1 * p;                       // sigmoid backward factor (1-y)*y
-      float term, gl, gr;                            // loss term, dL/dlogit, dL/drecon
-      if (dist == DVAE_REC_BERNOULLI) {
-        // ATen binary_cross_entropy: (x-1)*max(log1p(-p),-100) - x*max(log(p),-100); backward
-        // (p-x)/max((1-p)*p, 1e-12).  log1p(-p) is evaluated as log(1-p): 1-p is exact for
-        // p >= 0.5 and off by <= 6e-8 (absolute) below; __logf = v_log_f32 * ln2 (~1 ulp).
-        const float lp = p < 1e-30f ? logf(p) : __logf(p);     // v_log_f32 does not take denormal inputs
-        term = (x - 1.f) * fmaxf(__logf(q1), -100.f) - x * fmaxf(lp, -100.f);
-        const float d = p - x;
-        gl = qq >= 1e-12f ? d : d * 1e12f * qq;      // ((p-x)/max(qq,1e-12)) * qq
-        gr = wrt_logit ? 0.f : d / fmaxf(qq, 1e-12f);
-      } else if (dist == DVAE_REC_GAUSSIAN) {
-        const float d = p * 255.f - x * 255.f;       // mse(255p, 255x, sum) / 255
-        term = d * d / 255.f;
-        gr = 2.f * d;
-        gl = gr * qq;
-      } else {
-        const float d = p - x;                        // 3 * l1(sum)
-        term = 3.f * fabsf(d);
-        gr = d > 0.f ? 3.f : (d < 0.f ? -3.f : 0.f);
-        gl = gr * qq;
-      }
-      acc += term;
+      float gl, gr;
+      acc += recon_elem(pv[j], xv[j], dist, &gl, &gr);
       gv[j] = gs * (wrt_logit ? gl : gr);
     }
     if (g) g4[q] = gv;

@@ -16,7 +16,7 @@ LOSS_BETAH, LOSS_BETAB, LOSS_BTCVAE, LOSS_FACTOR = 0, 1, 2, 3
 # scalar slots (dvae_hip.h)
 S_LOSS, S_REC, S_KL, S_KL0, S_MI, S_TC, S_DWKL, S_KLW, S_DTC, NSCAL = 0, 1, 2, 3, 19, 20, 21, 22, 23, 32
 C_INV_B, C_ANNEAL, C_BETA, C_ALPHA, C_GAMMA, C_CAP, NCOEF = 0, 1, 2, 3, 4, 5, 8
-REC_NPART = 512
+REC_NPART = 2048
 NPACK = 32
 
 _p = ctypes.c_void_p
@@ -33,6 +33,7 @@ SIGNATURES = {
     "dvae_convT4s2_fwd": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "dvae_convT4s2_dgrad": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "dvae_convT4s2_wgrad": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "dvae_convT4s2_sigmoid_recon_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "dvae_conv_wgrad_ws_floats": [],
     "dvae_relayout": [_p, _i, _p, _i, _i, _i, _i, _p],
     "dvae_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],

@@ -194,8 +194,10 @@ class VAEEngine:
         call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(kl_dim),
              ptr(coef), B, self.latent_dim, _stream())
 
-    def decode(self, z, buf, n=None):
-        """z[B,D] -> buf.recon[B,C,H,W] (NCHW, post-sigmoid)."""
+    def decode(self, z, buf, n=None, fuse_loss=None):
+        """z[B,D] -> buf.recon[B,C,H,W] (NCHW, post-sigmoid).  fuse_loss = (target, dist_code, coef,
+        partials): the last layer also evaluates the reconstruction likelihood against `target`
+        (partial sums -> partials) and writes dLoss/dlogit into buf.g_logit in the same pass."""
         s = _stream()
         ws = ptr(self._ws)
         B = z.shape[0] if n is None else n
@@ -213,8 +215,14 @@ class VAEEngine:
                  ptr(self.p("decoder.%s.bias" % name)), ptr(act), NHWC, B, HID, h, h, HID, ACT_RELU, s)
             src, h = act, h * 2
         c = self.img_size[0]
-        call("dvae_convT4s2_fwd", ptr(src), NHWC, ptr(self.p("decoder.convT3.weight")),
-             ptr(self.p("decoder.convT3.bias")), ptr(buf.recon), NCHW, B, HID, h, h, c, ACT_SIGMOID, s)
+        if fuse_loss is None:
+            call("dvae_convT4s2_fwd", ptr(src), NHWC, ptr(self.p("decoder.convT3.weight")),
+                 ptr(self.p("decoder.convT3.bias")), ptr(buf.recon), NCHW, B, HID, h, h, c, ACT_SIGMOID, s)
+        else:
+            target, dist_code, coef, partials = fuse_loss
+            call("dvae_convT4s2_sigmoid_recon_fwd", ptr(src), NHWC, ptr(self.p("decoder.convT3.weight")),
+                 ptr(self.p("decoder.convT3.bias")), ptr(target), ptr(buf.recon), ptr(buf.g_logit), dist_code,
+                 ptr(coef), ptr(partials), B, HID, h, h, c, s)
 
     # ------------------------------------------------------------------ backward
     def decode_backward(self, z, buf, n=None):

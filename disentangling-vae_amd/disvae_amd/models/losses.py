@@ -298,9 +298,8 @@ class _SingleOptimizerLoss(BaseLoss):
         data = data.contiguous()
         eng.encode(data, buf)
         eng.reparam(buf, eps, sc.kl_dim, sc.coef)
-        eng.decode(buf.z, buf)
-        call("dvae_recon_loss", ptr(buf.recon), ptr(data), buf.recon.numel(), self._rec_code(), ptr(sc.coef),
-             ptr(sc.partials), ptr(buf.g_logit), 1, s)
+        # decoder; its last layer also evaluates the reconstruction likelihood and dL/dlogit
+        eng.decode(buf.z, buf, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         rowstats = None
         if self.KIND == _lib.LOSS_BTCVAE:
             zg, mug, lvg = buf.z, buf.mu, buf.logvar
@@ -498,9 +497,7 @@ class FactorKLoss(BaseLoss):
         # reparameterise the two halves (KL only over data1, denominator = half batch; losses.py:255-259)
         call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps1), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(sc.kl_dim),
              ptr(sc.coef), Bh, D, s)
-        eng.decode(buf.z, buf, n=Bh)
-        call("dvae_recon_loss", ptr(buf.recon), ptr(data), Bh * data[0].numel(), self._rec_code(), ptr(sc.coef),
-             ptr(sc.partials), ptr(buf.g_logit), 1, s)
+        eng.decode(buf.z, buf, n=Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         if not is_train:
             # evaluation: vae_loss only (losses.py:276-278); discriminator on z1
             logits = disc.forward_raw(buf.z, Bh)

@@ -115,12 +115,21 @@ int dvae_reparam_kl_bwd(const float* dz, const float* dmu_x, const float* dlv_x,
  * recon, target: [n] elements.  partials[DVAE_REC_NPART] receives per-block partial sums of
  * the un-normalised loss; g[n] (may be NULL) = coef[INV_B] * dLoss/d(pre-sigmoid logit)
  * when wrt_logit != 0 (the logit gradient is what the fused backward consumes).            */
-#define DVAE_REC_NPART 512
+#define DVAE_REC_NPART 2048
 int dvae_recon_loss(const float* recon, const float* target, long n, int dist, const float* coef,
                     float* partials, float* g, int wrt_logit, void* stream);
 /* wrt_logit == 0: g is the gradient w.r.t. `recon` itself (autograd-compatible path).      */
 /* out[n] = grad_y * (1 - y) * y : backward of the final torch.sigmoid (decoders.py:82).     */
 int dvae_sigmoid_bwd(const float* grad_y, const float* y, float* out, long n, void* stream);
+
+/* Final decoder layer fused with the likelihood: recon = sigmoid(convT(x,w)+b) (decoders.py:82),
+ * partials[DVAE_REC_NPART] = per-workgroup sums of the loss vs `target`, g = coef[INV_B] *
+ * dLoss/d(pre-sigmoid logit).  x[N,Cin,H,W]; target, recon, g: [N,Cout,2H,2W] NCHW.  One pass over
+ * the reconstruction instead of three (convT3 store, loss read, gradient write).              */
+int dvae_convT4s2_sigmoid_recon_fwd(const float* x, int x_layout, const float* w, const float* b,
+                                    const float* target, float* recon, float* g, int dist,
+                                    const float* coef, float* partials, int N, int Cin, int H, int W,
+                                    int Cout, void* stream);
 
 /* ---- beta-TCVAE estimator: losses.py:523-544, utils/math.py:8-73 --------------------------
  * z,mu,logvar: [Bg,D] (the whole -- global -- batch); this call evaluates rows

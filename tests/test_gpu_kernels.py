@@ -107,6 +107,33 @@ def test_convT_fwd_dgrad_wgrad(N, H, Cout, yl, act, generic):
         check(from_nhwc(dx, N, Cin, H, H), xr.grad * (x > 0), what="convT dgrad")
 
 
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("N,C,H,dist", [(5, 3, 32, "bernoulli"), (3, 1, 32, "gaussian"), (300, 3, 32, "bernoulli"),
+                                         (4, 1, 16, "laplace")])
+def test_convT_sigmoid_recon_fused(N, C, H, dist, generic):
+    """last decoder layer fused with the likelihood: recon, loss partial sums and dL/dlogit in one pass."""
+    if generic and N > 9:
+        pytest.skip("large case only for the tuned path")
+    x = torch.relu(_rand(N, 32, H, H, seed=1))
+    w = _rand(32, C, 4, 4, seed=2, scale=0.2)
+    b = _rand(C, seed=3, scale=0.1)
+    tgt = torch.rand(N, C, 2 * H, 2 * H, generator=torch.Generator().manual_seed(4))
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / N
+    recon = torch.empty(N, C, 2 * H, 2 * H, device=DEV)
+    g = torch.empty_like(recon)
+    parts = torch.full((_lib.REC_NPART,), 7.0, device=DEV)
+    with force_generic(generic):
+        call("dvae_convT4s2_sigmoid_recon_fwd", ptr(nhwc(x)), _lib.NHWC, ptr(dev(w)), ptr(dev(b)), ptr(dev(tgt)), ptr(recon),
+             ptr(g), _lib.REC[dist], ptr(dev(coef)), ptr(parts), N, 32, H, H, C, stream())
+    lr = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1).requires_grad_(True)
+    ref_recon = torch.sigmoid(lr)
+    loss = O.reconstruction_loss(tgt.double(), ref_recon, dist)
+    loss.backward()
+    check(recon, ref_recon, what="fused recon")
+    check(parts.sum() / N, loss, rtol=2e-5, what="fused loss")
+    check(g, lr.grad, rtol=2e-4, atol_rel=2e-5, what="fused dL/dlogit")
+
+
 def test_relayout():
     x = _rand(5, 32, 4, 4)
     a = nhwc(x)
