@@ -167,8 +167,11 @@ def main():
     if world > 1:
         parallel.init_process_group_from_env("nccl")
         parallel.data_parallel(model, loss_f)
-    torch.manual_seed(1234 + rank)
-    data = torch.rand((B,) + img, device=device)        # synthetic, resident in HBM
+    # synthetic batch, resident in HBM; every rank draws its own shard and its own device noise, while
+    # the CPU generator (FactorVAE permutations, losses.py:505) stays identical on all ranks
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    data = torch.rand((B,) + img, device=device, generator=gen)
+    torch.cuda.manual_seed(1234 + rank)
     storer = defaultdict(list)
 
     def barrier():

@@ -116,7 +116,8 @@ int dvae_convT4s2_sigmoid_recon_fwd(const float* x, int x_layout, const float* w
   DVAE_CHECK_ARG(check_layout(x_layout));
   DVAE_CHECK_ARG(dist == DVAE_REC_BERNOULLI || dist == DVAE_REC_GAUSSIAN || dist == DVAE_REC_LAPLACE);
   ConvArgs a{nullptr, 0, x, x_layout, w, b, nullptr, recon, DVAE_NCHW, N, Cout, Cin, H, W, DVAE_ACT_SIGMOID};
-  if (!use_generic_only()) {
+  static const bool two_pass = getenv("DVAE_RECON_TWO_PASS") != nullptr;   // A/B switch
+  if (!use_generic_only() && !two_pass) {
     int r = launch_up_thin_recon(a, target, g, dist, coef, partials, (hipStream_t)stream);
     if (r <= 0) return r;
   }

@@ -449,7 +449,7 @@ int launch_down_thin(const ConvArgs& a, hipStream_t s) {
 int launch_up_thin(const ConvArgs& a, hipStream_t s) {
   if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
   const int n_units = a.N * 8;
-  const int grid = n_units < DVAE_REC_NPART ? n_units : DVAE_REC_NPART;
+  const int grid = n_units;          // one unit per workgroup: the hardware dispatcher balances the load
   if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
   else hipLaunchKernelGGL((k_up_thin<3, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
   DVAE_CHECK_LAUNCH();
@@ -460,7 +460,8 @@ int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int d
                          float* partials, hipStream_t s) {
   if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
   const int n_units = a.N * 8;
-  const int grid = n_units < DVAE_REC_NPART ? n_units : DVAE_REC_NPART;
+  // persistent (one loss partial per workgroup): 6 workgroups of 128 threads fit a CU (26 KB LDS each)
+  const int grid = n_units < 1536 ? n_units : 1536;
   if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
   else hipLaunchKernelGGL((k_up_thin<3, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
   DVAE_CHECK_LAUNCH();

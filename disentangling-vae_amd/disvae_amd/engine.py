@@ -74,6 +74,14 @@ class ParamArena:
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
 
+    def span(self, prefix, grad=True):
+        """Contiguous slice of the (gradient) arena covering every tensor whose name starts with
+        `prefix` (the reference's registration order keeps encoder.* and decoder.* contiguous)."""
+        offs = [(o, n) for k, (o, n) in self.offsets.items() if k.startswith(prefix)]
+        lo = min(o for o, _ in offs)
+        hi = max(o + (n + 3) // 4 * 4 for o, n in offs)
+        return (self.grad if grad else self.flat)[lo:min(hi, self.numel)]
+
     def view(self, name, grad=False):
         off, n = self.offsets[name]
         buf = self.grad if grad else self.flat

@@ -326,13 +326,18 @@ class _SingleOptimizerLoss(BaseLoss):
                 else:
                     dmu_x, dlv_x = dmu_all, dlv_all
             eng.decode_backward(buf.z, buf)
+            pending = []
+            if world > 1:      # decoder gradients are final: their all-reduce overlaps the encoder backward
+                pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
             if dz_x is not None:
                 call("dvae_add", ptr(buf.dz), ptr(dz_x), ptr(buf.dz), buf.dz.numel(), s)
             call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dmu_x), ptr(dlv_x), ptr(buf.mu), ptr(buf.logvar), ptr(eps),
                  ptr(sc.scal), ptr(sc.coef), ptr(buf.dml), B, D, s)
             eng.encode_backward(data, buf)
             if world > 1:
-                self.comm.all_reduce(model.arena.grad)
+                pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))
+                for h_ in pending:
+                    h_.wait()
             model.assign_grads()          # optimizer.zero_grad(); loss.backward()  (training.py:156-157)
             optimizer.step()              # training.py:158
         if storer is not None:
@@ -555,8 +560,9 @@ class FactorKLoss(BaseLoss):
              ptr(sc.coef), ptr(buf.dml), Bh, D, s)
         eng.encode_backward(data, buf, n=Bh)
         if world > 1:
-            self.comm.all_reduce(model.arena.grad)
-            self.comm.all_reduce(disc.arena.grad)
+            pending = [self.comm.all_reduce_async(model.arena.grad), self.comm.all_reduce_async(disc.arena.grad)]
+            for h_ in pending:
+                h_.wait()
         model.assign_grads()
         disc.assign_grads()
         optimizer.step()              # losses.py:307

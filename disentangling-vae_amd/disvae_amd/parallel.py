@@ -34,6 +34,12 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_reduce_async(self, t):
+        """Start a sum-all-reduce of `t` (ordered after the work already enqueued on the current
+        stream) and return the handle; `handle.wait()` orders the current stream after it.  Used to
+        overlap the decoder half of the gradient arena with the encoder backward."""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _all_gather(self, t):
         t = t.contiguous()
         if self._host_gather and t.is_cuda:

@@ -290,3 +290,43 @@ def test_no_silent_fallback():
     model = init_specific_model("Burgess", (1, 32, 32), 10)
     with pytest.raises(_lib.DvaeHipError):
         model(torch.rand(2, 1, 32, 32))
+
+
+@pytest.mark.parametrize("loss", ["btcvae", "betaB", "factor"])
+def test_evaluator_losses_vs_oracle(loss, tmp_path):
+    """Evaluator.compute_losses (evaluate.py:97-117): eval-mode forward (z = mean), is_train=False
+    (annealing 1, storer always kept), every batch evaluated; vs the oracle."""
+    import logging
+    from disvae_amd.evaluate import Evaluator
+    img, B = (1, 64, 64), 12
+    model, opt, loss_f = _native(loss, img, 21, 737280, 5e-4)
+    gen = torch.Generator().manual_seed(2)
+    batches = [(torch.rand((B,) + img, generator=gen), torch.zeros(B)) for _ in range(2)]
+    ev = Evaluator(model, loss_f, device=torch.device(DEV), logger=logging.getLogger("e"), save_dir=str(tmp_path),
+                   is_progress_bar=False)
+    model.train()
+    _, losses = ev(batches, is_metrics=False, is_losses=True)
+    assert model.training and loss_f.n_train_steps == 0
+    torch.manual_seed(21)
+    params = O.init_vae_params(img, 10)
+    hp = dict(HP, n_data=737280)
+    want = defaultdict(list)
+    for data, _ in batches:
+        x = data[:B // 2] if loss == "factor" else data
+        with torch.no_grad():
+            recon, (mu, logvar), z = O.vae_forward(params, x, None)
+            if loss == "factor":
+                dparams = O.clone_params({k: v.cpu() for k, v in loss_f.discriminator.state_dict().items()})
+                rec = O.reconstruction_loss(x, recon); kl, _ = O.kl_normal_loss(mu, logvar)
+                d_z = O.discriminator_forward(dparams, z)
+                tc = (d_z[:, 0] - d_z[:, 1]).mean()
+                want["recon_loss"].append(rec.item()); want["kl_loss"].append(kl.item())
+                want["tc_loss"].append(tc.item()); want["loss"].append((rec + kl + 6.4 * tc).item())
+            else:
+                st = O.LossState(steps_anneal=HP["reg_anneal"])
+                _, logs, _ = O.single_optimizer_loss(loss, hp, st, x, recon, mu, logvar, z, False)
+                for k, v in logs.items():
+                    want[k].append(v.item())
+    for k, v in want.items():
+        np.testing.assert_allclose(losses[k], sum(v) / len(v), rtol=5e-5, atol=1e-5, err_msg=k)
+    assert (tmp_path / "test_losses.log").exists()
