@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=None, help="1/0: replay the iteration from a hipGraph "
+                    "(default: on for a single process, off under torch.distributed)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,7 +164,8 @@ def main():
     loss_f = get_loss_f(args.loss, n_data=202599, device=device, lr_disc=1e-5, **HP)
     import logging
     trainer = Trainer(model, optimizer, loss_f, device=device, logger=logging.getLogger("bench"),
-                      save_dir="/tmp/dvae_bench_%d" % rank, is_progress_bar=False)
+                      save_dir="/tmp/dvae_bench_%d" % rank, is_progress_bar=False,
+                      hip_graph=bool(args.graph) if args.graph is not None else None)
     model.train()
     if world > 1:
         parallel.init_process_group_from_env("nccl")

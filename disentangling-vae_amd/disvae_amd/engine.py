@@ -83,9 +83,16 @@ class ParamArena:
         return (self.grad if grad else self.flat)[lo:min(hi, self.numel)]
 
     def view(self, name, grad=False):
-        off, n = self.offsets[name]
-        buf = self.grad if grad else self.flat
-        return buf[off:off + n].view(self.shapes[name])
+        """Shaped view of one tensor of the (gradient) arena; views are cached per placement."""
+        cache = self.__dict__.get("_views")
+        if cache is None or cache[0] is not self.flat or cache[1] is not self.grad:
+            cache = self._views = (self.flat, self.grad, {})
+        v = cache[2].get((name, grad))
+        if v is None:
+            off, n = self.offsets[name]
+            buf = self.grad if grad else self.flat
+            v = cache[2][(name, grad)] = buf[off:off + n].view(self.shapes[name])
+        return v
 
     def to(self, device):
         self.flat = self.flat.to(device)
@@ -94,7 +101,9 @@ class ParamArena:
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream (the raw accessor is ~20x cheaper than building a
+    torch.cuda.Stream object per launch)."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 class _Buffers:

@@ -1,0 +1,48 @@
+"""hipGraph replay of the device side of a training iteration.
+
+A training iteration is a fixed sequence of ~70 launches from libdvae_hip.so whose arguments
+(device pointers, sizes) do not change while the batch size stays the same; below ~512 images
+per GPU the host cannot issue them as fast as the GPU retires them.  ``StepGraphs.run`` executes
+a step function eagerly for the first ``WARMUP`` calls with a given key (allocations, workspace
+sizing, function-attribute set-up happen there), captures it into a hipGraph (through
+torch.cuda.CUDAGraph: capture on a side stream, the engine's fork/join onto its second stream is
+recorded as graph dependencies) on the next call and replays the graph afterwards.
+
+Everything that varies between iterations must live in device memory the captured kernels read:
+the input batch (static buffer), the loss coefficients (``dvae_set_coef`` launch before the
+replay), injected noise / permutations (static buffers).  N(0,1) draws made with torch.randn
+inside the captured region use torch's graph-safe Philox offsets, i.e. every replay draws fresh
+numbers.
+"""
+import torch
+
+
+class StepGraphs:
+    WARMUP = 2
+
+    def __init__(self):
+        self._seen = {}
+        self._graphs = {}
+
+    def clear(self):
+        self._seen.clear()
+        self._graphs.clear()
+
+    def captured(self, key):
+        return key in self._graphs
+
+    def run(self, key, fn):
+        g = self._graphs.get(key)
+        if g is not None:
+            g.replay()
+            return
+        n = self._seen.get(key, 0)
+        self._seen[key] = n + 1
+        if n < self.WARMUP:
+            fn()
+            return
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        self._graphs[key] = g
+        g.replay()          # capture records the launches without executing them

@@ -6,6 +6,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from ..engine import _stream
 from ..engine import ParamArena
 from .. import _lib
 from .._lib import call, ptr, ACT_NONE, ACT_LEAKY02
@@ -70,10 +71,20 @@ class Discriminator(nn.Module):
         return self._arena
 
     def assign_grads(self):
-        for n in self._layer_names:
-            layer = getattr(self, n)
-            layer.weight.grad = self._arena.view(n + ".weight", grad=True)
-            layer.bias.grad = self._arena.view(n + ".bias", grad=True)
+        """Point every Parameter.grad at its slice of the gradient arena (views built once)."""
+        cache = getattr(self, "_grad_views", None)
+        if cache is None or cache[0] is not self._arena.grad:
+            pairs = []
+            for n in self._layer_names:
+                layer = getattr(self, n)
+                pairs.append((layer.weight, self._arena.view(n + ".weight", grad=True)))
+                pairs.append((layer.bias, self._arena.view(n + ".bias", grad=True)))
+            cache = self._grad_views = (self._arena.grad, pairs)
+        pairs = cache[1]
+        if pairs[0][0].grad is pairs[0][1] and pairs[-1][0].grad is pairs[-1][1]:
+            return
+        for p_, g_ in pairs:
+            p_.grad = g_
 
     # ---- raw (non-autograd) engine used by FactorKLoss ------------------------------------
     def _act_buffers(self, M):
@@ -97,7 +108,7 @@ class Discriminator(nn.Module):
         """z[M,latent] -> logits[M,2] (discriminator.py:60-70); activations kept for backward."""
         if self._arena.flat.device.type != "cuda":
             raise _lib.DvaeHipError("the native Discriminator computes only on an MI355X (no CPU fallback)")
-        s = torch.cuda.current_stream().cuda_stream
+        s = _stream()
         b = self._act_buffers(M)
         x = z
         for i, n in enumerate(self._layer_names):
@@ -111,7 +122,7 @@ class Discriminator(nn.Module):
         """Back-propagate g_logits[rows,2] through the MLP evaluated by forward_raw(z, M).
         rows < M restricts to the first `rows` samples (dgrad-only chain of quirk Q1).
         Returns the gradient w.r.t. z ([rows, latent])."""
-        s = torch.cuda.current_stream().cuda_stream
+        s = _stream()
         b = self._act_buffers(M)
         R = M if rows is None else rows
         dy = g_logits

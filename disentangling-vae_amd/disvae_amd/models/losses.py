@@ -12,6 +12,7 @@ Two ways in:
 Host-side state (n_train_steps, annealing, storer cadence) follows losses.py:71-75,105-114.
 """
 import abc
+import os
 
 import torch
 
@@ -19,6 +20,7 @@ from .. import _lib
 from .._lib import call, ptr
 from ..utils.math import log_importance_weights
 from .discriminator import Discriminator
+from ..graph import StepGraphs
 
 LOSSES = ["VAE", "betaH", "betaB", "factor", "btcvae"]  # losses.py:17
 RECON_DIST = ["bernoulli", "laplace", "gaussian"]        # losses.py:18
@@ -55,8 +57,7 @@ def linear_annealing(init, fin, step, annealing_steps):
     return min(init + delta * step / annealing_steps, fin)
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+from ..engine import _stream  # noqa: E402
 
 
 class _Scratch:
@@ -108,6 +109,24 @@ class BaseLoss(abc.ABC):
         self.steps_anneal = steps_anneal
         self._scratch = None
         self.comm = None   # set by disvae_amd.parallel.DataParallel for sharded batches
+        # replay the device side of the native training iteration from a hipGraph (graph.py);
+        # single-process only: collectives stay eager
+        self.use_hip_graph = os.environ.get("DVAE_HIP_GRAPH", "0") == "1"
+        self._graphs = StepGraphs()
+        self._static = {}
+
+    def _static_buf(self, name, like):
+        """Persistent device buffer with the shape/dtype of `like`, refreshed with its contents."""
+        key = (name, tuple(like.shape), like.dtype)
+        t = self._static.get(key)
+        if t is None:
+            t = self._static[key] = torch.empty(like.shape, dtype=like.dtype, device=self._scratch.device)
+        if t.data_ptr() != like.data_ptr():
+            t.copy_(like, non_blocking=True)
+        return t
+
+    def _graph_ok(self, is_train):
+        return self.use_hip_graph and is_train and self._world()[0] == 1
 
     @abc.abstractmethod
     def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):
@@ -283,19 +302,40 @@ class _SingleOptimizerLoss(BaseLoss):
     def fused_step(self, data, model, optimizer, storer, eps=None):
         is_train = model.training
         storer = self._pre_call(is_train, storer)
+        B, D = data.shape[0], model.latent_dim
+        world, rank = self._world()
+        sc = self.scratch(data.device)
+        sc.set_coef(INV_B=1.0 / (B * world), **self._coefs(is_train))
+        data = data.contiguous()
+        if self._graph_ok(is_train):
+            # every replay reads the batch (and injected noise) from the same device buffers
+            data = self._static_buf("data", data)
+            if eps is not None:
+                eps = self._static_buf("eps", eps)
+            self._graphs.run((id(model), B, eps is not None),
+                             lambda: self._device_step(data, model, sc, eps, True))
+        else:
+            self._device_step(data, model, sc, eps, is_train)
+        if is_train:
+            model.assign_grads()          # optimizer.zero_grad(); loss.backward()  (training.py:156-157)
+            optimizer.step()              # training.py:158
+        if storer is not None:
+            vals = sc.scal.tolist()       # ONE device->host copy for every logged scalar
+            self._store(storer, vals, D)
+        return sc.scal[_lib.S_LOSS]
+
+    def _device_step(self, data, model, sc, eps, is_train):
+        """Forward + loss + backward as one stream of launches; no host-dependent values."""
         eng = model.engine
         B, D = data.shape[0], model.latent_dim
         world, rank = self._world()
         Bg = B * world
         buf = eng.buffers(B)
-        sc = self.scratch(data.device)
-        sc.set_coef(INV_B=1.0 / Bg, **self._coefs(is_train))
         s = _stream()
         if is_train and eps is None:
             eps = torch.randn(B, D, dtype=torch.float32, device=data.device)   # vae.py:67
         if not is_train:
             eps = None
-        data = data.contiguous()
         eng.encode(data, buf)
         eng.reparam(buf, eps, sc.kl_dim, sc.coef)
         # decoder; its last layer also evaluates the reconstruction likelihood and dL/dlogit
@@ -314,36 +354,31 @@ class _SingleOptimizerLoss(BaseLoss):
         if world > 1:
             self.comm.all_reduce(sc.packed)
         call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), s)
-        if is_train:
-            dz_x = dmu_x = dlv_x = None
-            if self.KIND == _lib.LOSS_BTCVAE:
-                dz_x = sc.latent("dz_tc", B, D)
-                dmu_all, dlv_all = sc.latent("dmu_all", Bg, D), sc.latent("dlv_all", Bg, D)
-                call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Bg, D, rank * B, B,
-                     int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(tc_tmp), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), s)
-                if world > 1:
-                    dmu_x, dlv_x = self.comm.reduce_scatter_cols(dmu_all, dlv_all)
-                else:
-                    dmu_x, dlv_x = dmu_all, dlv_all
-            eng.decode_backward(buf.z, buf)
-            pending = []
-            if world > 1:      # decoder gradients are final: their all-reduce overlaps the encoder backward
-                pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
-            if dz_x is not None:
-                call("dvae_add", ptr(buf.dz), ptr(dz_x), ptr(buf.dz), buf.dz.numel(), s)
-            call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dmu_x), ptr(dlv_x), ptr(buf.mu), ptr(buf.logvar), ptr(eps),
-                 ptr(sc.scal), ptr(sc.coef), ptr(buf.dml), B, D, s)
-            eng.encode_backward(data, buf)
+        if not is_train:
+            return
+        dz_x = dmu_x = dlv_x = None
+        if self.KIND == _lib.LOSS_BTCVAE:
+            dz_x = sc.latent("dz_tc", B, D)
+            dmu_all, dlv_all = sc.latent("dmu_all", Bg, D), sc.latent("dlv_all", Bg, D)
+            call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Bg, D, rank * B, B,
+                 int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(tc_tmp), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), s)
             if world > 1:
-                pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))
-                for h_ in pending:
-                    h_.wait()
-            model.assign_grads()          # optimizer.zero_grad(); loss.backward()  (training.py:156-157)
-            optimizer.step()              # training.py:158
-        if storer is not None:
-            vals = sc.scal.tolist()       # ONE device->host copy for every logged scalar
-            self._store(storer, vals, D)
-        return sc.scal[_lib.S_LOSS]
+                dmu_x, dlv_x = self.comm.reduce_scatter_cols(dmu_all, dlv_all)
+            else:
+                dmu_x, dlv_x = dmu_all, dlv_all
+        eng.decode_backward(buf.z, buf)
+        pending = []
+        if world > 1:      # decoder gradients are final: their all-reduce overlaps the encoder backward
+            pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
+        if dz_x is not None:
+            call("dvae_add", ptr(buf.dz), ptr(dz_x), ptr(buf.dz), buf.dz.numel(), s)
+        call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dmu_x), ptr(dlv_x), ptr(buf.mu), ptr(buf.logvar), ptr(eps),
+             ptr(sc.scal), ptr(sc.coef), ptr(buf.dml), B, D, s)
+        eng.encode_backward(data, buf)
+        if world > 1:
+            pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))
+            for h_ in pending:
+                h_.wait()
 
 
 class BetaHLoss(_SingleOptimizerLoss):
@@ -469,12 +504,9 @@ class FactorKLoss(BaseLoss):
     def __call__(self, *args, **kwargs):
         raise ValueError("Use `call_optimize` to also train the discriminator")  # losses.py:240-241
 
-    def call_optimize(self, data, model, optimizer, storer, noise=None):
-        """noise: optional (eps1[Bh,D], eps2[Bh,D], perms int64[D,Bh]) injected for parity;
-        by default eps are drawn on the device and the permutations with torch.randperm on the
-        CPU generator, in the reference's order (losses.py:254,286,505)."""
-        is_train = model.training
-        storer = self._pre_call(is_train, storer)
+    def _device_step(self, data, model, sc, eps1, eps2, perms):
+        """Training iteration of FactorVAE as one stream of launches (no host-dependent values):
+        VAE forward on both halves, discriminator on (z1, z_perm), both backward passes."""
         eng = model.engine
         disc = self.discriminator
         D = model.latent_dim
@@ -484,43 +516,15 @@ class FactorKLoss(BaseLoss):
         Bhg = Bh * world
         dev = data.device
         s = _stream()
-        sc = self.scratch(dev)
-        anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
-        sc.set_coef(INV_B=1.0 / Bhg, ANNEAL=anneal, BETA=self.gamma)
-        data = data.contiguous()
-        if noise is not None:
-            eps1, eps2, perms = noise
-        elif is_train:
+        if eps1 is None:
             eps1 = torch.randn(Bh, D, dtype=torch.float32, device=dev)
             eps2 = torch.randn(Bh, D, dtype=torch.float32, device=dev)
-            perms = None
-        else:
-            eps1 = eps2 = perms = None
         buf = eng.buffers(B)
-        n_enc = 2 * Bh if is_train else Bh
-        eng.encode(data, buf, n=n_enc)                                # data1 and data2 in one pass
+        eng.encode(data, buf, n=2 * Bh)                               # data1 and data2 in one pass
         # reparameterise the two halves (KL only over data1, denominator = half batch; losses.py:255-259)
         call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps1), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(sc.kl_dim),
              ptr(sc.coef), Bh, D, s)
         eng.decode(buf.z, buf, n=Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
-        if not is_train:
-            # evaluation: vae_loss only (losses.py:276-278); discriminator on z1
-            logits = disc.forward_raw(buf.z, Bh)
-            g_dtc = sc.latent("g_dtc", 2 * Bh, 2)
-            lg2 = sc.latent("lg2", 2 * Bh, 2)
-            lg2[:Bh].copy_(logits[:Bh]); lg2[Bh:].copy_(logits[:Bh])
-            call("dvae_disc_losses", ptr(lg2), Bh, ptr(sc.coef), ptr(sc.disc_sums), ptr(g_dtc), None, s)
-            call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), s)
-            if world > 1:
-                self.comm.all_reduce(sc.packed)
-            call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), s)
-            if storer is not None:
-                vals = sc.scal.tolist()
-                storer['recon_loss'].append(vals[_lib.S_REC])
-                self._store_kl(storer, vals, D)
-                storer['loss'].append(vals[_lib.S_LOSS])
-                storer['tc_loss'].append(vals[_lib.S_TC])
-            return sc.scal[_lib.S_LOSS]
         off = Bh
         call("dvae_reparam_kl_fwd", ptr(buf.ml[off:]), ptr(eps2), ptr(buf.mu[off:]), ptr(buf.logvar[off:]),
              ptr(buf.z[off:]), None, None, Bh, D, s)                  # sample_latent(data2), losses.py:286
@@ -532,9 +536,6 @@ class FactorKLoss(BaseLoss):
             z2g = self.comm.all_gather_rows(z2)
         else:
             z2g = z2
-        if perms is None:
-            perms = torch.stack([torch.randperm(Bhg) for _ in range(D)])   # CPU generator (shared seed across ranks)
-        perms = perms.to(device=dev, dtype=torch.int64).contiguous()
         zperm_g = sc.latent("zperm_g", Bhg, D)
         call("dvae_permute_dims", ptr(z2g.contiguous()), ptr(perms), ptr(zperm_g), Bhg, D, s)
         zin[Bh:].copy_(zperm_g[rank * Bh:(rank + 1) * Bh])
@@ -563,6 +564,68 @@ class FactorKLoss(BaseLoss):
             pending = [self.comm.all_reduce_async(model.arena.grad), self.comm.all_reduce_async(disc.arena.grad)]
             for h_ in pending:
                 h_.wait()
+
+    def call_optimize(self, data, model, optimizer, storer, noise=None):
+        """noise: optional (eps1[Bh,D], eps2[Bh,D], perms int64[D,Bh]) injected for parity;
+        by default eps are drawn on the device and the permutations with torch.randperm on the
+        CPU generator, in the reference's order (losses.py:254,286,505)."""
+        is_train = model.training
+        storer = self._pre_call(is_train, storer)
+        eng = model.engine
+        disc = self.discriminator
+        D = model.latent_dim
+        B = data.size(0)
+        Bh = B // 2
+        world, rank = self._world()
+        Bhg = Bh * world
+        dev = data.device
+        s = _stream()
+        sc = self.scratch(dev)
+        anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
+        sc.set_coef(INV_B=1.0 / Bhg, ANNEAL=anneal, BETA=self.gamma)
+        data = data.contiguous()
+        if noise is not None:
+            eps1, eps2, perms = noise
+        else:
+            eps1 = eps2 = perms = None       # training draws them on the device in _device_step
+        if is_train:
+            if perms is None:
+                # CPU generator (shared seed across ranks), reference order losses.py:505
+                perms = torch.stack([torch.randperm(Bhg) for _ in range(D)])
+            perms = perms.to(dtype=torch.int64)
+            if self._graph_ok(True):
+                data = self._static_buf("data", data)
+                perms = self._static_buf("perms", perms)
+                if noise is not None:
+                    eps1, eps2 = self._static_buf("eps1", eps1), self._static_buf("eps2", eps2)
+                self._graphs.run((id(model), B, noise is not None),
+                                 lambda: self._device_step(data, model, sc, eps1, eps2, perms))
+            else:
+                self._device_step(data, model, sc, eps1, eps2, perms.to(device=dev).contiguous())
+        else:
+            buf = eng.buffers(B)
+            eng.encode(data, buf, n=Bh)
+            # z = mean; KL over data1 with the half batch as denominator (losses.py:255-259)
+            call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps1), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(sc.kl_dim),
+                 ptr(sc.coef), Bh, D, s)
+            eng.decode(buf.z, buf, n=Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
+            # evaluation: vae_loss only (losses.py:276-278); discriminator on z1
+            logits = disc.forward_raw(buf.z, Bh)
+            g_dtc = sc.latent("g_dtc", 2 * Bh, 2)
+            lg2 = sc.latent("lg2", 2 * Bh, 2)
+            lg2[:Bh].copy_(logits[:Bh]); lg2[Bh:].copy_(logits[:Bh])
+            call("dvae_disc_losses", ptr(lg2), Bh, ptr(sc.coef), ptr(sc.disc_sums), ptr(g_dtc), None, s)
+            call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), s)
+            if world > 1:
+                self.comm.all_reduce(sc.packed)
+            call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), s)
+            if storer is not None:
+                vals = sc.scal.tolist()
+                storer['recon_loss'].append(vals[_lib.S_REC])
+                self._store_kl(storer, vals, D)
+                storer['loss'].append(vals[_lib.S_LOSS])
+                storer['tc_loss'].append(vals[_lib.S_TC])
+            return sc.scal[_lib.S_LOSS]
         model.assign_grads()
         disc.assign_grads()
         optimizer.step()              # losses.py:307

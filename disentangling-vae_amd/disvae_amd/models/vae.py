@@ -10,6 +10,7 @@ All network arithmetic runs in libdvae_hip.so; there is no PyTorch/CPU fallback 
 import torch
 from torch import nn
 
+from ..engine import _stream
 from ..engine import VAEEngine, ParamArena, vae_param_shapes
 from .. import _lib
 from .._lib import call, ptr
@@ -155,14 +156,22 @@ class VAE(nn.Module):
         return list(self._flat_params)
 
     def assign_grads(self):
-        """Point every Parameter.grad at its slice of the flat gradient arena."""
-        for p_, g_ in zip(self._flat_params, self._arena_chunks(grad=True)):
+        """Point every Parameter.grad at its slice of the flat gradient arena.  The views are
+        built once per arena placement; afterwards this is two identity checks per step."""
+        cache = getattr(self, "_grad_views", None)
+        if cache is None or cache[0] is not self._arena.grad:
+            pairs = list(zip(self._flat_params, self._arena_chunks(grad=True)))
+            for name in self._layer_names:
+                half, lname = name.split(".")
+                layer = getattr(getattr(self, half), lname)
+                pairs.append((layer.weight, self._arena.view(name + ".weight", grad=True)))
+                pairs.append((layer.bias, self._arena.view(name + ".bias", grad=True)))
+            cache = self._grad_views = (self._arena.grad, pairs)
+        pairs = cache[1]
+        if pairs[0][0].grad is pairs[0][1] and pairs[-1][0].grad is pairs[-1][1]:
+            return
+        for p_, g_ in pairs:
             p_.grad = g_
-        for name in self._layer_names:
-            half, lname = name.split(".")
-            layer = getattr(getattr(self, half), lname)
-            layer.weight.grad = self._arena.view(name + ".weight", grad=True)
-            layer.bias.grad = self._arena.view(name + ".bias", grad=True)
 
     # ---- reference API --------------------------------------------------------------------
     def reparameterize(self, mean, logvar):
@@ -239,7 +248,7 @@ class _VAEFn(torch.autograd.Function):
         eng = model.engine
         B = x.shape[0]
         buf = eng.buffers(B)
-        s = torch.cuda.current_stream().cuda_stream
+        s = _stream()
         dz = g_z.contiguous() if g_z is not None else None
         if ctx.decode and g_recon is not None:
             call("dvae_sigmoid_bwd", ptr(g_recon.contiguous()), ptr(buf.recon), ptr(buf.g_logit), buf.recon.numel(), s)
@@ -288,7 +297,7 @@ class _EncodeFn(torch.autograd.Function):
             raise _lib.DvaeHipError("backward through a stale forward")
         eng = model.engine
         buf = eng.buffers(x.shape[0])
-        s = torch.cuda.current_stream().cuda_stream
+        s = _stream()
         scal = _zeros_scal(x.device)
         coef = torch.ones(_lib.NCOEF, dtype=torch.float32, device=x.device)
         gm = g_mu.contiguous() if g_mu is not None else None
@@ -324,7 +333,7 @@ class _DecodeFn(torch.autograd.Function):
             raise _lib.DvaeHipError("backward through a stale forward")
         eng = model.engine
         buf = eng.buffers(z.shape[0])
-        s = torch.cuda.current_stream().cuda_stream
+        s = _stream()
         call("dvae_sigmoid_bwd", ptr(g_recon.contiguous()), ptr(buf.recon), ptr(buf.g_logit), buf.recon.numel(), s)
         eng.decode_backward(z, buf)
         grads = []
