@@ -6,6 +6,7 @@
 //   wgrad : dw = dy^T x      A = dy (i fast)   B = x  (j fast)   + db[i] = sum_k A(i,k)
 // 64x64 output tile per 256-thread workgroup (2x2 waves of one 32x32 MFMA accumulator each),
 // K staged through LDS in slices of 32 with register prefetch of the next slice.
+#include <stdint.h>
 #include <stdlib.h>
 #include "common.h"
 
@@ -227,6 +228,172 @@ __global__ __launch_bounds__(256) void k_gemm32(const float* __restrict__ a, lon
   }
 }
 
+// ---- FC GEMM with the WHOLE contraction resident in LDS (Kc <= 512: every FC layer of the VAE) ----
+// A 32x32 output tile per 256-thread workgroup.  Both operand tiles (32 x Kc each) are fetched with
+// coalesced 16-byte loads that are ALL in flight at once (one memory latency per launch instead of
+// one per 32-deep slice), staged in LDS, and each of the 4 waves multiplies a quarter of the
+// contraction.  The contraction index is permuted so that a lane reads its MFMA operands with
+// 16-byte LDS loads: step t of lane-half h uses kappa = wave*KP/4 + h*S + t (S = KP/8); the sum is
+// order-independent and A and B use the same map.  The 4 partial tiles are summed through LDS in a
+// fixed order, every wave finishing 4 of the 16 accumulator rows (bias / activation / mask fused).
+//   A(i,k) = a[i*lda + k];  B_JFAST ? B(k,j) = b[k*ldb + j] (dgrad)  :  B(k,j) = b[j*ldb + k] (forward)
+// KP = Kc rounded up to a power of two in [32,512] (the tail is zero-filled in LDS).
+template <int KP, bool B_JFAST>
+__global__ __launch_bounds__(256) void k_fc32(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                              float* __restrict__ c, long ldc, int M, int N, int Kc,
+                                              const float* __restrict__ bias, int act,
+                                              const float* __restrict__ mask, int mask_act) {
+  extern __shared__ __attribute__((aligned(16))) float fc_lds[];
+  constexpr int SA = KP + 4;               // row stride of a k-contiguous tile (16-byte aligned, conflict-free b128 reads)
+  constexpr int KQ = KP / 4;               // 16-byte chunks per row
+  constexpr int S = KP / 8;                // MFMA steps per wave (per lane half)
+  constexpr int NA = KQ / 8;               // 16-byte loads per thread for a [32][KP] tile
+  constexpr int NBJ = KP / 32;             // 16-byte loads per thread for a [KP][32] tile
+  float* As = fc_lds;
+  float* Bs = fc_lds + 32 * SA;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+
+  // ---- stage: all global loads first, then the LDS stores
+  f32x4 ra[NA];
+  f32x4 rb[B_JFAST ? NBJ : NA];
+#pragma unroll
+  for (int p = 0; p < NA; ++p) {
+    const int idx = tid + 256 * p;
+    const int row = idx / KQ, c4 = (idx % KQ) * 4;
+    const int gi = m0 + row;
+    const bool ok = gi < M && c4 < Kc;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a + (long)(gi < M ? gi : M - 1) * lda + (c4 < Kc ? c4 : 0));
+    ra[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (!B_JFAST) {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const int idx = tid + 256 * p;
+      const int row = idx / KQ, c4 = (idx % KQ) * 4;
+      const int gj = n0 + row;
+      const bool ok = gj < N && c4 < Kc;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(b + (long)(gj < N ? gj : N - 1) * ldb + (c4 < Kc ? c4 : 0));
+      rb[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < NBJ; ++p) {
+      const int idx = tid + 256 * p;
+      const int kap = idx >> 3, j4 = (idx & 7) * 4;
+      const int gj = n0 + j4;
+      const bool ok = kap < Kc && gj < N;                      // N % 4 == 0: a chunk is entirely in or out
+      const f32x4 v = *reinterpret_cast<const f32x4*>(b + (long)(kap < Kc ? kap : 0) * ldb + (gj < N ? gj : 0));
+      rb[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NA; ++p) {
+    const int idx = tid + 256 * p;
+    *reinterpret_cast<f32x4*>(As + (idx / KQ) * SA + (idx % KQ) * 4) = ra[p];
+  }
+  if (!B_JFAST) {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const int idx = tid + 256 * p;
+      *reinterpret_cast<f32x4*>(Bs + (idx / KQ) * SA + (idx % KQ) * 4) = rb[p];
+    }
+  } else {
+    // [kappa][32] rows with one spare row after every S rows: the two lane halves of a wave (kappa
+    // apart by S, a multiple of 4) then read rows of different parity = different bank halves
+#pragma unroll
+    for (int p = 0; p < NBJ; ++p) {
+      const int idx = tid + 256 * p;
+      const int kap = idx >> 3;
+      *reinterpret_cast<f32x4*>(Bs + (kap + kap / S) * 32 + (idx & 7) * 4) = rb[p];
+    }
+  }
+  __syncthreads();
+
+  // ---- multiply: wave wv, lane half h: kappa = (2 wv + h) S + t
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+  const int kap0 = (2 * wv + h) * S;
+  const float* ap = As + i * SA + kap0;
+  const float* bp = B_JFAST ? Bs + (kap0 + 2 * wv + h) * 32 + i : Bs + i * SA + kap0;
+#pragma unroll
+  for (int q = 0; q < S / 4; ++q) {
+    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 4 * q);
+    f32x4 bv;
+    if (B_JFAST) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bv[u] = bp[(4 * q + u) * 32];
+    } else {
+      bv = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[u], 0, 0, 0);
+  }
+  const f32x16 accs = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();                                   // operand tiles are dead: reuse the space
+  float* red = fc_lds;                               // [4 waves][16 regs][64 lanes]
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[(wv * 16 + e) * 64 + lane] = accs[e];
+  __syncthreads();
+  const int col = n0 + i;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = 4 * wv + u;
+    const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    float v = (red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane]) +
+              (red[(2 * 16 + e) * 64 + lane] + red[(3 * 16 + e) * 64 + lane]);
+    if (row < M && col < N) {
+      if (bias) v += bias[col];
+      if (act == DVAE_ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (act == DVAE_ACT_LEAKY02) v = v > 0.f ? v : 0.2f * v;
+      const long o = (long)row * ldc + col;
+      if (mask) {
+        const float mv = mask[o];
+        if (mask_act == DVAE_ACT_RELU) v = mv > 0.f ? v : 0.f;
+        else if (mask_act == DVAE_ACT_LEAKY02) v = mv > 0.f ? v : 0.2f * v;
+      }
+      c[o] = v;
+    }
+  }
+}
+
+template <int KP, bool BJ>
+static void launch_fc32_t(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
+                          const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
+  size_t lds = (size_t)(32 * (KP + 4) + (BJ ? (KP + 8) * 32 : 32 * (KP + 4))) * sizeof(float);
+  if (lds < 4 * 16 * 64 * sizeof(float)) lds = 4 * 16 * 64 * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_fc32<KP, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_fc32<KP, BJ>), dim3((N + 31) / 32, (M + 31) / 32), dim3(256), lds, s, a, lda, b, ldb, c, ldc, M, N,
+                     Kc, bias, act, mask, mask_act);
+}
+
+// true if the launch was taken by k_fc32
+template <bool BJ>
+static bool try_fc32(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
+                     const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
+  static const bool off = getenv("DVAE_GEMM_FC") && getenv("DVAE_GEMM_FC")[0] == '0';
+  if (off || Kc > 512 || Kc % 4 || lda % 4 || ldb % 4 || (BJ && N % 4)) return false;
+  if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return false;
+  if ((long)((M + 63) / 64) * ((N + 63) / 64) >= 512) return false;      // big outputs: the 64x64-tile kernel
+#define DVAE_FC_CASE(KP) launch_fc32_t<KP, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s)
+  if (Kc <= 32) DVAE_FC_CASE(32);
+  else if (Kc <= 64) DVAE_FC_CASE(64);
+  else if (Kc <= 128) DVAE_FC_CASE(128);
+  else if (Kc <= 256) DVAE_FC_CASE(256);
+  else DVAE_FC_CASE(512);
+#undef DVAE_FC_CASE
+  return true;
+}
+
 // small problems (everything in the VAE) go to k_gemm32; large ones (discriminator) to k_gemm
 // measured (profiles/r01_run12): k_gemm32 wins only for the forward form with 16-byte loads on both
 // operands (11.2 vs 13.3 us at 1024x512x256); the lane-contiguous dgrad / wgrad forms are slower than the
@@ -290,6 +457,11 @@ static int pick_split(int tiles, int Kc, size_t out_elems, float* ws, size_t ws_
 
 int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, float* ws,
                       size_t ws_floats, hipStream_t s) {
+  // A = x (k contiguous), B(k,j) = w[j*K + k] (k contiguous)
+  if (try_fc32<false>(x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s)) {
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
   if (use_small(M, N, K, K % 4 == 0)) {
     // A = x (k contiguous), B(k,j) = w[j*K + k] (k contiguous)
     if (K % 4 == 0)
@@ -323,6 +495,10 @@ int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, 
 int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
                         float* ws, size_t ws_floats, hipStream_t s) {
   // dx[M,K] = dy[M,N] w[N,K]: contraction length N
+  if (try_fc32<true>(dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s)) {
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
   if (use_small(M, K, N, false)) {
     // A = dy (contraction index n contiguous), B(k=n, j) = w[n*K + j] (j contiguous -> lanes)
     if (N % 4 == 0)

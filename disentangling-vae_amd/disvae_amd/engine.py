@@ -11,6 +11,7 @@ Reference being replaced: EncoderBurgess.forward (encoders.py:69-89), VAE.repara
 (vae.py:52-71), DecoderBurgess.forward (decoders.py:67-84) and their autograd backward
 (training.py:157).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -100,6 +101,9 @@ class ParamArena:
         return self
 
 
+_CONV_WGRAD_MAIN = os.environ.get("DVAE_CONV_WGRAD_MAIN", "0") == "1"
+
+
 def _stream():
     """hipStream_t of torch's current stream (the raw accessor is ~20x cheaper than building a
     torch.cuda.Stream object per launch)."""
@@ -183,6 +187,16 @@ class VAEEngine:
         call("dvae_linear_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(db), M, K, N, ptr(self._ws_side),
              self._side.cuda_stream)
 
+    def _conv_wgrad(self, fn, *args):
+        """Conv / convT weight gradient `fn(*args, ws, stream)`: off the dgrad critical path, so it
+        goes to the side stream (ordered after everything enqueued so far on the current one) and
+        co-runs with the dgrad chain; DVAE_CONV_WGRAD_MAIN=1 keeps it on the current stream."""
+        if _CONV_WGRAD_MAIN:
+            call(fn, *args, ptr(self._ws), _stream())
+            return
+        self._side.wait_stream(torch.cuda.current_stream())
+        call(fn, *args, ptr(self._ws_side), self._side.cuda_stream)
+
     def _join_side(self):
         torch.cuda.current_stream().wait_stream(self._side)
 
@@ -257,8 +271,9 @@ class VAEEngine:
         dy, dy_layout = buf.g_logit, NCHW
         for k in range(len(names) - 1, -1, -1):
             name, x_in, gx, h = names[k], acts[k], gacts[k], hs[k]
-            call("dvae_convT4s2_wgrad", ptr(x_in), NHWC, ptr(dy), dy_layout, ptr(self.g("decoder.%s.weight" % name)),
-                 ptr(self.g("decoder.%s.bias" % name)), B, HID, h, h, couts[k], ws, s)
+            self._conv_wgrad("dvae_convT4s2_wgrad", ptr(x_in), NHWC, ptr(dy), dy_layout,
+                             ptr(self.g("decoder.%s.weight" % name)), ptr(self.g("decoder.%s.bias" % name)),
+                             B, HID, h, h, couts[k])
             call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(x_in), ptr(gx),
                  NHWC, B, HID, h, h, couts[k], s)
             dy, dy_layout = gx, NHWC
@@ -299,8 +314,9 @@ class VAEEngine:
             else:
                 x_in, x_layout, cin = x, NCHW, c
             dy = buf.enc_gact[k]
-            call("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), NHWC, ptr(self.g("encoder.%s.weight" % name)),
-                 ptr(self.g("encoder.%s.bias" % name)), B, cin, h_in, h_in, HID, ws, s)
+            self._conv_wgrad("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), NHWC,
+                             ptr(self.g("encoder.%s.weight" % name)), ptr(self.g("encoder.%s.bias" % name)),
+                             B, cin, h_in, h_in, HID)
             if k > 0:
                 call("dvae_conv4s2_dgrad", ptr(dy), NHWC, ptr(self.p("encoder.%s.weight" % name)), ptr(x_in),
                      ptr(buf.enc_gact[k - 1]), NHWC, B, cin, h_in, h_in, HID, s)
