@@ -132,8 +132,8 @@ def main():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--graph", type=int, default=None, help="1/0: replay the iteration from a hipGraph "
-                    "(default: on for a single process, off under torch.distributed)")
+    ap.add_argument("--replay", default=None, choices=["auto", "eager", "plan", "graph"],
+                    help="how the launches of an iteration are issued (disvae_amd/graph.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,7 +165,7 @@ def main():
     import logging
     trainer = Trainer(model, optimizer, loss_f, device=device, logger=logging.getLogger("bench"),
                       save_dir="/tmp/dvae_bench_%d" % rank, is_progress_bar=False,
-                      hip_graph=bool(args.graph) if args.graph is not None else None)
+                      replay=None if args.replay is None else (False if args.replay == "eager" else args.replay))
     model.train()
     if world > 1:
         parallel.init_process_group_from_env("nccl")

@@ -80,12 +80,53 @@ def lib():
     return _lib
 
 
+ALLOC_GEN = [0]   # bumped whenever the engine (re)allocates device buffers: recorded plans hold raw pointers
+
+
+def note_alloc():
+    ALLOC_GEN[0] += 1
+
+
+_REC = None   # launch list being recorded (graph.py: "plan" replay), or None
+
+
 def call(name, *args):
     """Call an int-returning entry point, raise on a non-zero status."""
     h = lib()
-    rc = getattr(h, name)(*args)
+    fn = getattr(h, name)
+    if _REC is not None:
+        # frozen copy of the launch: arguments pre-converted to their ctypes so that a replay is
+        # one foreign call per launch with no Python-side marshalling
+        _REC.append((fn, tuple(None if a is None else t(a) for t, a in zip(fn.argtypes, args)), name))
+    rc = fn(*args)
     if rc != 0:
         raise DvaeHipError("%s failed (%d): %s" % (name, rc, h.dvae_last_error().decode()))
+
+
+def record_py(fn, *args):
+    """Run a host-side callable that belongs to the launch sequence (stream fork/join, a torch
+    copy) and keep it in the recorded plan."""
+    if _REC is not None:
+        _REC.append((fn, args, None))
+    return fn(*args)
+
+
+def begin_record():
+    global _REC
+    _REC = []
+
+
+def end_record():
+    global _REC
+    plan, _REC = _REC, None
+    return plan
+
+
+def replay(plan):
+    for fn, args, name in plan:
+        rc = fn(*args)
+        if name is not None and rc != 0:
+            raise DvaeHipError("%s failed (%d): %s" % (name, rc, lib().dvae_last_error().decode()))
 
 
 def ptr(t):

@@ -17,7 +17,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib
-from ._lib import call, ptr, NCHW, NHWC, ACT_NONE, ACT_RELU, ACT_SIGMOID
+from ._lib import call, ptr, record_py, NCHW, NHWC, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 HID = 32
 HIDDEN_DIM = 256
@@ -96,6 +96,7 @@ class ParamArena:
         return v
 
     def to(self, device):
+        _lib.note_alloc()
         self.flat = self.flat.to(device)
         self.grad = self.grad.to(device)
         return self
@@ -114,6 +115,7 @@ class _Buffers:
     """Activation / gradient workspace for one batch size."""
 
     def __init__(self, eng, B):
+        _lib.note_alloc()
         dev = eng.device
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         self.B = B
@@ -173,6 +175,7 @@ class VAEEngine:
             self._bufs[B] = b
         if self._ws is None or self._ws.device != self.device:
             n = _lib.lib().dvae_conv_wgrad_ws_floats()
+            _lib.note_alloc()
             self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
             self._ws_side = torch.empty(n, dtype=torch.float32, device=self.device)
             self._side = torch.cuda.Stream(device=self.device)
@@ -182,8 +185,7 @@ class VAEEngine:
     def _side_wgrad(self, x, dy, dw, db, M, K, N):
         """dw, db <- wgrad(x, dy) on the side stream, ordered after everything enqueued so far on
         the current stream (the small GEMM then overlaps with the dgrad chain that continues on it)."""
-        main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
+        record_py(self._side.wait_stream, torch.cuda.current_stream())
         call("dvae_linear_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(db), M, K, N, ptr(self._ws_side),
              self._side.cuda_stream)
 
@@ -194,11 +196,11 @@ class VAEEngine:
         if _CONV_WGRAD_MAIN:
             call(fn, *args, ptr(self._ws), _stream())
             return
-        self._side.wait_stream(torch.cuda.current_stream())
+        record_py(self._side.wait_stream, torch.cuda.current_stream())
         call(fn, *args, ptr(self._ws_side), self._side.cuda_stream)
 
     def _join_side(self):
-        torch.cuda.current_stream().wait_stream(self._side)
+        record_py(torch.cuda.current_stream().wait_stream, self._side)
 
     # ------------------------------------------------------------------ forward
     def encode(self, x, buf, n=None):

@@ -1,4 +1,4 @@
-"""hipGraph replay of the device side of a training iteration.
+"""Replay of the device side of a training iteration: recorded launch plan or hipGraph.
 
 A training iteration is a fixed sequence of ~70 launches from libdvae_hip.so whose arguments
 (device pointers, sizes) do not change while the batch size stays the same; below ~512 images
@@ -16,13 +16,21 @@ numbers.
 """
 import torch
 
+from . import _lib
+
 
 class StepGraphs:
+    """mode "plan": the launches (C-ABI calls with frozen, pre-marshalled arguments + the stream
+    fork/join calls) are recorded once while they execute and re-issued from a flat list -- same
+    kernels, same streams, same order as the eager path, minus the Python work in between.
+    mode "graph": capture into a hipGraph and replay it (see the module docstring)."""
     WARMUP = 2
+    MAX_PLANS = 32
 
     def __init__(self):
         self._seen = {}
         self._graphs = {}
+        self.replays = 0
 
     def clear(self):
         self._seen.clear()
@@ -31,10 +39,27 @@ class StepGraphs:
     def captured(self, key):
         return key in self._graphs
 
-    def run(self, key, fn):
+    def run(self, key, fn, mode="graph"):
+        key = (mode,) + tuple(key)
         g = self._graphs.get(key)
         if g is not None:
-            g.replay()
+            self.replays += 1
+            if mode == "plan":
+                _lib.replay(g)
+            else:
+                g.replay()
+            return
+        if mode == "plan":
+            # recording IS an eager execution: no warm-up needed; a plan whose key went stale (new
+            # batch pointer, re-allocated buffers) is simply never replayed again
+            if len(self._graphs) >= self.MAX_PLANS:
+                self._graphs.clear()
+            _lib.begin_record()
+            try:
+                fn()
+            finally:
+                plan = _lib.end_record()
+            self._graphs[key] = plan
             return
         n = self._seen.get(key, 0)
         self._seen[key] = n + 1

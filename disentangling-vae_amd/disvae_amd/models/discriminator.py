@@ -90,6 +90,7 @@ class Discriminator(nn.Module):
     def _act_buffers(self, M):
         b = self._acts.get(M)
         if b is None:
+            _lib.note_alloc()
             dev = self._arena.flat.device
             f = lambda n: torch.empty(M, n, dtype=torch.float32, device=dev)
             b = dict(h=[f(self.dims[i + 1]) for i in range(6)],           # outputs of lin1..lin6
@@ -100,6 +101,7 @@ class Discriminator(nn.Module):
 
     def _ws(self):
         if getattr(self, "_wsbuf", None) is None or self._wsbuf.device != self._arena.flat.device:
+            _lib.note_alloc()
             self._wsbuf = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), dtype=torch.float32,
                                       device=self._arena.flat.device)
         return self._wsbuf

@@ -17,7 +17,7 @@ import os
 import torch
 
 from .. import _lib
-from .._lib import call, ptr
+from .._lib import call, ptr, record_py
 from ..utils.math import log_importance_weights
 from .discriminator import Discriminator
 from ..graph import StepGraphs
@@ -64,6 +64,7 @@ class _Scratch:
     """Small device buffers shared by the loss kernels of one loss object."""
 
     def __init__(self, device):
+        _lib.note_alloc()
         f = lambda n: torch.zeros(n, dtype=torch.float32, device=device)
         self.device = device
         self.coef = f(_lib.NCOEF)
@@ -94,6 +95,7 @@ class _Scratch:
     def latent(self, name, rows, cols):
         t = self.lat.get((name, rows, cols))
         if t is None:
+            _lib.note_alloc()
             t = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
             self.lat[(name, rows, cols)] = t
         return t
@@ -109,9 +111,12 @@ class BaseLoss(abc.ABC):
         self.steps_anneal = steps_anneal
         self._scratch = None
         self.comm = None   # set by disvae_amd.parallel.DataParallel for sharded batches
-        # replay the device side of the native training iteration from a hipGraph (graph.py);
-        # single-process only: collectives stay eager
-        self.use_hip_graph = os.environ.get("DVAE_HIP_GRAPH", "0") == "1"
+        # how the device side of the native training iteration is issued (graph.py): None = eager
+        # Python; "plan" = recorded launch list (the same launches on the same streams, bit-identical
+        # results); "graph" = hipGraph; "auto" (default) = plan while the iteration is launch-bound
+        # (batch tensor <= AUTO_PLAN_ELEMS elements: measured cross-over), eager
+        # above.  Single-process only (collectives stay eager)
+        self.replay = {"plan": "plan", "graph": "graph", "eager": None, "auto": "auto"}[os.environ.get("DVAE_REPLAY", "auto")]
         self._graphs = StepGraphs()
         self._static = {}
 
@@ -120,13 +125,26 @@ class BaseLoss(abc.ABC):
         key = (name, tuple(like.shape), like.dtype)
         t = self._static.get(key)
         if t is None:
+            _lib.note_alloc()
             t = self._static[key] = torch.empty(like.shape, dtype=like.dtype, device=self._scratch.device)
         if t.data_ptr() != like.data_ptr():
             t.copy_(like, non_blocking=True)
         return t
 
-    def _graph_ok(self, is_train):
-        return self.use_hip_graph and is_train and self._world()[0] == 1
+    AUTO_PLAN_ELEMS = 256 * 3 * 64 * 64
+
+    def _replay_mode(self, is_train, data):
+        if not (is_train and self._world()[0] == 1):
+            return None
+        if self.replay == "auto":
+            return "plan" if data.numel() <= self.AUTO_PLAN_ELEMS else None
+        return self.replay
+
+    def _replay_key(self, model, data, injected):
+        """Everything a recorded launch freezes: buffers (allocation generation), arenas, the
+        batch pointer, the stream, and the few Python-side switches passed as scalars."""
+        return (id(model), data.shape, data.data_ptr(), injected, _stream(), model.arena.flat.data_ptr(),
+                model.arena.grad.data_ptr(), _lib.ALLOC_GEN[0], self.rec_dist, getattr(self, "is_mss", None))
 
     @abc.abstractmethod
     def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):
@@ -307,13 +325,18 @@ class _SingleOptimizerLoss(BaseLoss):
         sc = self.scratch(data.device)
         sc.set_coef(INV_B=1.0 / (B * world), **self._coefs(is_train))
         data = data.contiguous()
-        if self._graph_ok(is_train):
-            # every replay reads the batch (and injected noise) from the same device buffers
-            data = self._static_buf("data", data)
+        if self.KIND == _lib.LOSS_BTCVAE:
+            sc.set_log_w(B * world, self.n_data)
+        mode = self._replay_mode(is_train, data)
+        if mode:
+            # a replay re-issues launches with frozen pointers: injected noise goes through a static
+            # buffer; the batch pointer is part of the plan key (a hipGraph needs it static as well)
+            if mode == "graph":
+                data = self._static_buf("data", data)
             if eps is not None:
                 eps = self._static_buf("eps", eps)
-            self._graphs.run((id(model), B, eps is not None),
-                             lambda: self._device_step(data, model, sc, eps, True))
+            self._graphs.run(self._replay_key(model, data, eps is not None),
+                             lambda: self._device_step(data, model, sc, eps, True), mode)
         else:
             self._device_step(data, model, sc, eps, is_train)
         if is_train:
@@ -333,7 +356,8 @@ class _SingleOptimizerLoss(BaseLoss):
         buf = eng.buffers(B)
         s = _stream()
         if is_train and eps is None:
-            eps = torch.randn(B, D, dtype=torch.float32, device=data.device)   # vae.py:67
+            eps = sc.latent("eps", B, D)
+            record_py(eps.normal_)             # = torch.randn_like (vae.py:67): same Philox consumption
         if not is_train:
             eps = None
         eng.encode(data, buf)
@@ -345,7 +369,6 @@ class _SingleOptimizerLoss(BaseLoss):
             zg, mug, lvg = buf.z, buf.mu, buf.logvar
             if world > 1:
                 zg, mug, lvg = self.comm.all_gather_latents(buf.z, buf.mu, buf.logvar)
-            sc.set_log_w(Bg, self.n_data)
             rowstats = sc.latent("rowstats", B, 16)
             tc_tmp = sc.latent("tc_tmp", 3 * D, Bg)
             call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Bg, D, rank * B, B, int(self.is_mss), ptr(sc.log_w),
@@ -517,8 +540,9 @@ class FactorKLoss(BaseLoss):
         dev = data.device
         s = _stream()
         if eps1 is None:
-            eps1 = torch.randn(Bh, D, dtype=torch.float32, device=dev)
-            eps2 = torch.randn(Bh, D, dtype=torch.float32, device=dev)
+            eps1, eps2 = sc.latent("eps1", Bh, D), sc.latent("eps2", Bh, D)
+            record_py(eps1.normal_)            # losses.py:254 (forward on data1)
+            record_py(eps2.normal_)            # losses.py:286 (sample_latent(data2))
         buf = eng.buffers(B)
         eng.encode(data, buf, n=2 * Bh)                               # data1 and data2 in one pass
         # reparameterise the two halves (KL only over data1, denominator = half batch; losses.py:255-259)
@@ -530,7 +554,7 @@ class FactorKLoss(BaseLoss):
              ptr(buf.z[off:]), None, None, Bh, D, s)                  # sample_latent(data2), losses.py:286
         # z_perm: permute across the (global) half batch, losses.py:287
         zin = sc.latent("disc_in", 2 * Bh, D)
-        zin[:Bh].copy_(buf.z[:Bh])
+        record_py(zin[:Bh].copy_, buf.z[:Bh])
         z2 = buf.z[off:off + Bh]
         if world > 1:
             z2g = self.comm.all_gather_rows(z2)
@@ -538,7 +562,7 @@ class FactorKLoss(BaseLoss):
             z2g = z2
         zperm_g = sc.latent("zperm_g", Bhg, D)
         call("dvae_permute_dims", ptr(z2g.contiguous()), ptr(perms), ptr(zperm_g), Bhg, D, s)
-        zin[Bh:].copy_(zperm_g[rank * Bh:(rank + 1) * Bh])
+        record_py(zin[Bh:].copy_, zperm_g[rank * Bh:(rank + 1) * Bh])
         logits = disc.forward_raw(zin, 2 * Bh)                        # D(z1) and D(z_perm) in one pass
         g_dtc = sc.latent("g_dtc", 2 * Bh, 2)
         g_tc = sc.latent("g_tc", Bh, 2)
@@ -593,13 +617,15 @@ class FactorKLoss(BaseLoss):
                 # CPU generator (shared seed across ranks), reference order losses.py:505
                 perms = torch.stack([torch.randperm(Bhg) for _ in range(D)])
             perms = perms.to(dtype=torch.int64)
-            if self._graph_ok(True):
-                data = self._static_buf("data", data)
+            mode = self._replay_mode(True, data)
+            if mode:
+                if mode == "graph":
+                    data = self._static_buf("data", data)
                 perms = self._static_buf("perms", perms)
                 if noise is not None:
                     eps1, eps2 = self._static_buf("eps1", eps1), self._static_buf("eps2", eps2)
-                self._graphs.run((id(model), B, noise is not None),
-                                 lambda: self._device_step(data, model, sc, eps1, eps2, perms))
+                self._graphs.run(self._replay_key(model, data, noise is not None) + (disc.arena.flat.data_ptr(),),
+                                 lambda: self._device_step(data, model, sc, eps1, eps2, perms), mode)
             else:
                 self._device_step(data, model, sc, eps1, eps2, perms.to(device=dev).contiguous())
         else:

@@ -26,10 +26,11 @@ TRAIN_LOSSES_LOGFILE = "train_losses.log"
 
 class Trainer():
     def __init__(self, model, optimizer, loss_f, device=torch.device("cpu"), logger=logging.getLogger(__name__),
-                 save_dir="results", gif_visualizer=None, is_progress_bar=True, hip_graph=None):
-        """``hip_graph=True`` replays the device side of the native iteration from a hipGraph
-        (disvae_amd/graph.py): worthwhile below ~512 images per GPU, where issuing the ~70
-        launches from the host takes longer than the GPU needs to run them."""
+                 save_dir="results", gif_visualizer=None, is_progress_bar=True, replay=None):
+        """``replay="plan"`` re-issues the device side of the native iteration from a recorded
+        launch list, ``replay="graph"`` from a hipGraph (disvae_amd/graph.py): worthwhile below
+        ~512 images per GPU, where issuing the ~75 launches from Python takes longer than the GPU
+        needs to run them.  ``False`` forces the eager path; ``None`` keeps the loss's setting."""
         self.device = device
         self.model = model.to(self.device)
         self.loss_f = loss_f
@@ -39,8 +40,8 @@ class Trainer():
         self.logger = logger
         self.losses_logger = LossesLogger(os.path.join(self.save_dir, TRAIN_LOSSES_LOGFILE))
         self.gif_visualizer = gif_visualizer
-        if hip_graph is not None and isinstance(loss_f, BaseLoss):
-            loss_f.use_hip_graph = bool(hip_graph)
+        if replay is not None and isinstance(loss_f, BaseLoss):
+            loss_f.replay = replay or None
         self.logger.info("Training Device: {}".format(self.device))
 
     def __call__(self, data_loader, epochs=10, checkpoint_every=10):
