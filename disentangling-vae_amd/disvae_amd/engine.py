@@ -182,21 +182,31 @@ class VAEEngine:
         return b
 
     # ---- fork / join of the side stream (weight-gradient GEMMs of the FC layers) ----------------
-    def _side_wgrad(self, x, dy, dw, db, M, K, N):
-        """dw, db <- wgrad(x, dy) on the side stream, ordered after everything enqueued so far on
-        the current stream (the small GEMM then overlaps with the dgrad chain that continues on it)."""
+    def fork_side(self):
+        """Order the side stream after everything enqueued so far on the current stream.  A fork
+        costs the current stream ~6 us (event signal between hardware queues, profiles/r01_run19
+        timeline), so the FC weight gradients fork once per chain, not once per layer."""
         record_py(self._side.wait_stream, torch.cuda.current_stream())
+
+    @property
+    def side_stream(self):
+        return self._side
+
+    def _side_wgrad(self, x, dy, dw, db, M, K, N):
+        """dw, db <- wgrad(x, dy) on the side stream (after a fork_side): overlaps with whatever the
+        current stream does next."""
         call("dvae_linear_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(db), M, K, N, ptr(self._ws_side),
              self._side.cuda_stream)
 
-    def _conv_wgrad(self, fn, *args):
+    def _conv_wgrad(self, fn, *args, fork=True):
         """Conv / convT weight gradient `fn(*args, ws, stream)`: off the dgrad critical path, so it
-        goes to the side stream (ordered after everything enqueued so far on the current one) and
-        co-runs with the dgrad chain; DVAE_CONV_WGRAD_MAIN=1 keeps it on the current stream."""
+        goes to the side stream (after a fork) and co-runs with the dgrad chain;
+        DVAE_CONV_WGRAD_MAIN=1 keeps it on the current stream."""
         if _CONV_WGRAD_MAIN:
             call(fn, *args, ptr(self._ws), _stream())
             return
-        record_py(self._side.wait_stream, torch.cuda.current_stream())
+        if fork:
+            self.fork_side()
         call(fn, *args, ptr(self._ws_side), self._side.cuda_stream)
 
     def _join_side(self):
@@ -258,7 +268,7 @@ class VAEEngine:
                  ptr(coef), ptr(partials), B, HID, h, h, c, s)
 
     # ------------------------------------------------------------------ backward
-    def decode_backward(self, z, buf, n=None):
+    def decode_backward(self, z, buf, n=None, join=True):
         """buf.g_logit (grad w.r.t. the pre-sigmoid output) -> decoder weight grads, buf.dz."""
         s = _stream()
         B = z.shape[0] if n is None else n
@@ -271,25 +281,35 @@ class VAEEngine:
         couts = [HID] * len(self.dec_names) + [c]
         hs = [4 << i for i in range(len(names))]  # input H of each convT
         dy, dy_layout = buf.g_logit, NCHW
+        deferred = []                            # weight gradients of the small layers: launched after ONE fork
         for k in range(len(names) - 1, -1, -1):
             name, x_in, gx, h = names[k], acts[k], gacts[k], hs[k]
-            self._conv_wgrad("dvae_convT4s2_wgrad", ptr(x_in), NHWC, ptr(dy), dy_layout,
-                             ptr(self.g("decoder.%s.weight" % name)), ptr(self.g("decoder.%s.bias" % name)),
-                             B, HID, h, h, couts[k])
+            wargs = ("dvae_convT4s2_wgrad", ptr(x_in), NHWC, ptr(dy), dy_layout,
+                     ptr(self.g("decoder.%s.weight" % name)), ptr(self.g("decoder.%s.bias" % name)),
+                     B, HID, h, h, couts[k])
+            if h >= 16:                          # the two big layers fork right away and co-run with their dgrad
+                self._conv_wgrad(*wargs)
+            else:
+                deferred.append(wargs)
             call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(x_in), ptr(gx),
                  NHWC, B, HID, h, h, couts[k], s)
             dy, dy_layout = gx, NHWC
         call("dvae_relayout", ptr(buf.gd3n), NHWC, ptr(buf.gd3), B, HID, 4, 4, s)
-        self._side_wgrad(buf.d2, buf.gd3, self.g("decoder.lin3.weight"), self.g("decoder.lin3.bias"), B, HIDDEN_DIM, HID * 16)
         call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
              B, HIDDEN_DIM, HID * 16, ws, s)
-        self._side_wgrad(buf.d1, buf.gd2, self.g("decoder.lin2.weight"), self.g("decoder.lin2.bias"), B, HIDDEN_DIM, HIDDEN_DIM)
         call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
              B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
-        self._side_wgrad(z, buf.gd1, self.g("decoder.lin1.weight"), self.g("decoder.lin1.bias"), B, D, HIDDEN_DIM)
         call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
              B, D, HIDDEN_DIM, ws, s)
-        self._join_side()
+        # small conv layers + the three FC weight gradients: one fork, then they co-run with whatever follows
+        self.fork_side()
+        for wargs in deferred:
+            self._conv_wgrad(*wargs, fork=False)
+        self._side_wgrad(buf.d2, buf.gd3, self.g("decoder.lin3.weight"), self.g("decoder.lin3.bias"), B, HIDDEN_DIM, HID * 16)
+        self._side_wgrad(buf.d1, buf.gd2, self.g("decoder.lin2.weight"), self.g("decoder.lin2.bias"), B, HIDDEN_DIM, HIDDEN_DIM)
+        self._side_wgrad(z, buf.gd1, self.g("decoder.lin1.weight"), self.g("decoder.lin1.bias"), B, D, HIDDEN_DIM)
+        if join:
+            self._join_side()
 
     def encode_backward(self, x, buf, n=None):
         """buf.dml (grad w.r.t. the interleaved mu/logvar output) -> encoder weight grads."""
@@ -297,17 +317,22 @@ class VAEEngine:
         B = x.shape[0] if n is None else n
         c, H, _ = self.img_size
         ws = ptr(self._ws)
-        self._side_wgrad(buf.h2, buf.dml, self.g("encoder.mu_logvar_gen.weight"), self.g("encoder.mu_logvar_gen.bias"), B, HIDDEN_DIM, 2 * self.latent_dim)
         call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
              ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
-        self._side_wgrad(buf.h1, buf.gh2, self.g("encoder.lin2.weight"), self.g("encoder.lin2.bias"), B, HIDDEN_DIM, HIDDEN_DIM)
         call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
              B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
-        self._side_wgrad(buf.a_flat, buf.gh1, self.g("encoder.lin1.weight"), self.g("encoder.lin1.bias"), B, HID * 16, HIDDEN_DIM)
         call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
              ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, ws, s)
+        # weight gradients wait for the next fork (they only have to be done by the end of the backward pass)
+        deferred = [lambda: self._side_wgrad(buf.h2, buf.dml, self.g("encoder.mu_logvar_gen.weight"),
+                                             self.g("encoder.mu_logvar_gen.bias"), B, HIDDEN_DIM, 2 * self.latent_dim),
+                    lambda: self._side_wgrad(buf.h1, buf.gh2, self.g("encoder.lin2.weight"), self.g("encoder.lin2.bias"),
+                                             B, HIDDEN_DIM, HIDDEN_DIM),
+                    lambda: self._side_wgrad(buf.a_flat, buf.gh1, self.g("encoder.lin1.weight"), self.g("encoder.lin1.bias"),
+                                             B, HID * 16, HIDDEN_DIM)]
         last = len(self.enc_names) - 1
         call("dvae_relayout", ptr(buf.ga_flat), NCHW, ptr(buf.enc_gact[last]), B, HID, 4, 4, s)
+        forked = False
         for k in range(last, -1, -1):
             name = self.enc_names[k]
             h_in = self.enc_sizes[k] * 2
@@ -316,10 +341,28 @@ class VAEEngine:
             else:
                 x_in, x_layout, cin = x, NCHW, c
             dy = buf.enc_gact[k]
-            self._conv_wgrad("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), NHWC,
-                             ptr(self.g("encoder.%s.weight" % name)), ptr(self.g("encoder.%s.bias" % name)),
-                             B, cin, h_in, h_in, HID)
+            # forks: one before the first big layer (h_in >= 32; the small layers' weight gradients ride
+            # along with it), one per big layer after that
+            big = h_in >= 32
+            if big and deferred:
+                self.fork_side()
+                for launch in deferred:
+                    launch()
+                deferred = []
+                forked = True
+            wargs = ("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), NHWC,
+                     ptr(self.g("encoder.%s.weight" % name)), ptr(self.g("encoder.%s.bias" % name)),
+                     B, cin, h_in, h_in, HID)
+            if big:
+                self._conv_wgrad(*wargs, fork=not forked)
+                forked = False
+            else:
+                deferred.append(lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False))
             if k > 0:
                 call("dvae_conv4s2_dgrad", ptr(dy), NHWC, ptr(self.p("encoder.%s.weight" % name)), ptr(x_in),
                      ptr(buf.enc_gact[k - 1]), NHWC, B, cin, h_in, h_in, HID, s)
+        if deferred:
+            self.fork_side()
+            for launch in deferred:
+                launch()
         self._join_side()

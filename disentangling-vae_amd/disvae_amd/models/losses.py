@@ -362,34 +362,41 @@ class _SingleOptimizerLoss(BaseLoss):
             eps = None
         eng.encode(data, buf)
         eng.reparam(buf, eps, sc.kl_dim, sc.coef)
+        rowstats = None
+        dz_x = dmu_x = dlv_x = None
+        if self.KIND == _lib.LOSS_BTCVAE:
+            # the B x B estimator (forward AND backward: it needs z, mu, logvar and the coefficients only)
+            # runs on the side stream while the decoder forward occupies the current one
+            eng.fork_side()
+            with torch.cuda.stream(eng.side_stream):
+                ss = _stream()
+                zg, mug, lvg = buf.z, buf.mu, buf.logvar
+                if world > 1:
+                    zg, mug, lvg = self.comm.all_gather_latents(buf.z, buf.mu, buf.logvar)
+                rowstats = sc.latent("rowstats", B, 16)
+                tc_tmp = sc.latent("tc_tmp", 3 * D, Bg)
+                call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Bg, D, rank * B, B, int(self.is_mss), ptr(sc.log_w),
+                     ptr(tc_tmp), ptr(rowstats), ss)
+                if is_train:
+                    dz_x = sc.latent("dz_tc", B, D)
+                    dmu_all, dlv_all = sc.latent("dmu_all", Bg, D), sc.latent("dlv_all", Bg, D)
+                    call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Bg, D, rank * B, B,
+                         int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(tc_tmp), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), ss)
+                    if world > 1:
+                        dmu_x, dlv_x = self.comm.reduce_scatter_cols(dmu_all, dlv_all)
+                    else:
+                        dmu_x, dlv_x = dmu_all, dlv_all
         # decoder; its last layer also evaluates the reconstruction likelihood and dL/dlogit
         eng.decode(buf.z, buf, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
-        rowstats = None
         if self.KIND == _lib.LOSS_BTCVAE:
-            zg, mug, lvg = buf.z, buf.mu, buf.logvar
-            if world > 1:
-                zg, mug, lvg = self.comm.all_gather_latents(buf.z, buf.mu, buf.logvar)
-            rowstats = sc.latent("rowstats", B, 16)
-            tc_tmp = sc.latent("tc_tmp", 3 * D, Bg)
-            call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Bg, D, rank * B, B, int(self.is_mss), ptr(sc.log_w),
-                 ptr(tc_tmp), ptr(rowstats), s)
+            eng._join_side()
         call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
         if world > 1:
             self.comm.all_reduce(sc.packed)
         call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), s)
         if not is_train:
             return
-        dz_x = dmu_x = dlv_x = None
-        if self.KIND == _lib.LOSS_BTCVAE:
-            dz_x = sc.latent("dz_tc", B, D)
-            dmu_all, dlv_all = sc.latent("dmu_all", Bg, D), sc.latent("dlv_all", Bg, D)
-            call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Bg, D, rank * B, B,
-                 int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(tc_tmp), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), s)
-            if world > 1:
-                dmu_x, dlv_x = self.comm.reduce_scatter_cols(dmu_all, dlv_all)
-            else:
-                dmu_x, dlv_x = dmu_all, dlv_all
-        eng.decode_backward(buf.z, buf)
+        eng.decode_backward(buf.z, buf, join=world > 1)     # single process: one join, at the end of the backward pass
         pending = []
         if world > 1:      # decoder gradients are final: their all-reduce overlaps the encoder backward
             pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
@@ -578,7 +585,7 @@ class FactorKLoss(BaseLoss):
         dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
         # tc term of vae_loss through D: dgrad only, first half (its disc weight grads are zeroed at :303)
         dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2")
-        eng.decode_backward(buf.z, buf, n=Bh)
+        eng.decode_backward(buf.z, buf, n=Bh, join=False)   # joined at the end of encode_backward
         call("dvae_add", ptr(buf.dz), ptr(dz_a), ptr(buf.dz), Bh * D, s)      # quirk Q1
         call("dvae_add", ptr(buf.dz), ptr(dz_b), ptr(buf.dz), Bh * D, s)
         call("dvae_reparam_kl_bwd", ptr(buf.dz), None, None, ptr(buf.mu), ptr(buf.logvar), ptr(eps1), ptr(sc.scal),

@@ -65,6 +65,9 @@ def _compare_grads(model, ref_grads, what, first=True):
     ("betaH", (3, 64, 64), 5, "gaussian"), ("betaH", (1, 64, 64), 4, "laplace"),
     ("btcvae", (1, 64, 64), 16, "bernoulli"), ("btcvae", (3, 64, 64), 12, "bernoulli"),
     ("btcvae", (3, 64, 64), 70, "bernoulli"),
+    # ragged / minimal batches (below one MFMA tile, odd, straddling a 32-row tile)
+    ("btcvae", (3, 64, 64), 3, "bernoulli"), ("btcvae", (1, 64, 64), 33, "bernoulli"),
+    ("btcvae", (3, 64, 64), 2, "bernoulli"), ("VAE", (3, 32, 32), 7, "bernoulli"),
 ])
 def test_fused_step_vs_oracle(loss, img, B, rec_dist):
     seed, n_data, lr = 1234, 202599, 5e-4
@@ -117,7 +120,7 @@ def test_fused_step_vs_oracle(loss, img, B, rec_dist):
     assert loss_f.n_train_steps == 3
 
 
-@pytest.mark.parametrize("img,B", [((1, 64, 64), 8), ((3, 64, 64), 20), ((1, 32, 32), 6)])
+@pytest.mark.parametrize("img,B", [((1, 64, 64), 8), ((3, 64, 64), 20), ((1, 32, 32), 6), ((3, 64, 64), 6), ((1, 64, 64), 2)])
 def test_factor_step_vs_oracle(img, B):
     seed, n_data, lr = 1234, 737280, 1e-4
     model, opt, loss_f = _native("factor", img, seed, n_data, lr)
