@@ -281,19 +281,26 @@ class VAEEngine:
         couts = [HID] * len(self.dec_names) + [c]
         hs = [4 << i for i in range(len(names))]  # input H of each convT
         dy, dy_layout = buf.g_logit, NCHW
-        deferred = []                            # weight gradients of the small layers: launched after ONE fork
+        # Weight gradients are off the critical path and only due at the end of the backward pass.  The
+        # dgrads of the two big layers (convT3, convT2) fill the chip by themselves; everything after them
+        # on this stream is small (8x8 / 4x4 layers, the FC chain, the latent glue, the encoder's FC chain)
+        # and leaves most CUs idle -- so the big weight gradients are forked THERE (fork 1, after the last
+        # big dgrad), and the rest after the FC dgrads (fork 2).  Every fork costs this stream ~6 us.
+        pending, deferred = [], []
         for k in range(len(names) - 1, -1, -1):
             name, x_in, gx, h = names[k], acts[k], gacts[k], hs[k]
             wargs = ("dvae_convT4s2_wgrad", ptr(x_in), NHWC, ptr(dy), dy_layout,
                      ptr(self.g("decoder.%s.weight" % name)), ptr(self.g("decoder.%s.bias" % name)),
                      B, HID, h, h, couts[k])
-            if h >= 16:                          # the two big layers fork right away and co-run with their dgrad
-                self._conv_wgrad(*wargs)
-            else:
-                deferred.append(wargs)
+            (pending if h >= 16 else deferred).append(wargs)
             call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(x_in), ptr(gx),
                  NHWC, B, HID, h, h, couts[k], s)
             dy, dy_layout = gx, NHWC
+            if h == 16 or (k == 0 and pending):  # last big dgrad is enqueued: its inputs and those of `pending` are final
+                self.fork_side()
+                for w_ in pending:
+                    self._conv_wgrad(*w_, fork=False)
+                pending = []
         call("dvae_relayout", ptr(buf.gd3n), NHWC, ptr(buf.gd3), B, HID, 4, 4, s)
         call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
              B, HIDDEN_DIM, HID * 16, ws, s)
