@@ -873,6 +873,7 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
                           float* ws, hipStream_t s) {
   using G = Geo<HS>;
   const int n_units = units_for(N, HS);
+  // (capping the persistent grid to leave CUs to the dgrad stream was measured: 128 -> +10 % step time)
   const int grid = n_units < WG_MAX_BLOCKS ? n_units : WG_MAX_BLOCKS;
   const size_t lds = (G::BIG_FLOATS + 64 * 32) * sizeof(float);
   static bool attr = false;

@@ -8,6 +8,7 @@
 //              kernel, one thread per small pixel producing its 2x2xC outputs, weights are
 //              wave-uniform (scalar loads -> SGPR operands), inputs staged in swizzled LDS.
 //   wgrad_thin (conv1 / convT3 wgrad): M = 32 cs, N = 16*C (cb,tap) columns, K = pixels.
+#include <stdlib.h>
 #include "common.h"
 
 namespace dvae {

@@ -394,6 +394,121 @@ static bool try_fc32(const float* a, long lda, const float* b, long ldb, float* 
   return true;
 }
 
+// ---- FC weight gradient with the contraction (the batch) streamed through LDS in slabs of KP rows ----
+//   dw[n][k] = sum_m dy[m][n] x[m][k],   db[n] = sum_m dy[m][n]
+// Same tile / wave split / contraction permutation as k_fc32, but BOTH operands are contraction-slow
+// ([m][32 columns], 16-byte loads along the columns, skewed [kappa][32] LDS image read with conflict-free
+// ds_read_b32) and the accumulators persist over M/KP slabs; the next slab's global loads are issued
+// before the MFMA phase of the current one.  One launch, no partial tiles, no reduce kernel: the VAE's FC
+// weight gradients are latency-bound side-stream work and every launch there delays the big conv weight
+// gradients queued behind it.
+template <int KP>
+__global__ __launch_bounds__(256) void k_fcw32(const float* __restrict__ dy, const float* __restrict__ x,
+                                               float* __restrict__ dw, float* __restrict__ db, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) float fc_lds[];
+  constexpr int S = KP / 8;                // MFMA steps per wave and lane half per slab
+  constexpr int NB = KP / 32;              // 16-byte loads per thread and operand per slab
+  constexpr int ROWS = KP + 8;             // skewed rows: one spare row after every S rows
+  float* As = fc_lds;                      // [ROWS][32]  A(i = n, kappa = m)
+  float* Bs = fc_lds + ROWS * 32;          // [ROWS][32]  B(kappa = m, j = k)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int j4 = (tid & 7) * 4;
+  const bool okA = n0 + j4 < N, okB = k0 + j4 < K;             // N % 4 == K % 4 == 0
+  const float* pa = dy + (okA ? n0 + j4 : 0);
+  const float* pb = x + (okB ? k0 + j4 : 0);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+  float rs = 0.f;
+  f32x4 ra[NB], rb[NB];
+  auto load = [&](int m0) {
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const int m = m0 + (tid >> 3) + 32 * p;
+      const long mm = m < M ? m : M - 1;
+      const f32x4 va = *reinterpret_cast<const f32x4*>(pa + mm * N);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + mm * K);
+      ra[p] = (m < M && okA) ? va : f32x4{0.f, 0.f, 0.f, 0.f};
+      rb[p] = (m < M && okB) ? vb : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  const int kap0 = (2 * wv + h) * S;
+  const float* ap = As + (kap0 + 2 * wv + h) * 32 + i;
+  const float* bp = Bs + (kap0 + 2 * wv + h) * 32 + i;
+  load(0);
+  for (int m0 = 0; m0 < M; m0 += KP) {
+    if (m0) __syncthreads();                          // the previous slab's operand reads are done
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const int kap = (tid >> 3) + 32 * p;
+      *reinterpret_cast<f32x4*>(As + (kap + kap / S) * 32 + j4) = ra[p];
+      *reinterpret_cast<f32x4*>(Bs + (kap + kap / S) * 32 + j4) = rb[p];
+    }
+    __syncthreads();
+    if (m0 + KP < M) load(m0 + KP);
+#pragma unroll
+    for (int t = 0; t < S; t += 4) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { av[u] = ap[(t + u) * 32]; bv[u] = bp[(t + u) * 32]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[u], 0, 0, 0);
+        rs += av[u];
+      }
+    }
+  }
+  const f32x16 accs = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  float* red = fc_lds;                                // [4 waves][16 regs][64 lanes] + [4][32] row sums
+  float* rsum = fc_lds + 4 * 16 * 64;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[(wv * 16 + e) * 64 + lane] = accs[e];
+  rs += __shfl_xor(rs, 32, 64);
+  if (h == 0) rsum[wv * 32 + i] = rs;
+  __syncthreads();
+  const int col = k0 + i;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = 4 * wv + u;
+    const int row = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    const float v = (red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane]) +
+                    (red[(2 * 16 + e) * 64 + lane] + red[(3 * 16 + e) * 64 + lane]);
+    if (row < N && col < K) dw[(long)row * K + col] = v;
+  }
+  if (db && blockIdx.x == 0 && wv == 0 && h == 0 && n0 + i < N)
+    db[n0 + i] = (rsum[i] + rsum[32 + i]) + (rsum[64 + i] + rsum[96 + i]);
+}
+
+static bool try_fcw32(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, hipStream_t s) {
+  static const bool off = getenv("DVAE_GEMM_FC") && getenv("DVAE_GEMM_FC")[0] == '0';
+  if (off || N % 4 || K % 4 || M > 4096) return false;
+  if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return false;
+  if ((long)((N + 63) / 64) * ((K + 63) / 64) >= 512) return false;     // big outputs: 64x64 tiles + split contraction
+  const dim3 grid((K + 31) / 32, (N + 31) / 32);
+  if (M <= 64) {
+    constexpr int KP = 64;
+    const size_t lds = sizeof(float) * 2 * (KP + 8) * 32;               // operand tiles; the reduction image (4224 floats) fits
+    hipLaunchKernelGGL((k_fcw32<KP>), grid, dim3(256), lds, s, dy, x, dw, db, M, N, K);
+  } else {
+    constexpr int KP = 256;
+    const size_t lds = sizeof(float) * 2 * (KP + 8) * 32;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)k_fcw32<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((k_fcw32<KP>), grid, dim3(256), lds, s, dy, x, dw, db, M, N, K);
+  }
+  return true;
+}
+
 // small problems (everything in the VAE) go to k_gemm32; large ones (discriminator) to k_gemm
 // measured (profiles/r01_run12): k_gemm32 wins only for the forward form with 16-byte loads on both
 // operands (11.2 vs 13.3 us at 1024x512x256); the lane-contiguous dgrad / wgrad forms are slower than the
@@ -534,6 +649,10 @@ int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, i
                         size_t ws_floats, hipStream_t s) {
   // dw[N,K] = dy^T[N,M] x[M,K]: contraction length M (the batch); db[n] = sum_m dy[m][n] = row sums of A.
   // Few output tiles + a long contraction: split the batch over gridDim.z and reduce (fixed order).
+  if (try_fcw32(x, dy, dw, db, M, K, N, s)) {
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
   if (use_small(N, K, M, false)) {
     // A(i=n, k=m) = dy[m*N + n], B(k=m, j) = x[m*K + j]: both lane-contiguous, contraction over the batch
     hipLaunchKernelGGL((k_gemm32<false, false>), grid32(N, K), dim3(256), 0, s, dy, 1L, (long)N, x, (long)K, 1L, dw,

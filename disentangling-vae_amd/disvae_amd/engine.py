@@ -286,7 +286,7 @@ class VAEEngine:
         # on this stream is small (8x8 / 4x4 layers, the FC chain, the latent glue, the encoder's FC chain)
         # and leaves most CUs idle -- so the big weight gradients are forked THERE (fork 1, after the last
         # big dgrad), and the rest after the FC dgrads (fork 2).  Every fork costs this stream ~6 us.
-        pending, deferred = [], []
+        pending, deferred, queued = [], [], []
         for k in range(len(names) - 1, -1, -1):
             name, x_in, gx, h = names[k], acts[k], gacts[k], hs[k]
             wargs = ("dvae_convT4s2_wgrad", ptr(x_in), NHWC, ptr(dy), dy_layout,
@@ -296,12 +296,15 @@ class VAEEngine:
             call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(x_in), ptr(gx),
                  NHWC, B, HID, h, h, couts[k], s)
             dy, dy_layout = gx, NHWC
+            for w_ in queued:                    # side launches of the previous fork, issued AFTER this stream's next kernel
+                self._conv_wgrad(*w_, fork=False)
+            queued = []
             if h == 16 or (k == 0 and pending):  # last big dgrad is enqueued: its inputs and those of `pending` are final
                 self.fork_side()
-                for w_ in pending:
-                    self._conv_wgrad(*w_, fork=False)
-                pending = []
+                queued, pending = pending, []
         call("dvae_relayout", ptr(buf.gd3n), NHWC, ptr(buf.gd3), B, HID, 4, 4, s)
+        for w_ in queued:
+            self._conv_wgrad(*w_, fork=False)
         call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
              B, HIDDEN_DIM, HID * 16, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
@@ -339,7 +342,6 @@ class VAEEngine:
                                              B, HID * 16, HIDDEN_DIM)]
         last = len(self.enc_names) - 1
         call("dvae_relayout", ptr(buf.ga_flat), NCHW, ptr(buf.enc_gact[last]), B, HID, 4, 4, s)
-        forked = False
         for k in range(last, -1, -1):
             name = self.enc_names[k]
             h_in = self.enc_sizes[k] * 2
@@ -351,23 +353,27 @@ class VAEEngine:
             # forks: one before the first big layer (h_in >= 32; the small layers' weight gradients ride
             # along with it), one per big layer after that
             big = h_in >= 32
-            if big and deferred:
-                self.fork_side()
-                for launch in deferred:
-                    launch()
-                deferred = []
-                forked = True
             wargs = ("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), NHWC,
                      ptr(self.g("encoder.%s.weight" % name)), ptr(self.g("encoder.%s.bias" % name)),
                      B, cin, h_in, h_in, HID)
-            if big:
-                self._conv_wgrad(*wargs, fork=not forked)
-                forked = False
+            side = []
+            if k == 0:
+                # the first layer has no dgrad: this stream has nothing else left, so it computes the last
+                # weight gradient itself (no fork) while the side stream drains its queue
+                if deferred:
+                    self.fork_side()
+                    side, deferred = deferred, []
+                call(wargs[0], *wargs[1:], ptr(self._ws), s)
+            elif big:
+                self.fork_side()
+                side, deferred = deferred + [lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False)], []
             else:
                 deferred.append(lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False))
-            if k > 0:
+            if k > 0:                            # this stream's next kernel first, then the side launches
                 call("dvae_conv4s2_dgrad", ptr(dy), NHWC, ptr(self.p("encoder.%s.weight" % name)), ptr(x_in),
                      ptr(buf.enc_gact[k - 1]), NHWC, B, cin, h_in, h_in, HID, s)
+            for launch in side:
+                launch()
         if deferred:
             self.fork_side()
             for launch in deferred:
