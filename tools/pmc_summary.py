@@ -44,9 +44,10 @@ def main(root):
         f, w = v.get("FETCH_SIZE", float("nan")), v.get("WRITE_SIZE", float("nan"))
         gui = v.get("GRBM_GUI_ACTIVE", float("nan"))
         mf = v.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan"))
-        # SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs (1024): utilisation = busy / (gui * 1024)
+        # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (check:
+        # k_down32ws<16> 92.7 us x 2.4 GHz = 2.2e5 cycles vs GUI 1.76e6): utilisation = busy / (gui / 8 * 1024)
         print("| %s | " % k + " | ".join("%.3g" % v.get(c, float("nan")) for c in cols) +
-              " | %.1f | %.1f | %.3f |" % (2 * f * 1024 / 1e6, w * 1024 / 1e6, mf / (gui * 1024) if gui else float("nan")))
+              " | %.1f | %.1f | %.3f |" % (2 * f * 1024 / 1e6, w * 1024 / 1e6, mf / (gui / 8 * 1024) if gui else float("nan")))
 
 
 if __name__ == "__main__":
