@@ -44,7 +44,7 @@ def flops_per_image_train(C):
 
 
 # HBM traffic of ONE launch of the dominant kernel at B = 1024, from rocprofv3 PMC passes over this
-# same command (profiles/r01_run6_pmc_summary.md): FETCH_SIZE 7.81e4 KiB (x2: the gfx950 counter
+# same command (profiles/r01_run31_pmc_summary.md): FETCH_SIZE 7.81e4 KiB (x2: the gfx950 counter
 # reports half of a wide coalesced streaming read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
 # 3.28e4 KiB = 160.0 MB + 33.6 MB.  Algorithmic bytes: 134.2 MB in + 33.6 MB out (the extra 19 % of
 # reads are the 2-row halos of the 64-pixel units).
@@ -54,7 +54,7 @@ PMC_TRAFFIC_BYTES_B1024 = 2 * 7.81e4 * 1024 + 3.28e4 * 1024
 def dominant_kernel_roofline(B, device):
     """HIP-event timing of the dominant kernel of the step -- k_down32ws<16>: the 32->32 channel,
     32x32 -> 16x16 'down' MFMA kernel that runs conv2 forward and the convT2 dgrad (largest
-    share of GPU time in profiles/r01_run9_kernel_stats.md) -- launched through the C-ABI on the
+    share of GPU time in profiles/r01_run31_kernel_stats.md) -- launched through the C-ABI on the
     stream the engine uses (torch's current stream)."""
     from disvae_amd import _lib
     from disvae_amd._lib import call, ptr

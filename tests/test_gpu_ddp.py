@@ -37,7 +37,7 @@ def _make(loss, lr):
     return model, opt, loss_f
 
 
-def _worker(rank, world, port, loss, q):
+def _worker(rank, world, port, loss, q, backend="gloo"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import sys
@@ -45,7 +45,7 @@ def _worker(rank, world, port, loss, q):
         for p in (root, os.path.join(root, "disentangling-vae_amd"), os.path.join(root, "tests")):
             sys.path.insert(0, p)
         from disvae_amd import parallel
-        parallel.init_process_group_from_env("gloo")
+        parallel.init_process_group_from_env(backend)
         torch.cuda.set_device(0)
         lr = 1e-4 if loss == "factor" else 5e-4
         Bl = 12
@@ -114,3 +114,17 @@ def test_sharded_step_matches_global_batch(loss):
         p_.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+@pytest.mark.parametrize("loss", ["btcvae", "factor"])
+def test_rccl_call_sites_single_rank(loss):
+    """backend "nccl" (= RCCL) with ONE rank on the one GPU of the test box: the same collectives'
+    call sites as on 8 GPUs (broadcast, list all_gather, sum all_reduce, async bucket all_reduce under
+    the side-stream context) run through RCCL itself; results must equal the communicator-free step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_worker, args=(0, 1, _free_port(), loss, q, "nccl"))
+    p_.start()
+    rank, msg = q.get(timeout=280)
+    p_.join(timeout=60)
+    assert msg == "ok", msg
