@@ -159,15 +159,15 @@ int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int
 
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                         const float* coef, int B, int D, void* stream) {
-  DVAE_CHECK_ARG(ml && mu && logvar && z && B > 0 && D > 0 && D <= 16 && (kl_dim == nullptr || coef != nullptr));
+  DVAE_CHECK_ARG(ml && mu && logvar && z && B > 0 && D > 0 && D <= 16);    // kl_dim without coef: partials only
   return launch_reparam_kl_fwd(ml, eps, mu, logvar, z, kl_dim, coef, B, D, (hipStream_t)stream);
 }
 
-int dvae_reparam_kl_bwd(const float* dz, const float* dmu_x, const float* dlv_x, const float* mu, const float* logvar,
-                        const float* eps, const float* scal, const float* coef, float* dml, int B, int D,
-                        void* stream) {
+int dvae_reparam_kl_bwd(const float* dz, const float* dz2, const float* dz3, const float* dmu_x, const float* dlv_x,
+                        const float* mu, const float* logvar, const float* eps, const float* scal, const float* coef,
+                        float* dml, int B, int D, void* stream) {
   DVAE_CHECK_ARG(mu && logvar && scal && coef && dml && B > 0 && D > 0);
-  return launch_reparam_kl_bwd(dz, dmu_x, dlv_x, mu, logvar, eps, scal, coef, dml, B, D, (hipStream_t)stream);
+  return launch_reparam_kl_bwd(dz, dz2, dz3, dmu_x, dlv_x, mu, logvar, eps, scal, coef, dml, B, D, (hipStream_t)stream);
 }
 
 int dvae_recon_loss(const float* recon, const float* target, long n, int dist, const float* coef, float* partials,
@@ -213,6 +213,15 @@ int dvae_loss_pack(const float* rec_partials, const float* kl_dim, int D, const 
                    const float* disc_sums, float* packed, void* stream) {
   DVAE_CHECK_ARG(rec_partials && packed && D >= 0 && D <= 16);
   return launch_loss_pack(rec_partials, kl_dim, D, rowstats, Bl, disc_sums, packed, (hipStream_t)stream);
+}
+
+int dvae_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_rows, int D, const float* rowstats,
+                       int Bl, const float* disc_sums, int Bg, const float* coef, float* packed, float* scal,
+                       void* stream) {
+  DVAE_CHECK_ARG(rec_partials && packed && coef && D >= 0 && D <= 16 && Bl >= 0 && Bg > 0 && kl_rows >= 0);
+  DVAE_CHECK_ARG(kind >= DVAE_LOSS_BETAH && kind <= DVAE_LOSS_FACTOR);
+  return launch_loss_epilogue(kind, rec_partials, kl_dim, kl_rows, D, rowstats, Bl, disc_sums, Bg, coef, packed, scal,
+                              (hipStream_t)stream);
 }
 
 int dvae_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal, void* stream) {

@@ -130,7 +130,7 @@ int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, i
 
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                           const float* coef, int B, int D, hipStream_t s);
-int launch_reparam_kl_bwd(const float* dz, const float* dmu_x, const float* dlv_x, const float* mu, const float* logvar,
+int launch_reparam_kl_bwd(const float* dz, const float* dz2, const float* dz3, const float* dmu_x, const float* dlv_x, const float* mu, const float* logvar,
                           const float* eps, const float* scal, const float* coef, float* dml, int B, int D,
                           hipStream_t s);
 int launch_recon_loss(const float* recon, const float* target, long n, int dist, const float* coef, float* partials,
@@ -147,6 +147,9 @@ int launch_disc_losses(const float* lg, int Bh, const float* coef, float* sums, 
 int launch_loss_pack(const float* rec_partials, const float* kl_dim, int D, const float* rowstats, int Bl,
                      const float* disc_sums, float* packed, hipStream_t s);
 int launch_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal, hipStream_t s);
+int launch_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_rows, int D, const float* rowstats,
+                         int Bl, const float* disc_sums, int Bg, const float* coef, float* packed, float* scal,
+                         hipStream_t s);
 int launch_set_coef(float* coef, const float* v, hipStream_t s);
 int launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);
 

@@ -238,7 +238,10 @@ __global__ __launch_bounds__(256) void k_gemm32(const float* __restrict__ a, lon
 // fixed order, every wave finishing 4 of the 16 accumulator rows (bias / activation / mask fused).
 //   A(i,k) = a[i*lda + k];  B_JFAST ? B(k,j) = b[k*ldb + j] (dgrad)  :  B(k,j) = b[j*ldb + k] (forward)
 // KP = Kc rounded up to a power of two in [32,512] (the tail is zero-filled in LDS).
-template <int KP, bool B_JFAST>
+// SC (scalar staging for rows that are not 16-byte aligned, i.e. the 10-wide latent side of decoder lin1):
+//   0 = 16-byte loads for both operands; 1 = 4-byte loads for A and B (forward, Kc = 10);
+//   2 = 4-byte loads for B only (dgrad whose OUTPUT is 10 wide: B rows are 10 floats).
+template <int KP, bool B_JFAST, int SC>
 __global__ __launch_bounds__(256) void k_fc32(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
                                               float* __restrict__ c, long ldc, int M, int N, int Kc,
                                               const float* __restrict__ bias, int act,
@@ -264,9 +267,17 @@ __global__ __launch_bounds__(256) void k_fc32(const float* __restrict__ a, long 
     const int idx = tid + 256 * p;
     const int row = idx / KQ, c4 = (idx % KQ) * 4;
     const int gi = m0 + row;
-    const bool ok = gi < M && c4 < Kc;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(a + (long)(gi < M ? gi : M - 1) * lda + (c4 < Kc ? c4 : 0));
-    ra[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* src = a + (long)(gi < M ? gi : M - 1) * lda;
+    if (SC == 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v = src[c4 + u < Kc ? c4 + u : 0];
+        ra[p][u] = (gi < M && c4 + u < Kc) ? v : 0.f;
+      }
+    } else {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + (c4 < Kc ? c4 : 0));
+      ra[p] = (gi < M && c4 < Kc) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   if (!B_JFAST) {
 #pragma unroll
@@ -274,9 +285,17 @@ __global__ __launch_bounds__(256) void k_fc32(const float* __restrict__ a, long 
       const int idx = tid + 256 * p;
       const int row = idx / KQ, c4 = (idx % KQ) * 4;
       const int gj = n0 + row;
-      const bool ok = gj < N && c4 < Kc;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(b + (long)(gj < N ? gj : N - 1) * ldb + (c4 < Kc ? c4 : 0));
-      rb[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* src = b + (long)(gj < N ? gj : N - 1) * ldb;
+      if (SC == 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float v = src[c4 + u < Kc ? c4 + u : 0];
+          rb[p][u] = (gj < N && c4 + u < Kc) ? v : 0.f;
+        }
+      } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (c4 < Kc ? c4 : 0));
+        rb[p] = (gj < N && c4 < Kc) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   } else {
 #pragma unroll
@@ -284,9 +303,18 @@ __global__ __launch_bounds__(256) void k_fc32(const float* __restrict__ a, long 
       const int idx = tid + 256 * p;
       const int kap = idx >> 3, j4 = (idx & 7) * 4;
       const int gj = n0 + j4;
-      const bool ok = kap < Kc && gj < N;                      // N % 4 == 0: a chunk is entirely in or out
-      const f32x4 v = *reinterpret_cast<const f32x4*>(b + (long)(kap < Kc ? kap : 0) * ldb + (gj < N ? gj : 0));
-      rb[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* src = b + (long)(kap < Kc ? kap : 0) * ldb;
+      if (SC == 2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float v = src[gj + u < N ? gj + u : 0];
+          rb[p][u] = (kap < Kc && gj + u < N) ? v : 0.f;
+        }
+      } else {
+        const bool ok = kap < Kc && gj < N;                    // N % 4 == 0: a chunk is entirely in or out
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (gj < N ? gj : 0));
+        rb[p] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
 #pragma unroll
@@ -362,17 +390,17 @@ __global__ __launch_bounds__(256) void k_fc32(const float* __restrict__ a, long 
   }
 }
 
-template <int KP, bool BJ>
+template <int KP, bool BJ, int SC>
 static void launch_fc32_t(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
                           const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
   size_t lds = (size_t)(32 * (KP + 4) + (BJ ? (KP + 8) * 32 : 32 * (KP + 4))) * sizeof(float);
   if (lds < 4 * 16 * 64 * sizeof(float)) lds = 4 * 16 * 64 * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_fc32<KP, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_fc32<KP, BJ, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((k_fc32<KP, BJ>), dim3((N + 31) / 32, (M + 31) / 32), dim3(256), lds, s, a, lda, b, ldb, c, ldc, M, N,
+  hipLaunchKernelGGL((k_fc32<KP, BJ, SC>), dim3((N + 31) / 32, (M + 31) / 32), dim3(256), lds, s, a, lda, b, ldb, c, ldc, M, N,
                      Kc, bias, act, mask, mask_act);
 }
 
@@ -381,10 +409,21 @@ template <bool BJ>
 static bool try_fc32(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
                      const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
   static const bool off = getenv("DVAE_GEMM_FC") && getenv("DVAE_GEMM_FC")[0] == '0';
-  if (off || Kc > 512 || Kc % 4 || lda % 4 || ldb % 4 || (BJ && N % 4)) return false;
-  if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return false;
+  if (off || Kc > 512) return false;
   if ((long)((M + 63) / 64) * ((N + 63) / 64) >= 512) return false;      // big outputs: the 64x64-tile kernel
-#define DVAE_FC_CASE(KP) launch_fc32_t<KP, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s)
+  const bool al = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+  if (!BJ && Kc <= 32 && (Kc % 4 || lda % 4 || ldb % 4 || !al)) {          // forward with a short unaligned contraction
+    launch_fc32_t<32, false, 1>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
+    return true;
+  }
+  if (Kc % 4 || lda % 4 || !al) return false;
+  const bool scb = BJ && (N % 4 || ldb % 4);                                // dgrad into a narrow, unaligned output
+  if (!BJ && ldb % 4) return false;
+#define DVAE_FC_CASE(KP)                                                                                   \
+  do {                                                                                                     \
+    if (scb) launch_fc32_t<KP, BJ, BJ ? 2 : 0>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s); \
+    else launch_fc32_t<KP, BJ, 0>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);          \
+  } while (0)
   if (Kc <= 32) DVAE_FC_CASE(32);
   else if (Kc <= 64) DVAE_FC_CASE(64);
   else if (Kc <= 128) DVAE_FC_CASE(128);

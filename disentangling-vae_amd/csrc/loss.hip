@@ -56,7 +56,8 @@ __global__ void k_reparam_kl_finish(const float* __restrict__ kl_part, int nblk,
   }
 }
 
-__global__ void k_reparam_kl_bwd(const float* __restrict__ dz, const float* __restrict__ dmu_x,
+__global__ void k_reparam_kl_bwd(const float* __restrict__ dz, const float* __restrict__ dz2,
+                                 const float* __restrict__ dz3, const float* __restrict__ dmu_x,
                                  const float* __restrict__ dlv_x, const float* __restrict__ mu,
                                  const float* __restrict__ logvar, const float* __restrict__ eps,
                                  const float* __restrict__ scal, const float* __restrict__ coef,
@@ -65,7 +66,9 @@ __global__ void k_reparam_kl_bwd(const float* __restrict__ dz, const float* __re
   if (idx >= (long)B * D) return;
   const float klw = scal[DVAE_S_KLW] * coef[DVAE_C_INV_B];
   const float m = mu[idx], lv = logvar[idx];
-  const float g = dz ? dz[idx] : 0.f;
+  float g = dz ? dz[idx] : 0.f;
+  if (dz2) g += dz2[idx];                 // gradients reaching z by other routes (TC estimator, discriminator)
+  if (dz3) g += dz3[idx];
   float dm = g + klw * m;
   float dl = klw * 0.5f * (expf(lv) - 1.f);
   if (eps) dl += g * eps[idx] * 0.5f * expf(0.5f * lv);
@@ -368,10 +371,11 @@ __global__ __launch_bounds__(256) void k_disc_losses(const float* __restrict__ l
 
 // ---- scalar epilogue -------------------------------------------------------------------------
 // pack: local sums -> packed[DVAE_NPACK] (sum-all-reduce this buffer over ranks when sharded)
-__global__ __launch_bounds__(256) void k_loss_pack(const float* __restrict__ rec_partials,
-                                                   const float* __restrict__ kl_dim, int D,
-                                                   const float* __restrict__ rowstats, int Bl,
-                                                   const float* __restrict__ disc_sums, float* __restrict__ packed) {
+__device__ __forceinline__ void loss_pack_body(const float* __restrict__ rec_partials,
+                                               const float* __restrict__ kl_dim, int D,
+                                               const float* __restrict__ rowstats, int Bl,
+                                               const float* __restrict__ disc_sums, float* packed,
+                                               int kl_blocks, float kl_scale) {
   __shared__ float red[5][4];
   const int tid = threadIdx.x;
   float r = 0.f;
@@ -394,14 +398,32 @@ __global__ __launch_bounds__(256) void k_loss_pack(const float* __restrict__ rec
     const float t = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
     packed[tid == 0 ? 0 : 16 + tid] = t;          // [0] rec, [17..20] rowstat sums
   }
-  if (tid >= 32 && tid < 32 + 16) packed[1 + (tid - 32)] = (kl_dim && (tid - 32) < D) ? kl_dim[tid - 32] : 0.f;
+  if (tid >= 32 && tid < 32 + 16) {
+    const int d = tid - 32;
+    float v = 0.f;
+    if (kl_dim && d < D) {
+      if (kl_blocks > 0) {               // un-finished per-workgroup partials of k_reparam_kl_fwd (same order as k_reparam_kl_finish)
+        for (int g = 0; g < kl_blocks; ++g) v += kl_dim[16 + g * 16 + d];
+        v *= kl_scale;
+      } else {
+        v = kl_dim[d];
+      }
+    }
+    packed[1 + d] = v;
+  }
   if (tid >= 64 && tid < 64 + 3) packed[21 + (tid - 64)] = disc_sums ? disc_sums[tid - 64] : 0.f;
   if (tid >= 96 && tid < 96 + 8) packed[24 + (tid - 96)] = 0.f;
 }
 
-__global__ void k_loss_finalize(int kind, const float* __restrict__ packed, int D, int Bg,
-                                const float* __restrict__ coef, float* __restrict__ scal) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void k_loss_pack(const float* __restrict__ rec_partials,
+                                                   const float* __restrict__ kl_dim, int D,
+                                                   const float* __restrict__ rowstats, int Bl,
+                                                   const float* __restrict__ disc_sums, float* __restrict__ packed) {
+  loss_pack_body(rec_partials, kl_dim, D, rowstats, Bl, disc_sums, packed, 0, 0.f);
+}
+
+__device__ __forceinline__ void loss_finalize_body(int kind, const float* packed, int D, int Bg,
+                                                   const float* __restrict__ coef, float* __restrict__ scal) {
   const float rec = packed[0] * coef[DVAE_C_INV_B];
   float kl = 0.f;
   for (int d = 0; d < D; ++d) { kl += packed[1 + d]; scal[DVAE_S_KL0 + d] = packed[1 + d]; }
@@ -432,6 +454,26 @@ __global__ void k_loss_finalize(int kind, const float* __restrict__ packed, int 
   scal[DVAE_S_TC] = tc; scal[DVAE_S_DWKL] = dw; scal[DVAE_S_KLW] = klw; scal[DVAE_S_DTC] = dtc;
 }
 
+__global__ void k_loss_finalize(int kind, const float* __restrict__ packed, int D, int Bg,
+                                const float* __restrict__ coef, float* __restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  loss_finalize_body(kind, packed, D, Bg, coef, scal);
+}
+
+// single-process epilogue: pack (+ finishing the KL partials) and finalize in ONE launch
+__global__ __launch_bounds__(256) void k_loss_epilogue(int kind, const float* __restrict__ rec_partials,
+                                                       const float* __restrict__ kl_dim, int kl_blocks, int D,
+                                                       const float* __restrict__ rowstats, int Bl,
+                                                       const float* __restrict__ disc_sums, int Bg,
+                                                       const float* __restrict__ coef, float* packed,
+                                                       float* __restrict__ scal) {
+  loss_pack_body(rec_partials, kl_dim, D, rowstats, Bl, disc_sums, packed, kl_blocks, coef[DVAE_C_INV_B]);
+  if (!scal) return;
+  __threadfence();
+  __syncthreads();                       // packed[] was written by this workgroup
+  if (threadIdx.x == 0) loss_finalize_body(kind, packed, D, Bg, coef, scal);
+}
+
 __global__ void k_sigmoid_bwd(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ out, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     out[i] = gy[i] * ((1.f - y[i]) * y[i]);
@@ -456,19 +498,20 @@ int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* l
   float* part = kl_dim ? kl_dim + 16 : nullptr;
   hipLaunchKernelGGL(k_reparam_kl_fwd, dim3(blocks), dim3(256), 0, s, ml, eps, mu, logvar, z, part, B, D);
   DVAE_CHECK_LAUNCH();
-  if (kl_dim) {
+  if (kl_dim && coef) {      // coef == NULL: the raw partials stay in kl_dim[16..]; dvae_loss_epilogue finishes them
     hipLaunchKernelGGL(k_reparam_kl_finish, dim3(1), dim3(64), 0, s, part, blocks, kl_dim, coef, D);
     DVAE_CHECK_LAUNCH();
   }
   return 0;
 }
 
-int launch_reparam_kl_bwd(const float* dz, const float* dmu_x, const float* dlv_x, const float* mu, const float* logvar,
+int launch_reparam_kl_bwd(const float* dz, const float* dz2, const float* dz3, const float* dmu_x, const float* dlv_x,
+                          const float* mu, const float* logvar,
                           const float* eps, const float* scal, const float* coef, float* dml, int B, int D,
                           hipStream_t s) {
   long n = (long)B * D;
-  hipLaunchKernelGGL(k_reparam_kl_bwd, dim3((n + 255) / 256), dim3(256), 0, s, dz, dmu_x, dlv_x, mu, logvar, eps, scal,
-                     coef, dml, B, D);
+  hipLaunchKernelGGL(k_reparam_kl_bwd, dim3((n + 255) / 256), dim3(256), 0, s, dz, dz2, dz3, dmu_x, dlv_x, mu, logvar, eps,
+                     scal, coef, dml, B, D);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -523,6 +566,20 @@ int launch_disc_losses(const float* lg, int Bh, const float* coef, float* sums, 
 int launch_loss_pack(const float* rec_partials, const float* kl_dim, int D, const float* rowstats, int Bl,
                      const float* disc_sums, float* packed, hipStream_t s) {
   hipLaunchKernelGGL(k_loss_pack, dim3(1), dim3(256), 0, s, rec_partials, kl_dim, D, rowstats, Bl, disc_sums, packed);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_rows, int D, const float* rowstats,
+                         int Bl, const float* disc_sums, int Bg, const float* coef, float* packed, float* scal,
+                         hipStream_t s) {
+  int kl_blocks = 0;
+  if (kl_rows > 0) {                     // same grid as launch_reparam_kl_fwd
+    kl_blocks = (kl_rows + 255) / 256;
+    if (kl_blocks > RK_BLOCKS) kl_blocks = RK_BLOCKS;
+  }
+  hipLaunchKernelGGL(k_loss_epilogue, dim3(1), dim3(256), 0, s, kind, rec_partials, kl_dim, kl_blocks, D, rowstats, Bl,
+                     disc_sums, Bg, coef, packed, scal);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -40,7 +40,7 @@ SIGNATURES = {
     "dvae_linear_dgrad": [_p, _p, _p, _i, _p, _i, _i, _i, _p, _p],
     "dvae_linear_wgrad": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dvae_reparam_kl_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
-    "dvae_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "dvae_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_recon_loss": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
     "dvae_sigmoid_bwd": [_p, _p, _p, _l, _p],
     "dvae_btcvae_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
@@ -49,6 +49,7 @@ SIGNATURES = {
     "dvae_disc_losses": [_p, _i, _p, _p, _p, _p, _p],
     "dvae_loss_pack": [_p, _p, _i, _p, _i, _p, _p, _p],
     "dvae_loss_finalize": [_i, _p, _i, _i, _p, _p, _p],
+    "dvae_loss_epilogue": [_i, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p],
     "dvae_set_coef": [_p] + [ctypes.c_float] * 8 + [_p],
     "dvae_add": [_p, _p, _p, _l, _p],
 }

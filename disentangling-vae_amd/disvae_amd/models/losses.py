@@ -361,7 +361,8 @@ class _SingleOptimizerLoss(BaseLoss):
         if not is_train:
             eps = None
         eng.encode(data, buf)
-        eng.reparam(buf, eps, sc.kl_dim, sc.coef)
+        # single process: the KL partials are finished by the one-launch loss epilogue
+        eng.reparam(buf, eps, sc.kl_dim, sc.coef if world > 1 else None)
         rowstats = None
         dz_x = dmu_x = dlv_x = None
         if self.KIND == _lib.LOSS_BTCVAE:
@@ -390,19 +391,26 @@ class _SingleOptimizerLoss(BaseLoss):
         eng.decode(buf.z, buf, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         if self.KIND == _lib.LOSS_BTCVAE:
             eng._join_side()
-        call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
         if world > 1:
-            self.comm.all_reduce(sc.packed)
-        call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), s)
+            call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
+            # the global loss sums are first needed by reparam_kl_bwd (a whole decoder backward later): their
+            # all-reduce and the scalar epilogue leave the critical path; decode_backward's join covers them
+            eng.fork_side()
+            with torch.cuda.stream(eng.side_stream):
+                self.comm.all_reduce(sc.packed)
+                call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), _stream())
+            if not is_train:
+                eng._join_side()
+        else:
+            call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), B, D, ptr(rowstats), B, None, Bg,
+                 ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), s)
         if not is_train:
             return
         eng.decode_backward(buf.z, buf, join=world > 1)     # single process: one join, at the end of the backward pass
         pending = []
         if world > 1:      # decoder gradients are final: their all-reduce overlaps the encoder backward
             pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
-        if dz_x is not None:
-            call("dvae_add", ptr(buf.dz), ptr(dz_x), ptr(buf.dz), buf.dz.numel(), s)
-        call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dmu_x), ptr(dlv_x), ptr(buf.mu), ptr(buf.logvar), ptr(eps),
+        call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dz_x), None, ptr(dmu_x), ptr(dlv_x), ptr(buf.mu), ptr(buf.logvar), ptr(eps),
              ptr(sc.scal), ptr(sc.coef), ptr(buf.dml), B, D, s)
         eng.encode_backward(data, buf)
         if world > 1:
@@ -554,7 +562,7 @@ class FactorKLoss(BaseLoss):
         eng.encode(data, buf, n=2 * Bh)                               # data1 and data2 in one pass
         # reparameterise the two halves (KL only over data1, denominator = half batch; losses.py:255-259)
         call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps1), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(sc.kl_dim),
-             ptr(sc.coef), Bh, D, s)
+             ptr(sc.coef) if world > 1 else None, Bh, D, s)
         eng.decode(buf.z, buf, n=Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         off = Bh
         call("dvae_reparam_kl_fwd", ptr(buf.ml[off:]), ptr(eps2), ptr(buf.mu[off:]), ptr(buf.logvar[off:]),
@@ -577,18 +585,22 @@ class FactorKLoss(BaseLoss):
         if world > 1:
             # the CE / tc means run over the global half batch
             g_dtc.mul_(1.0 / world); g_tc.mul_(1.0 / world)
-        call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), s)
-        if world > 1:
-            self.comm.all_reduce(sc.packed)
-        call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), s)
+        if world > 1:          # off the critical path: first consumer is reparam_kl_bwd, after decode_backward's join
+            call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), s)
+            eng.fork_side()
+            with torch.cuda.stream(eng.side_stream):
+                self.comm.all_reduce(sc.packed)
+                call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), _stream())
+        else:
+            call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), Bh, D, None, 0, ptr(sc.disc_sums),
+                 Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), s)
         # discriminator backward of d_tc_loss (weight grads + dz), losses.py:303-304
         dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
         # tc term of vae_loss through D: dgrad only, first half (its disc weight grads are zeroed at :303)
         dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2")
-        eng.decode_backward(buf.z, buf, n=Bh, join=False)   # joined at the end of encode_backward
-        call("dvae_add", ptr(buf.dz), ptr(dz_a), ptr(buf.dz), Bh * D, s)      # quirk Q1
-        call("dvae_add", ptr(buf.dz), ptr(dz_b), ptr(buf.dz), Bh * D, s)
-        call("dvae_reparam_kl_bwd", ptr(buf.dz), None, None, ptr(buf.mu), ptr(buf.logvar), ptr(eps1), ptr(sc.scal),
+        eng.decode_backward(buf.z, buf, n=Bh, join=world > 1)   # single process: joined at the end of encode_backward
+        # dz_a: quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1); dz_b: the tc term through D
+        call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dz_a), ptr(dz_b), None, None, ptr(buf.mu), ptr(buf.logvar), ptr(eps1), ptr(sc.scal),
              ptr(sc.coef), ptr(buf.dml), Bh, D, s)
         eng.encode_backward(data, buf, n=Bh)
         if world > 1:

@@ -270,7 +270,7 @@ class _VAEFn(torch.autograd.Function):
         coef = torch.ones(_lib.NCOEF, dtype=torch.float32, device=x.device)
         gm = g_mu.contiguous() if g_mu is not None else None
         gl = g_lv.contiguous() if g_lv is not None else None
-        call("dvae_reparam_kl_bwd", ptr(dz), ptr(gm), ptr(gl), ptr(buf.mu), ptr(buf.logvar), ptr(ctx.eps), ptr(scal),
+        call("dvae_reparam_kl_bwd", ptr(dz), None, None, ptr(gm), ptr(gl), ptr(buf.mu), ptr(buf.logvar), ptr(ctx.eps), ptr(scal),
              ptr(coef), ptr(buf.dml), B, model.latent_dim, s)
         eng.encode_backward(x, buf)
         return (None, None, None, None) + tuple(_param_grads(model))
@@ -302,7 +302,7 @@ class _EncodeFn(torch.autograd.Function):
         coef = torch.ones(_lib.NCOEF, dtype=torch.float32, device=x.device)
         gm = g_mu.contiguous() if g_mu is not None else None
         gl = g_lv.contiguous() if g_lv is not None else None
-        call("dvae_reparam_kl_bwd", None, ptr(gm), ptr(gl), ptr(buf.mu), ptr(buf.logvar), None, ptr(scal), ptr(coef),
+        call("dvae_reparam_kl_bwd", None, None, None, ptr(gm), ptr(gl), ptr(buf.mu), ptr(buf.logvar), None, ptr(scal), ptr(coef),
              ptr(buf.dml), x.shape[0], model.latent_dim, s)
         eng.encode_backward(x, buf)
         grads = []

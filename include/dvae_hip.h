@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DVAE_VERSION 100
+#define DVAE_VERSION 101
 
 enum { DVAE_NCHW = 0, DVAE_NHWC = 1 };
 enum { DVAE_ACT_NONE = 0, DVAE_ACT_RELU = 1, DVAE_ACT_LEAKY02 = 2, DVAE_ACT_SIGMOID = 3 };
@@ -101,13 +101,16 @@ int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int
  * ml[B,2D] is the interleaved output of mu_logvar_gen (encoders.py:87: mu = ml[:,0::2],
  * logvar = ml[:,1::2]).  z = mu + exp(.5 logvar) eps (eps == NULL: z = mu, eval mode).
  * kl_dim (may be NULL): float[DVAE_KL_FLOATS]; [0,D) = coef[INV_B] * sum_b 0.5(-1 - lv + mu^2 + e^lv),
- * the rest is scratch for the per-workgroup partial sums.                                   */
+ * the rest is scratch for the per-workgroup partial sums.  With kl_dim != NULL and coef == NULL only
+ * the partials are written (no finishing launch): dvae_loss_epilogue(kl_rows = B) finishes them.   */
 #define DVAE_KL_FLOATS (16 + 64 * 16)
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z,
                         float* kl_dim, const float* coef, int B, int D, void* stream);
-/* dml[B,2D] (interleaved) from dz[B,D] and optional direct grads dmu_x/dlv_x[B,D];
- * the KL term enters with weight scal[DVAE_S_KLW] * coef[INV_B].                            */
-int dvae_reparam_kl_bwd(const float* dz, const float* dmu_x, const float* dlv_x, const float* mu,
+/* dml[B,2D] (interleaved) from dz + dz2 + dz3 [B,D] (each may be NULL: gradients that reach z
+ * through the decoder, the TC estimator, the discriminator -- quirk Q1) and optional direct grads
+ * dmu_x/dlv_x[B,D]; the KL term enters with weight scal[DVAE_S_KLW] * coef[INV_B].             */
+int dvae_reparam_kl_bwd(const float* dz, const float* dz2, const float* dz3, const float* dmu_x,
+                        const float* dlv_x, const float* mu,
                         const float* logvar, const float* eps, const float* scal, const float* coef,
                         float* dml, int B, int D, void* stream);
 
@@ -169,6 +172,12 @@ int dvae_loss_pack(const float* rec_partials, const float* kl_dim, int D, const 
                    const float* disc_sums, float* packed, void* stream);
 int dvae_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal,
                        void* stream);
+/* Un-sharded batches: dvae_loss_pack and dvae_loss_finalize in ONE launch (scal == NULL: pack only).
+ * kl_rows > 0: kl_dim holds the un-finished partials of dvae_reparam_kl_fwd(coef = NULL) over
+ * kl_rows rows; they are summed (same order as the finishing kernel) and scaled by coef[INV_B].   */
+int dvae_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_rows, int D,
+                       const float* rowstats, int Bl, const float* disc_sums, int Bg,
+                       const float* coef, float* packed, float* scal, void* stream);
 
 /* coef[0..7] <- the eight values (passed as kernel arguments: in-order with the stream, no
  * host buffer whose lifetime must outlive the launch).                                      */

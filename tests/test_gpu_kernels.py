@@ -205,8 +205,9 @@ def test_reparam_kl(B):
     dz, dmx, dlx = _rand(B, D, seed=3), _rand(B, D, seed=4), _rand(B, D, seed=5)
     scal = torch.zeros(_lib.NSCAL); scal[_lib.S_KLW] = 2.5
     dml = torch.empty(B, 2 * D, device=DEV)
-    call("dvae_reparam_kl_bwd", ptr(dev(dz)), ptr(dev(dmx)), ptr(dev(dlx)), ptr(dev(m_ref)), ptr(dev(l_ref)), ptr(epsd),
-         ptr(dev(scal)), ptr(coefd), ptr(dml), B, D, stream())
+    dz2, dz3 = _rand(B, D, seed=6), _rand(B, D, seed=7)          # gradients reaching z by other routes
+    call("dvae_reparam_kl_bwd", ptr(dev(dz - dz2 - dz3)), ptr(dev(dz2)), ptr(dev(dz3)), ptr(dev(dmx)), ptr(dev(dlx)),
+         ptr(dev(m_ref)), ptr(dev(l_ref)), ptr(epsd), ptr(dev(scal)), ptr(coefd), ptr(dml), B, D, stream())
     mr, lr = m_ref.double().requires_grad_(True), l_ref.double().requires_grad_(True)
     zz = O.reparameterize(mr, lr, eps.double())
     obj = (zz * dz.double()).sum() + (mr * dmx.double()).sum() + (lr * dlx.double()).sum() + 2.5 * O.kl_normal_loss(mr, lr)[0]
@@ -318,3 +319,36 @@ def test_permute_dims_and_disc_losses():
     check(g_dtc, lr.grad, what="g_dtc")
     ref_tc = torch.zeros(Bh, 2, dtype=torch.double); ref_tc[:, 0] = 0.3 * 6.4 / Bh; ref_tc[:, 1] = -0.3 * 6.4 / Bh
     check(g_tc, ref_tc, what="g_tc")
+
+
+@pytest.mark.parametrize("kind,B", [(_lib.LOSS_BETAH, 8), (_lib.LOSS_BETAB, 700), (_lib.LOSS_BTCVAE, 300), (_lib.LOSS_FACTOR, 20000)])
+def test_loss_epilogue_equals_pack_then_finalize(kind, B):
+    """dvae_loss_epilogue (one launch: finish the KL partials + pack + finalize) == the sharded
+    sequence dvae_reparam_kl_fwd(coef) -> dvae_loss_pack -> dvae_loss_finalize, bit for bit."""
+    D = 10
+    ml = dev(_rand(B, 2 * D, seed=1, scale=0.5))
+    eps = dev(_rand(B, D, seed=2))
+    coef = torch.zeros(_lib.NCOEF)
+    coef[_lib.C_INV_B], coef[_lib.C_ANNEAL], coef[_lib.C_BETA] = 1.0 / B, 0.3, 4.0
+    coef[_lib.C_ALPHA], coef[_lib.C_GAMMA], coef[_lib.C_CAP] = 1.0, 2.0, 7.0
+    coefd = dev(coef)
+    partials = dev(_rand(_lib.REC_NPART, seed=3).abs())
+    rowstats = dev(_rand(B, 16, seed=4)) if kind == _lib.LOSS_BTCVAE else None
+    disc = dev(_rand(4, seed=5)) if kind == _lib.LOSS_FACTOR else None
+    f = lambda *s: torch.empty(*s, device=DEV)
+    mu, lv, z = f(B, D), f(B, D), f(B, D)
+    out = []
+    for fused in (False, True):
+        kl = torch.zeros(16 + 64 * 16, device=DEV)
+        packed, scal = torch.zeros(_lib.NPACK, device=DEV), torch.zeros(_lib.NSCAL, device=DEV)
+        call("dvae_reparam_kl_fwd", ptr(ml), ptr(eps), ptr(mu), ptr(lv), ptr(z), ptr(kl), None if fused else ptr(coefd), B, D, stream())
+        if fused:
+            call("dvae_loss_epilogue", kind, ptr(partials), ptr(kl), B, D, ptr(rowstats), B if rowstats is not None else 0,
+                 ptr(disc), B, ptr(coefd), ptr(packed), ptr(scal), stream())
+        else:
+            call("dvae_loss_pack", ptr(partials), ptr(kl), D, ptr(rowstats), B if rowstats is not None else 0, ptr(disc), ptr(packed), stream())
+            call("dvae_loss_finalize", kind, ptr(packed), D, B, ptr(coefd), ptr(scal), stream())
+        out.append((packed.cpu(), scal.cpu()))
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    assert out[0][1][_lib.S_LOSS].abs() > 0
