@@ -110,7 +110,11 @@ class BaseLoss(abc.ABC):
         self.rec_dist = rec_dist
         self.steps_anneal = steps_anneal
         self._scratch = None
-        self.comm = None   # set by disvae_amd.parallel.DataParallel for sharded batches
+        self.comm = None   # set by disvae_amd.parallel.data_parallel for sharded batches
+        # sharded batches: "global" = the B x B estimator / permute_dims couple the GLOBAL batch (equal to the
+        # single-process step on the concatenated batch); "local" = every rank's shard is its own minibatch
+        # (what running the reference under DistributedDataParallel would compute: a different estimator)
+        self.estimator = "global"
         # how the device side of the native training iteration is issued (graph.py): None = eager
         # Python; "plan" = recorded launch list (the same launches on the same streams, bit-identical
         # results); "graph" = hipGraph; "auto" (default) = plan while the iteration is launch-bound
@@ -173,6 +177,10 @@ class BaseLoss(abc.ABC):
     # world size / rank of the data-parallel group (1 / 0 without a communicator)
     def _world(self):
         return (1, 0) if self.comm is None else (self.comm.world_size, self.comm.rank)
+
+    def _est_world(self):
+        """(world, rank) as seen by the batch-coupled estimators."""
+        return (1, 0) if (self.comm is None or self.estimator == "local") else (self.comm.world_size, self.comm.rank)
 
     @staticmethod
     def _store_common(storer, vals, D):
@@ -326,7 +334,7 @@ class _SingleOptimizerLoss(BaseLoss):
         sc.set_coef(INV_B=1.0 / (B * world), **self._coefs(is_train))
         data = data.contiguous()
         if self.KIND == _lib.LOSS_BTCVAE:
-            sc.set_log_w(B * world, self.n_data)
+            sc.set_log_w(B * self._est_world()[0], self.n_data)
         mode = self._replay_mode(is_train, data)
         if mode:
             # a replay re-issues launches with frozen pointers: injected noise goes through a static
@@ -368,25 +376,30 @@ class _SingleOptimizerLoss(BaseLoss):
         if self.KIND == _lib.LOSS_BTCVAE:
             # the B x B estimator (forward AND backward: it needs z, mu, logvar and the coefficients only)
             # runs on the side stream while the decoder forward occupies the current one
+            ew, er = self._est_world()            # the estimator's view of the sharding (local mode: one shard = one batch)
+            Be = B * ew
             eng.fork_side()
             with torch.cuda.stream(eng.side_stream):
                 ss = _stream()
                 zg, mug, lvg = buf.z, buf.mu, buf.logvar
-                if world > 1:
+                if ew > 1:
                     zg, mug, lvg = self.comm.all_gather_latents(buf.z, buf.mu, buf.logvar)
                 rowstats = sc.latent("rowstats", B, 16)
-                tc_tmp = sc.latent("tc_tmp", 3 * D, Bg)
-                call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Bg, D, rank * B, B, int(self.is_mss), ptr(sc.log_w),
+                tc_tmp = sc.latent("tc_tmp", 3 * D, Be)
+                call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Be, D, er * B, B, int(self.is_mss), ptr(sc.log_w),
                      ptr(tc_tmp), ptr(rowstats), ss)
                 if is_train:
                     dz_x = sc.latent("dz_tc", B, D)
-                    dmu_all, dlv_all = sc.latent("dmu_all", Bg, D), sc.latent("dlv_all", Bg, D)
-                    call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Bg, D, rank * B, B,
+                    dmu_all, dlv_all = sc.latent("dmu_all", Be, D), sc.latent("dlv_all", Be, D)
+                    call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Be, D, er * B, B,
                          int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(tc_tmp), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), ss)
-                    if world > 1:
+                    if ew > 1:
                         dmu_x, dlv_x = self.comm.reduce_scatter_cols(dmu_all, dlv_all)
                     else:
                         dmu_x, dlv_x = dmu_all, dlv_all
+                    if world > ew:                # local estimator: its mean runs over B, the loss over B * world
+                        for t_ in (dz_x, dmu_x, dlv_x):
+                            t_.mul_(1.0 / world)
         # decoder; its last layer also evaluates the reconstruction likelihood and dL/dlogit
         eng.decode(buf.z, buf, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         if self.KIND == _lib.LOSS_BTCVAE:
@@ -571,13 +584,14 @@ class FactorKLoss(BaseLoss):
         zin = sc.latent("disc_in", 2 * Bh, D)
         record_py(zin[:Bh].copy_, buf.z[:Bh])
         z2 = buf.z[off:off + Bh]
-        if world > 1:
+        ew, er = self._est_world()                # scope of permute_dims: global half batch, or this shard ("local")
+        if ew > 1:
             z2g = self.comm.all_gather_rows(z2)
         else:
             z2g = z2
-        zperm_g = sc.latent("zperm_g", Bhg, D)
-        call("dvae_permute_dims", ptr(z2g.contiguous()), ptr(perms), ptr(zperm_g), Bhg, D, s)
-        record_py(zin[Bh:].copy_, zperm_g[rank * Bh:(rank + 1) * Bh])
+        zperm_g = sc.latent("zperm_g", Bh * ew, D)
+        call("dvae_permute_dims", ptr(z2g.contiguous()), ptr(perms), ptr(zperm_g), Bh * ew, D, s)
+        record_py(zin[Bh:].copy_, zperm_g[er * Bh:(er + 1) * Bh])
         logits = disc.forward_raw(zin, 2 * Bh)                        # D(z1) and D(z_perm) in one pass
         g_dtc = sc.latent("g_dtc", 2 * Bh, 2)
         g_tc = sc.latent("g_tc", Bh, 2)
@@ -634,7 +648,7 @@ class FactorKLoss(BaseLoss):
         if is_train:
             if perms is None:
                 # CPU generator (shared seed across ranks), reference order losses.py:505
-                perms = torch.stack([torch.randperm(Bhg) for _ in range(D)])
+                perms = torch.stack([torch.randperm(Bh * self._est_world()[0]) for _ in range(D)])
             perms = perms.to(dtype=torch.int64)
             mode = self._replay_mode(True, data)
             if mode:

@@ -88,12 +88,21 @@ def init_process_group_from_env(backend=None):
     dist.init_process_group(backend=backend)
 
 
-def data_parallel(model, loss_f, group=None):
+def data_parallel(model, loss_f, group=None, estimator="global"):
     """Attach a communicator to a native loss plugin (and make every rank start from rank 0's
     weights).  After this, ``loss_f.fused_step`` / ``call_optimize`` treat their input as this
-    rank's shard of a global batch of world_size x B images."""
+    rank's shard of a global batch of world_size x B images.
+
+    estimator: scope of the batch-coupled terms (the beta-TCVAE B x B estimator and its minibatch
+    weights, FactorVAE's permute_dims).  "global" (default): over the global batch -- equal to the
+    single-process step on the concatenated batch, at the price of a latent all-gather, a column-gradient
+    all-reduce and B x (world B) estimator work per rank.  "local": over each rank's shard -- what the
+    reference computes under DistributedDataParallel (gradient all-reduce only); a different estimator."""
+    if estimator not in ("global", "local"):
+        raise ValueError("estimator must be 'global' or 'local'")
     comm = Comm(group)
     loss_f.comm = comm
+    loss_f.estimator = estimator
     comm.broadcast(model.arena.flat)
     disc = getattr(loss_f, "discriminator", None)
     if disc is not None:

@@ -128,3 +128,77 @@ def test_rccl_call_sites_single_rank(loss):
     rank, msg = q.get(timeout=280)
     p_.join(timeout=60)
     assert msg == "ok", msg
+
+
+def _worker_local(rank, world, port, loss, q):
+    """estimator="local": the sharded step must equal the rank-AVERAGE of independent single-process steps on
+    the shards (loss = mean of the shard losses, gradient = mean of the shard gradients)."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for p in (root, os.path.join(root, "disentangling-vae_amd"), os.path.join(root, "tests")):
+            sys.path.insert(0, p)
+        from disvae_amd import parallel
+        parallel.init_process_group_from_env("gloo")
+        torch.cuda.set_device(0)
+        lr = 1e-4 if loss == "factor" else 5e-4
+        Bl, D = 12, 10
+        gen = torch.Generator().manual_seed(5)
+        shards, noises = [], []
+        for r in range(world):
+            shards.append(torch.rand((Bl,) + IMG, generator=gen))
+            if loss == "factor":
+                noises.append((torch.randn(Bl // 2, D, generator=gen), torch.randn(Bl // 2, D, generator=gen),
+                               torch.stack([torch.randperm(Bl // 2, generator=gen) for _ in range(D)])))
+            else:
+                noises.append(torch.randn(Bl, D, generator=gen))
+
+        def step(m, o, l, r):
+            if loss == "factor":
+                e1, e2, pm = noises[r]
+                return l.call_optimize(shards[r].cuda(), m, o, defaultdict(list), noise=(e1.cuda(), e2.cuda(), pm))
+            return l.fused_step(shards[r].cuda(), m, o, defaultdict(list), eps=noises[r].cuda())
+
+        ref_loss, ref_grad, ref_dgrad = 0.0, 0.0, 0.0
+        for r in range(world):
+            m0, o0, l0 = _make(loss, lr)
+            ref_loss += step(m0, o0, l0, r).item() / world
+            ref_grad = ref_grad + m0.arena.grad.clone() / world
+            if loss == "factor":
+                ref_dgrad = ref_dgrad + l0.discriminator.arena.grad.clone() / world
+        m1, o1, l1 = _make(loss, lr)
+        parallel.data_parallel(m1, l1, estimator="local")
+        out1 = step(m1, o1, l1, rank)
+        err = ((m1.arena.grad - ref_grad).abs().max() / ref_grad.abs().max()).item()
+        assert err < 2e-5, "grad err %.3e" % err
+        assert abs(out1.item() - ref_loss) <= 2e-6 * abs(ref_loss), (out1.item(), ref_loss)
+        if loss == "factor":
+            dg = l1.discriminator.arena.grad
+            derr = ((dg - ref_dgrad).abs().max() / ref_dgrad.abs().max()).item()
+            assert derr < 2e-5, "disc grad err %.3e" % derr
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        try:
+            torch.distributed.destroy_process_group()
+        except Exception:
+            pass
+
+
+@pytest.mark.parametrize("loss", ["btcvae", "factor"])
+def test_local_estimator_is_rank_average(loss):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_local, args=(r, world, port, loss, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=280) for _ in range(world)]
+    for p_ in procs:
+        p_.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)

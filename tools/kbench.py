@@ -77,3 +77,11 @@ coef = torch.tensor([1.0 / B, 0.5, 6.4, 1.0, 1.0, 0, 0, 0], device=dev)
 dz, dm, dl = (torch.empty(B, D, device=dev) for _ in range(3))
 report("btcvae fwd B=%d" % B, timeit(lambda: call("dvae_btcvae_fwd", ptr(z), ptr(mu), ptr(lv), B, D, 0, B, 1, ptr(lw), ptr(tmp), ptr(rs), s)), 30.0 * B * B * D, 0)
 report("btcvae bwd (rows+cols)", timeit(lambda: call("dvae_btcvae_bwd", ptr(z), ptr(mu), ptr(lv), ptr(rs), B, D, 0, B, 1, ptr(lw), ptr(coef), ptr(tmp), ptr(dz), ptr(dm), ptr(dl), s)), 60.0 * B * B * D, 0)
+
+# the estimator as ONE RANK OF 8 sees it (weak scaling, global estimator): its B rows against 8B columns
+Bg = 8 * B
+zg, mug, lvg = (torch.randn(Bg, D, device=dev) for _ in range(3))
+tmpg = torch.empty(3 * D, Bg, device=dev)
+dmg, dlg = torch.empty(Bg, D, device=dev), torch.empty(Bg, D, device=dev)
+report("btcvae fwd rows=%d cols=%d (rank 3 of 8)" % (B, Bg), timeit(lambda: call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Bg, D, 3 * B, B, 1, ptr(lw), ptr(tmpg), ptr(rs), s)), 30.0 * B * Bg * D, 0)
+report("btcvae bwd rows=%d cols=%d" % (B, Bg), timeit(lambda: call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rs), Bg, D, 3 * B, B, 1, ptr(lw), ptr(coef), ptr(tmpg), ptr(dz), ptr(dmg), ptr(dlg), s)), 60.0 * B * Bg * D, 0)
