@@ -192,7 +192,8 @@ __device__ __forceinline__ float epilogue_act(float v, int act) {
 template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, const float* __restrict__ w,
                                                 const float* __restrict__ bias, const float* __restrict__ mask,
-                                                float* __restrict__ out, int N, int act, int n_units) {
+                                                float* __restrict__ out, int N, int act, int n_units,
+                                                int out_nchw) {
   using G = Geo<HS>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                    // 16384 floats
@@ -243,6 +244,12 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
     // epilogue: this wave owns D-fragment rows j + 8*kh + 4*h (j = 0..3) of its M-tile.  Mask
     // loads are issued together before any store (no load->wait->store chains).
     const long P0 = (long)unit * G::U + mt * 32 + 8 * kh + 4 * h;
+    // element (pixel pix, channel i) of out / mask: NHWC, or NCHW = the (c,h,w) flatten order the FC stack
+    // consumes (encoders.py:80) -- written directly, no relayout pass in between
+    auto oidx = [&](long pix) -> long {
+      constexpr int PP = HS * HS;
+      return out_nchw ? ((pix / PP) * 32 + i) * PP + (pix % PP) : pix * 32 + i;
+    };
     float vals[4], mv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -256,13 +263,13 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
     if (full) {
       if (MASK) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mv[j] = mask[(P0 + j) * 32 + i];
+        for (int j = 0; j < 4; ++j) mv[j] = mask[oidx(P0 + j)];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float v = epilogue_act(vals[j] + bv, act);
         if (MASK) v = mv[j] > 0.f ? v : 0.f;
-        out[(P0 + j) * 32 + i] = v;
+        out[oidx(P0 + j)] = v;
       }
     } else {
 #pragma unroll
@@ -270,8 +277,8 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
         const long pix = P0 + j;
         if (pix < npix) {
           float v = epilogue_act(vals[j] + bv, act);
-          if (MASK) v = mask[pix * 32 + i] > 0.f ? v : 0.f;
-          out[pix * 32 + i] = v;
+          if (MASK) v = mask[oidx(pix)] > 0.f ? v : 0.f;
+          out[oidx(pix)] = v;
         }
       }
     }
@@ -844,8 +851,9 @@ static int launch_down_t(const ConvArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_down32<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  if (a.mask) hipLaunchKernelGGL((k_down32<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
-  else hipLaunchKernelGGL((k_down32<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  const int out_nchw = a.out_layout == DVAE_NCHW;
+  if (a.mask) hipLaunchKernelGGL((k_down32<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, out_nchw);
+  else hipLaunchKernelGGL((k_down32<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, out_nchw);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -891,7 +899,9 @@ static bool mfma32_applicable(int Cb, int Cs, int Hs, int Ws, int l0, int l1, in
 }
 
 int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
-  if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.big_layout, a.out_layout, DVAE_NHWC)) return 1;
+  // the 4x4 end of the conv stack may write NCHW (= the FC stack's flatten order; its mask is then NCHW too)
+  const int out_l = (a.Hs == 4 && a.out_layout == DVAE_NCHW) ? DVAE_NHWC : a.out_layout;
+  if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.big_layout, out_l, DVAE_NHWC)) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
   // A/B switches: DVAE_DOWN_V1 = K-split 32x32x2 kernel, DVAE_DOWN_V2 = 8 symmetric waves;
   // default = wave-specialised (4 MFMA waves + 4 loader waves)

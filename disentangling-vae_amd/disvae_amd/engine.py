@@ -220,11 +220,14 @@ class VAEEngine:
         B = x.shape[0] if n is None else n
         c, H, _ = self.img_size
         src, src_layout, cin, h = x, NCHW, c, H
-        for name, act in zip(self.enc_names, buf.enc_act):
+        last = len(self.enc_names) - 1
+        for k, (name, act) in enumerate(zip(self.enc_names, buf.enc_act)):
+            # the last conv writes its 4x4x32 output NCHW = the (c,h,w) flatten order lin1 consumes
+            # (encoders.py:80), straight into a_flat: no relayout pass; no conv kernel reads that tensor
+            dst, dst_layout = (buf.a_flat, NCHW) if k == last else (act, NHWC)
             call("dvae_conv4s2_fwd", ptr(src), src_layout, ptr(self.p("encoder.%s.weight" % name)),
-                 ptr(self.p("encoder.%s.bias" % name)), ptr(act), NHWC, B, cin, h, h, HID, ACT_RELU, s)
+                 ptr(self.p("encoder.%s.bias" % name)), ptr(dst), dst_layout, B, cin, h, h, HID, ACT_RELU, s)
             src, src_layout, cin, h = act, NHWC, HID, h // 2
-        call("dvae_relayout", ptr(src), NHWC, ptr(buf.a_flat), B, HID, 4, 4, s)
         call("dvae_linear_fwd", ptr(buf.a_flat), ptr(self.p("encoder.lin1.weight")), ptr(self.p("encoder.lin1.bias")),
              ptr(buf.h1), B, HID * 16, HIDDEN_DIM, ACT_RELU, ws, s)
         call("dvae_linear_fwd", ptr(buf.h1), ptr(self.p("encoder.lin2.weight")), ptr(self.p("encoder.lin2.bias")),
@@ -293,8 +296,14 @@ class VAEEngine:
                      ptr(self.g("decoder.%s.weight" % name)), ptr(self.g("decoder.%s.bias" % name)),
                      B, HID, h, h, couts[k])
             (pending if h >= 16 else deferred).append(wargs)
-            call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(x_in), ptr(gx),
-                 NHWC, B, HID, h, h, couts[k], s)
+            if k == 0:
+                # the first decoder layer's input gradient leaves NCHW = (c,h,w) order, straight into gd3 (the
+                # gradient of lin3's output; ReLU mask = lin3's output d3 in the same order): no relayout pass
+                call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(buf.d3),
+                     ptr(buf.gd3), NCHW, B, HID, h, h, couts[k], s)
+            else:
+                call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(x_in), ptr(gx),
+                     NHWC, B, HID, h, h, couts[k], s)
             dy, dy_layout = gx, NHWC
             for w_ in queued:                    # side launches of the previous fork, issued AFTER this stream's next kernel
                 self._conv_wgrad(*w_, fork=False)
@@ -302,7 +311,6 @@ class VAEEngine:
             if h == 16 or (k == 0 and pending):  # last big dgrad is enqueued: its inputs and those of `pending` are final
                 self.fork_side()
                 queued, pending = pending, []
-        call("dvae_relayout", ptr(buf.gd3n), NHWC, ptr(buf.gd3), B, HID, 4, 4, s)
         for w_ in queued:
             self._conv_wgrad(*w_, fork=False)
         call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),

@@ -352,3 +352,28 @@ def test_loss_epilogue_equals_pack_then_finalize(kind, B):
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1], out[1][1])
     assert out[0][1][_lib.S_LOSS].abs() > 0
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("N", [3, 7, 70])
+def test_4x4_end_of_the_conv_stack_writes_nchw(N, generic):
+    """The last encoder conv (8x8 -> 4x4) writes its output NCHW = the (c,h,w) flatten order of encoders.py:80,
+    and the first decoder convT's dgrad (8x8 -> 4x4) writes dx NCHW with an NCHW ReLU mask (decoders.py:74):
+    the tuned MFMA kernel and the generic kernel, vs torch."""
+    C = 32
+    x = _rand(N, C, 8, 8, seed=1)
+    w = _rand(C, C, 4, 4, seed=2, scale=0.2)
+    b = _rand(C, seed=3, scale=0.1)
+    with force_generic(generic):
+        y = torch.empty(N, C, 4, 4, device=DEV)
+        call("dvae_conv4s2_fwd", ptr(nhwc(x)), _lib.NHWC, ptr(dev(w)), ptr(dev(b)), ptr(y), _lib.NCHW, N, C, 8, 8, C, _lib.ACT_RELU, stream())
+        check(y, torch.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)), what="conv fwd -> NCHW")
+        # convT 4x4 -> 8x8: dgrad takes dy[N,8,8,32] back to dx[N,32,4,4] (NCHW), masked by the NCHW activation
+        xa = torch.relu(_rand(N, C, 4, 4, seed=5))
+        wt = _rand(C, C, 4, 4, seed=6, scale=0.2)
+        dy = _rand(N, C, 8, 8, seed=7)
+        xr = xa.double().requires_grad_(True)
+        F.conv_transpose2d(xr, wt.double(), None, stride=2, padding=1).backward(dy.double())
+        dx = torch.empty(N, C, 4, 4, device=DEV)
+        call("dvae_convT4s2_dgrad", ptr(nhwc(dy)), _lib.NHWC, ptr(dev(wt)), ptr(dev(xa)), ptr(dx), _lib.NCHW, N, C, 4, 4, C, stream())
+        check(dx, xr.grad * (xa > 0), what="convT dgrad -> NCHW")
