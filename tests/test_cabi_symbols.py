@@ -38,3 +38,15 @@ def test_argument_errors_are_reported():
         assert "invalid argument" in str(e)
     else:
         raise AssertionError("expected DvaeHipError")
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() is what the driver calls on the CPU box: it must compile (no-op when the
+    objects are current), load the library and agree with the header's DVAE_VERSION."""
+    import importlib
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = importlib.import_module("__graft_entry__")
+    g.build()
+    hdr = open(os.path.join(root, "include", "dvae_hip.h")).read()
+    assert int(re.search(r"#define DVAE_VERSION (\d+)", hdr).group(1)) == _lib.lib().dvae_version()
