@@ -43,6 +43,10 @@ static int run_up(const ConvArgs& a, hipStream_t s) {
 }
 static int run_wgrad(const float* big, int big_layout, const float* small, int small_layout, float* dw, float* db,
                      int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws, float* ws, hipStream_t s) {
+  // the small side of the 4x4 end of the conv stack may be NCHW (= the FC stack's (c,h,w) order)
+  if (!use_generic_only() && ws != nullptr && Hs == Ws && Cs == 32 && Cb == 32 && big_layout == DVAE_NHWC && Hs == 4 &&
+      small_layout == DVAE_NCHW)
+    return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s, 1);
   if (!use_generic_only() && ws != nullptr && Hs == Ws && Cs == 32 && small_layout == DVAE_NHWC) {
     if (Cb == 32 && big_layout == DVAE_NHWC && (Hs == 4 || Hs == 8 || Hs == 16))
       return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s);

@@ -107,7 +107,7 @@ int launch_wgrad_generic(const float* big, int big_layout, const float* small, i
 int launch_down_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_up_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big,
-                        int N, int Hs, float* ws, hipStream_t s);
+                        int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0);
 // thin paths (Cb in {1,3}, Cs == 32, big NCHW 64x64 / small NHWC 32x32)
 int launch_down_thin(const ConvArgs& a, hipStream_t s);
 int launch_up_thin(const ConvArgs& a, hipStream_t s);

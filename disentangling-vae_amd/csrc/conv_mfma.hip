@@ -106,8 +106,11 @@ __device__ __forceinline__ void store_big(const f32x4 (&pf)[NPF], const SlotDesc
     if (d.lds[k] >= 0) *reinterpret_cast<f32x4*>(bt + d.lds[k]) = pf[k];
 }
 
+// small_nchw: the small tensor is [N][32][HS*HS] (the FC stack's (c,h,w) order at the 4x4 end of the
+// network) instead of NHWC: a 16-byte LDS slot = 4 channels of one pixel is then gathered with four
+// 4-byte loads HS*HS floats apart (the tensor is 2 KB per image).
 template <int HS>
-__device__ __forceinline__ void init_small_slots(SlotDesc<Geo<HS>::SH_NPF>& d, int tid) {
+__device__ __forceinline__ void init_small_slots(SlotDesc<Geo<HS>::SH_NPF>& d, int tid, int small_nchw = 0) {
   using G = Geo<HS>;
 #pragma unroll
   for (int k = 0; k < G::SH_NPF; ++k) {
@@ -121,7 +124,8 @@ __device__ __forceinline__ void init_small_slots(SlotDesc<Geo<HS>::SH_NPF>& d, i
       int img = t / G::SROWS;
       int sx = col - 1;
       d.lds[k] = ((img * G::SROWS + row) * G::SCOLS + col) * 32 + ((chunk ^ swz_small<HS>(row, col)) << 2);
-      d.gofs[k] = ((img * HS + (row - 1)) * HS + sx) * 32 + chunk * 4;
+      d.gofs[k] = small_nchw ? ((img * 32 + chunk * 4) * HS + (row - 1)) * HS + sx
+                             : ((img * HS + (row - 1)) * HS + sx) * 32 + chunk * 4;
       d.rimg[k] = row | (img << 8) | ((sx >= 0 && sx < HS) ? (1 << 16) : 0);
     }
   }
@@ -129,19 +133,25 @@ __device__ __forceinline__ void init_small_slots(SlotDesc<Geo<HS>::SH_NPF>& d, i
 
 template <int HS>
 __device__ __forceinline__ void load_small_halo(f32x4 (&pf)[Geo<HS>::SH_NPF], const SlotDesc<Geo<HS>::SH_NPF>& d,
-                                                const float* __restrict__ small, int unit, int N) {
+                                                const float* __restrict__ small, int unit, int N, int small_nchw = 0) {
   using G = Geo<HS>;
   const long P0 = (long)unit * G::U;
   const int n0 = (int)(P0 / (HS * HS));
   const int sy0 = (int)(P0 % (HS * HS)) / HS;
-  const float* base = small + ((long)n0 * HS + sy0) * HS * 32;
+  const float* base = small_nchw ? small + (long)n0 * 32 * HS * HS + sy0 * HS : small + ((long)n0 * HS + sy0) * HS * 32;
 #pragma unroll
   for (int k = 0; k < G::SH_NPF; ++k) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int row = d.rimg[k] & 0xff, img = (d.rimg[k] >> 8) & 0xff;
     const int sy = sy0 - 1 + row;
-    if ((d.rimg[k] >> 16) && n0 + img < N && sy >= 0 && sy < HS)
-      v = *reinterpret_cast<const f32x4*>(base + d.gofs[k]);
+    if ((d.rimg[k] >> 16) && n0 + img < N && sy >= 0 && sy < HS) {
+      if (small_nchw) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = base[d.gofs[k] + u * HS * HS];
+      } else {
+        v = *reinterpret_cast<const f32x4*>(base + d.gofs[k]);
+      }
+    }
     pf[k] = v;
   }
 }
@@ -558,7 +568,8 @@ __device__ __forceinline__ void up_store(const float (&vals)[16], float* __restr
 template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, const float* __restrict__ w,
                                               const float* __restrict__ bias, const float* __restrict__ mask,
-                                              float* __restrict__ out, int N, int act, int n_units) {
+                                              float* __restrict__ out, int N, int act, int n_units,
+                                              int small_nchw) {
   using G = Geo<HS>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;              // 16384 floats
@@ -571,10 +582,10 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
   const int img_l = p / (G::R * HS), m = (p / HS) % G::R, l = p % HS;
 
   SlotDesc<G::SH_NPF> sd;
-  init_small_slots<HS>(sd, tid);
+  init_small_slots<HS>(sd, tid, small_nchw);
   f32x4 pf[G::SH_NPF];
   int unit = blockIdx.x;
-  if (unit < n_units) load_small_halo<HS>(pf, sd, small, unit, N);
+  if (unit < n_units) load_small_halo<HS>(pf, sd, small, unit, N, small_nchw);
   stage_weights<false>(w, wl, tid);
   const float bv = bias ? bias[i] : 0.f;
   float vals[16];
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
     __syncthreads();  // previous unit's reads of st are complete
     store_small_halo<HS>(pf, sd, st);
     __syncthreads();
-    if (unit + (int)gridDim.x < n_units) load_small_halo<HS>(pf, sd, small, unit + gridDim.x, N);
+    if (unit + (int)gridDim.x < n_units) load_small_halo<HS>(pf, sd, small, unit + gridDim.x, N, small_nchw);
     float mv[16];
     if (MASK) {       // prefetch the ReLU mask of this unit (consumed after the MFMA phase)
       long offs[16];
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
 #define WG_STRIDE (16384 + 320)
 template <int HS>
 __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, const float* __restrict__ small,
-                                                 float* __restrict__ ws, int N, int n_units) {
+                                                 float* __restrict__ ws, int N, int n_units, int small_nchw) {
   using G = Geo<HS>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* bt = smem;                     // G::BIG_FLOATS
@@ -670,7 +681,16 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
   auto load_sp = [&](int u) {
     long e0 = (long)u * G::U * 32 + tid * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (e0 < npix * 32) v = *reinterpret_cast<const f32x4*>(small + e0);
+    if (e0 < npix * 32) {
+      if (small_nchw) {                  // [N][32][HS*HS]: pixel e0/32, channels e0%32 .. +3, HS*HS floats apart
+        const long pg = e0 >> 5;
+        const float* src = small + ((pg / (HS * HS)) * 32 + (e0 & 31)) * (HS * HS) + pg % (HS * HS);
+#pragma unroll
+        for (int u2 = 0; u2 < 4; ++u2) v[u2] = src[u2 * HS * HS];
+      } else {
+        v = *reinterpret_cast<const f32x4*>(small + e0);
+      }
+    }
     pfs = v;
   };
   if (unit < n_units) { load_big<HS>(pf, sd, big, unit, N); load_sp(unit); }
@@ -870,15 +890,16 @@ static int launch_up_t(const ConvArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_up32<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  if (a.mask) hipLaunchKernelGGL((k_up32<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
-  else hipLaunchKernelGGL((k_up32<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+  const int small_nchw = a.small_layout == DVAE_NCHW;
+  if (a.mask) hipLaunchKernelGGL((k_up32<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, small_nchw);
+  else hipLaunchKernelGGL((k_up32<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, small_nchw);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
 
 template <int HS>
 static int launch_wgrad_t(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
-                          float* ws, hipStream_t s) {
+                          float* ws, hipStream_t s, int small_nchw) {
   using G = Geo<HS>;
   const int n_units = units_for(N, HS);
   // (capping the persistent grid to leave CUs to the dgrad stream was measured: 128 -> +10 % step time)
@@ -886,7 +907,7 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
   const size_t lds = (G::BIG_FLOATS + 64 * 32) * sizeof(float);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units);
+  hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units, small_nchw);
   DVAE_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_wgrad32_reduce, dim3(1024 + 2), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   DVAE_CHECK_LAUNCH();
@@ -915,7 +936,9 @@ int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_up_mfma32(const ConvArgs& a, hipStream_t s) {
-  if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.small_layout, a.out_layout, DVAE_NHWC)) return 1;
+  // the 4x4 end of the conv stack may be read NCHW (= the FC stack's (c,h,w) order)
+  const int small_l = (a.Hs == 4 && a.small_layout == DVAE_NCHW) ? DVAE_NHWC : a.small_layout;
+  if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, small_l, a.out_layout, DVAE_NHWC)) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
   switch (a.Hs) {
     case 16: return launch_up_t<16>(a, s);
@@ -925,11 +948,11 @@ int launch_up_mfma32(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
-                        int Hs, float* ws, hipStream_t s) {
+                        int Hs, float* ws, hipStream_t s, int small_nchw) {
   switch (Hs) {
-    case 16: return launch_wgrad_t<16>(big, small, dw, db, bias_from_big, N, ws, s);
-    case 8: return launch_wgrad_t<8>(big, small, dw, db, bias_from_big, N, ws, s);
-    case 4: return launch_wgrad_t<4>(big, small, dw, db, bias_from_big, N, ws, s);
+    case 16: return launch_wgrad_t<16>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
+    case 8: return launch_wgrad_t<8>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
+    case 4: return launch_wgrad_t<4>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
     default: return 1;
   }
 }

@@ -130,7 +130,6 @@ class _Buffers:
         self.mu, self.logvar, self.z = f(B, D), f(B, D), f(B, D)
         self.d1, self.d2, self.d3 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM), f(B, HID * 16)
         self.gd1, self.gd2, self.gd3 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM), f(B, HID * 16)
-        self.d3n, self.gd3n = f(B, 4, 4, HID), f(B, 4, 4, HID)
         self.dec_act = [f(B, h, h, HID) for h in eng.dec_sizes]       # NHWC outputs of the hidden convT layers
         self.dec_gact = [f(B, h, h, HID) for h in eng.dec_sizes]
         c, hh, ww = eng.img_size
@@ -254,12 +253,13 @@ class VAEEngine:
              ptr(buf.d2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, ws, s)
         call("dvae_linear_fwd", ptr(buf.d2), ptr(self.p("decoder.lin3.weight")), ptr(self.p("decoder.lin3.bias")),
              ptr(buf.d3), B, HIDDEN_DIM, HID * 16, ACT_RELU, ws, s)
-        call("dvae_relayout", ptr(buf.d3), NCHW, ptr(buf.d3n), B, HID, 4, 4, s)
-        src, h = buf.d3n, 4
+        # lin3's output [B, 32*4*4] in (c,h,w) order IS the NCHW 4x4x32 input of the first convT
+        # (decoders.py:74): read as such, no relayout pass
+        src, src_layout, h = buf.d3, NCHW, 4
         for name, act in zip(self.dec_names, buf.dec_act):
-            call("dvae_convT4s2_fwd", ptr(src), NHWC, ptr(self.p("decoder.%s.weight" % name)),
+            call("dvae_convT4s2_fwd", ptr(src), src_layout, ptr(self.p("decoder.%s.weight" % name)),
                  ptr(self.p("decoder.%s.bias" % name)), ptr(act), NHWC, B, HID, h, h, HID, ACT_RELU, s)
-            src, h = act, h * 2
+            src, src_layout, h = act, NHWC, h * 2
         c = self.img_size[0]
         if fuse_loss is None:
             call("dvae_convT4s2_fwd", ptr(src), NHWC, ptr(self.p("decoder.convT3.weight")),
@@ -278,8 +278,8 @@ class VAEEngine:
         D = self.latent_dim
         c = self.img_size[0]
         ws = ptr(self._ws)
-        acts = [buf.d3n] + buf.dec_act          # inputs of convT_64/convT1/convT2/convT3
-        gacts = [buf.gd3n] + buf.dec_gact
+        acts = [buf.d3] + buf.dec_act           # inputs of convT_64/convT1/convT2/convT3 (the first one NCHW = lin3's output)
+        gacts = [buf.gd3] + buf.dec_gact
         names = self.dec_names + ["convT3"]
         couts = [HID] * len(self.dec_names) + [c]
         hs = [4 << i for i in range(len(names))]  # input H of each convT
@@ -292,7 +292,7 @@ class VAEEngine:
         pending, deferred, queued = [], [], []
         for k in range(len(names) - 1, -1, -1):
             name, x_in, gx, h = names[k], acts[k], gacts[k], hs[k]
-            wargs = ("dvae_convT4s2_wgrad", ptr(x_in), NHWC, ptr(dy), dy_layout,
+            wargs = ("dvae_convT4s2_wgrad", ptr(x_in), NCHW if k == 0 else NHWC, ptr(dy), dy_layout,
                      ptr(self.g("decoder.%s.weight" % name)), ptr(self.g("decoder.%s.bias" % name)),
                      B, HID, h, h, couts[k])
             (pending if h >= 16 else deferred).append(wargs)
@@ -349,7 +349,6 @@ class VAEEngine:
                     lambda: self._side_wgrad(buf.a_flat, buf.gh1, self.g("encoder.lin1.weight"), self.g("encoder.lin1.bias"),
                                              B, HID * 16, HIDDEN_DIM)]
         last = len(self.enc_names) - 1
-        call("dvae_relayout", ptr(buf.ga_flat), NCHW, ptr(buf.enc_gact[last]), B, HID, 4, 4, s)
         for k in range(last, -1, -1):
             name = self.enc_names[k]
             h_in = self.enc_sizes[k] * 2
@@ -357,11 +356,12 @@ class VAEEngine:
                 x_in, x_layout, cin = buf.enc_act[k - 1], NHWC, HID
             else:
                 x_in, x_layout, cin = x, NCHW, c
-            dy = buf.enc_gact[k]
+            # the last conv's output gradient is lin1's input gradient, (c,h,w) order = NCHW 4x4x32: read as such
+            dy, dy_layout = (buf.ga_flat, NCHW) if k == last else (buf.enc_gact[k], NHWC)
             # forks: one before the first big layer (h_in >= 32; the small layers' weight gradients ride
             # along with it), one per big layer after that
             big = h_in >= 32
-            wargs = ("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), NHWC,
+            wargs = ("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), dy_layout,
                      ptr(self.g("encoder.%s.weight" % name)), ptr(self.g("encoder.%s.bias" % name)),
                      B, cin, h_in, h_in, HID)
             side = []
@@ -378,7 +378,7 @@ class VAEEngine:
             else:
                 deferred.append(lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False))
             if k > 0:                            # this stream's next kernel first, then the side launches
-                call("dvae_conv4s2_dgrad", ptr(dy), NHWC, ptr(self.p("encoder.%s.weight" % name)), ptr(x_in),
+                call("dvae_conv4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("encoder.%s.weight" % name)), ptr(x_in),
                      ptr(buf.enc_gact[k - 1]), NHWC, B, cin, h_in, h_in, HID, s)
             for launch in side:
                 launch()

@@ -377,3 +377,42 @@ def test_4x4_end_of_the_conv_stack_writes_nchw(N, generic):
         dx = torch.empty(N, C, 4, 4, device=DEV)
         call("dvae_convT4s2_dgrad", ptr(nhwc(dy)), _lib.NHWC, ptr(dev(wt)), ptr(dev(xa)), ptr(dx), _lib.NCHW, N, C, 4, 4, C, stream())
         check(dx, xr.grad * (xa > 0), what="convT dgrad -> NCHW")
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("N", [3, 7, 70])
+def test_4x4_end_of_the_conv_stack_reads_nchw(N, generic):
+    """The first decoder convT reads its 4x4x32 input NCHW (= lin3's output, decoders.py:74), and the last
+    encoder conv's backward reads its 4x4x32 output gradient NCHW (= lin1's input gradient): forward, dgrad and
+    both weight gradients, tuned MFMA kernels and generic kernels, vs torch."""
+    C = 32
+    ws = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), device=DEV)
+    with force_generic(generic):
+        # ---- convT 4x4 -> 8x8 with NCHW input
+        x = torch.relu(_rand(N, C, 4, 4, seed=1))
+        w = _rand(C, C, 4, 4, seed=2, scale=0.2)
+        b = _rand(C, seed=3, scale=0.1)
+        y = torch.empty(N, 8, 8, C, device=DEV)
+        call("dvae_convT4s2_fwd", ptr(dev(x)), _lib.NCHW, ptr(dev(w)), ptr(dev(b)), ptr(y), _lib.NHWC, N, C, 4, 4, C, _lib.ACT_RELU, stream())
+        xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+        pre = F.conv_transpose2d(xr, wr, br, stride=2, padding=1)
+        check(from_nhwc(y, N, C, 8, 8), torch.relu(pre), what="convT fwd <- NCHW")
+        dy = _rand(N, C, 8, 8, seed=4)
+        pre.backward(dy.double())
+        dw, db = torch.full((C, C, 4, 4), 7.0, device=DEV), torch.full((C,), 7.0, device=DEV)
+        call("dvae_convT4s2_wgrad", ptr(dev(x)), _lib.NCHW, ptr(nhwc(dy)), _lib.NHWC, ptr(dw), ptr(db), N, C, 4, 4, C, ptr(ws), stream())
+        check(dw, wr.grad, what="convT wgrad <- NCHW x")
+        check(db, br.grad, what="convT bias grad")
+        # ---- conv 8x8 -> 4x4 backward with the NCHW output gradient
+        xin = torch.relu(_rand(N, C, 8, 8, seed=5))
+        w2 = _rand(C, C, 4, 4, seed=6, scale=0.2)
+        g = _rand(N, C, 4, 4, seed=7)
+        xr2, wr2, br2 = xin.double().requires_grad_(True), w2.double().requires_grad_(True), torch.zeros(C, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr2, wr2, br2, stride=2, padding=1).backward(g.double())
+        dx = torch.empty(N, 8, 8, C, device=DEV)
+        call("dvae_conv4s2_dgrad", ptr(dev(g)), _lib.NCHW, ptr(dev(w2)), ptr(nhwc(xin)), ptr(dx), _lib.NHWC, N, C, 8, 8, C, stream())
+        check(from_nhwc(dx, N, C, 8, 8), xr2.grad * (xin > 0), what="conv dgrad <- NCHW dy")
+        dw2, db2 = torch.full((C, C, 4, 4), 7.0, device=DEV), torch.full((C,), 7.0, device=DEV)
+        call("dvae_conv4s2_wgrad", ptr(nhwc(xin)), _lib.NHWC, ptr(dev(g)), _lib.NCHW, ptr(dw2), ptr(db2), N, C, 8, 8, C, ptr(ws), stream())
+        check(dw2, wr2.grad, what="conv wgrad <- NCHW dy")
+        check(db2, br2.grad, what="conv bias grad <- NCHW dy")
