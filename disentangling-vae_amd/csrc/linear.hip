@@ -465,16 +465,18 @@ __global__ __launch_bounds__(256) void k_fcw32(const float* __restrict__ dy, con
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
   float rs = 0.f;
+  // unconditional loads (clamped rows); rows beyond M are zeroed when the slab is written to LDS, so that the
+  // prefetched registers are not touched (no s_waitcnt vmcnt) during the MFMA phase of the previous slab
   f32x4 ra[NB], rb[NB];
+  int mload = 0;
   auto load = [&](int m0) {
+    mload = m0;
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int m = m0 + (tid >> 3) + 32 * p;
       const long mm = m < M ? m : M - 1;
-      const f32x4 va = *reinterpret_cast<const f32x4*>(pa + mm * N);
-      const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + mm * K);
-      ra[p] = (m < M && okA) ? va : f32x4{0.f, 0.f, 0.f, 0.f};
-      rb[p] = (m < M && okB) ? vb : f32x4{0.f, 0.f, 0.f, 0.f};
+      ra[p] = *reinterpret_cast<const f32x4*>(pa + mm * N);
+      rb[p] = *reinterpret_cast<const f32x4*>(pb + mm * K);
     }
   };
   const int kap0 = (2 * wv + h) * S;
@@ -486,8 +488,10 @@ __global__ __launch_bounds__(256) void k_fcw32(const float* __restrict__ dy, con
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int kap = (tid >> 3) + 32 * p;
-      *reinterpret_cast<f32x4*>(As + (kap + kap / S) * 32 + j4) = ra[p];
-      *reinterpret_cast<f32x4*>(Bs + (kap + kap / S) * 32 + j4) = rb[p];
+      const bool in = mload + kap < M;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(As + (kap + kap / S) * 32 + j4) = (in && okA) ? ra[p] : zero;
+      *reinterpret_cast<f32x4*>(Bs + (kap + kap / S) * 32 + j4) = (in && okB) ? rb[p] : zero;
     }
     __syncthreads();
     if (m0 + KP < M) load(m0 + KP);
@@ -545,6 +549,172 @@ static bool try_fcw32(const float* x, const float* dy, float* dw, float* db, int
     }
     hipLaunchKernelGGL((k_fcw32<KP>), grid, dim3(256), lds, s, dy, x, dw, db, M, N, K);
   }
+  return true;
+}
+
+// ---- large FC GEMM (the 1000-wide discriminator layers): TM x 64 output tile, contraction in slabs of 64 ----
+// 4 waves; wave w owns rows (w&1)*TM/2 .. +TM/2 and columns (w>>1)*32 .. +32 of the tile, i.e. TM/64 accumulators of
+// 32x32 that share one B fragment.  Operand tiles are double-buffered in LDS ([row][64+4] images, 16-byte operand
+// reads through the permuted contraction index kappa = h*32 + t of k_fc32; the j-fast B of the dgrad form as a
+// [kappa][64] image whose upper half is skewed by 32 floats so that the two lane halves use disjoint banks); the
+// next slab's global loads are issued before the MFMA phase of the current one; ONE barrier per slab.
+//   A(i,k) = a[i*lda + k];  B_JFAST ? B(k,j) = b[k*ldb + j] (dgrad)  :  B(k,j) = b[j*ldb + k] (forward)
+template <int TM, bool B_JFAST>
+__global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                  float* __restrict__ c, long ldc, int M, int N, int Kc,
+                                                  const float* __restrict__ bias, int act,
+                                                  const float* __restrict__ mask, int mask_act) {
+  extern __shared__ __attribute__((aligned(16))) float fc_lds[];
+  constexpr int KS = 64, SA = KS + 4;
+  constexpr int A_FLOATS = TM * SA;
+  constexpr int B_FLOATS = B_JFAST ? KS * 64 + 32 : 64 * SA;
+  constexpr int NLA = TM / 16;             // 16-byte loads per thread for the A slab (TM rows x 16 chunks / 256)
+  constexpr int NACC = TM / 64;            // 32-row blocks per wave
+  float* As = fc_lds;                      // [2][A_FLOATS]
+  float* Bs = fc_lds + 2 * A_FLOATS;       // [2][B_FLOATS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 64;
+  const int r0 = (wv & 1) * (TM / 2), c0 = (wv >> 1) * 32;
+
+  // Loads are unconditional (clamped addresses); the out-of-range zeroing happens in store(), AFTER the MFMA
+  // phase, so that nothing touches the loaded registers (= no s_waitcnt vmcnt) while the matrix core works.
+  f32x4 ra[NLA], rb[4];
+  unsigned oka = 0, okb = 0;
+  auto load = [&](int k0) {
+    oka = 0; okb = 0;
+#pragma unroll
+    for (int p = 0; p < NLA; ++p) {
+      const int idx = tid + 256 * p;
+      const int row = idx >> 4, kk = k0 + (idx & 15) * 4;
+      const int gi = m0 + row;
+      ra[p] = *reinterpret_cast<const f32x4*>(a + (long)(gi < M ? gi : M - 1) * lda + (kk < Kc ? kk : 0));
+      oka |= (unsigned)(gi < M && kk < Kc) << p;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int idx = tid + 256 * p;
+      if (!B_JFAST) {
+        const int row = idx >> 4, kk = k0 + (idx & 15) * 4;
+        const int gj = n0 + row;
+        rb[p] = *reinterpret_cast<const f32x4*>(b + (long)(gj < N ? gj : N - 1) * ldb + (kk < Kc ? kk : 0));
+        okb |= (unsigned)(gj < N && kk < Kc) << p;
+      } else {
+        const int kap = k0 + (idx >> 4), gj = n0 + (idx & 15) * 4;
+        rb[p] = *reinterpret_cast<const f32x4*>(b + (long)(kap < Kc ? kap : 0) * ldb + (gj < N ? gj : 0));
+        okb |= (unsigned)(kap < Kc && gj < N) << p;                         // N % 4 == 0
+      }
+    }
+  };
+  auto store = [&](int bufi) {
+    float* Ab = As + bufi * A_FLOATS;
+    float* Bb = Bs + bufi * B_FLOATS;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < NLA; ++p) {
+      const int idx = tid + 256 * p;
+      *reinterpret_cast<f32x4*>(Ab + (idx >> 4) * SA + (idx & 15) * 4) = ((oka >> p) & 1) ? ra[p] : zero;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int idx = tid + 256 * p;
+      const f32x4 v = ((okb >> p) & 1) ? rb[p] : zero;
+      if (!B_JFAST) *reinterpret_cast<f32x4*>(Bb + (idx >> 4) * SA + (idx & 15) * 4) = v;
+      else { const int kap = idx >> 4; *reinterpret_cast<f32x4*>(Bb + kap * 64 + (kap >= 32 ? 32 : 0) + (idx & 15) * 4) = v; }
+    }
+  };
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int q = 0; q < NACC; ++q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+
+  const int nslab = (Kc + KS - 1) / KS;
+  load(0);
+  store(0);
+  __syncthreads();
+  for (int sl = 0; sl < nslab; ++sl) {
+    if (sl + 1 < nslab) load((sl + 1) * KS);
+    const float* Ab = As + (sl & 1) * A_FLOATS + (r0 + i) * SA + h * 32;
+    const float* Bb = Bs + (sl & 1) * B_FLOATS + (B_JFAST ? h * (32 * 64 + 32) + c0 + i : (c0 + i) * SA + h * 32);
+    // operand registers are double-buffered: the LDS reads of step q+1 are issued before the MFMAs of step q
+    f32x4 av[2][NACC], bv[2];
+    auto rd = [&](int q, int slot) {
+#pragma unroll
+      for (int t = 0; t < NACC; ++t) av[slot][t] = *reinterpret_cast<const f32x4*>(Ab + t * 32 * SA + 4 * q);
+      if (B_JFAST) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bv[slot][u] = Bb[(4 * q + u) * 64];
+      } else {
+        bv[slot] = *reinterpret_cast<const f32x4*>(Bb + 4 * q);
+      }
+    };
+    constexpr int NRD = NACC + (B_JFAST ? 4 : 1);       // LDS reads per step
+    rd(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q + 1 < 8) rd(q + 1, (q + 1) & 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < NACC; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][t][u], bv[q & 1][u], acc[t], 0, 0, 0);
+      // pin the order: reads of step q+1, THEN the MFMAs of step q (the scheduler otherwise re-serialises them)
+      if (q + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NACC, 0);
+    }
+    if (sl + 1 < nslab) store((sl + 1) & 1);
+    __syncthreads();
+  }
+
+  const int col = n0 + c0 + i;
+#pragma unroll
+  for (int t = 0; t < NACC; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + r0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row < M && col < N) {
+        float v = acc[t][e];
+        if (bias) v += bias[col];
+        if (act == DVAE_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == DVAE_ACT_LEAKY02) v = v > 0.f ? v : 0.2f * v;
+        const long o = (long)row * ldc + col;
+        if (mask) {
+          const float mv = mask[o];
+          if (mask_act == DVAE_ACT_RELU) v = mv > 0.f ? v : 0.f;
+          else if (mask_act == DVAE_ACT_LEAKY02) v = mv > 0.f ? v : 0.2f * v;
+        }
+        c[o] = v;
+      }
+    }
+}
+
+template <int TM, bool BJ>
+static void launch_gemm_big_t(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
+                              const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
+  const size_t lds = sizeof(float) * 2 * (TM * 68 + (BJ ? 64 * 64 + 32 : 64 * 68));
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_gemm_big<TM, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_gemm_big<TM, BJ>), dim3((N + 63) / 64, (M + TM - 1) / TM), dim3(256), lds, s, a, lda, b, ldb, c, ldc,
+                     M, N, Kc, bias, act, mask, mask_act);
+}
+
+// true if the launch was taken: long contractions and wide outputs with 16-byte-aligned rows
+template <bool BJ>
+static bool try_gemm_big(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
+                         const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
+  static const bool off = getenv("DVAE_GEMM_BIG") && getenv("DVAE_GEMM_BIG")[0] == '0';
+  if (off || Kc < 256 || N < 128 || Kc % 4 || lda % 4 || ldb % 4 || (BJ && N % 4)) return false;
+  if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return false;
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 63) / 64);
+  if (tiles128 >= 224) launch_gemm_big_t<128, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
+  else launch_gemm_big_t<64, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
   return true;
 }
 
@@ -612,7 +782,8 @@ static int pick_split(int tiles, int Kc, size_t out_elems, float* ws, size_t ws_
 int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, float* ws,
                       size_t ws_floats, hipStream_t s) {
   // A = x (k contiguous), B(k,j) = w[j*K + k] (k contiguous)
-  if (try_fc32<false>(x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s)) {
+  if (try_fc32<false>(x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s) ||
+      try_gemm_big<false>(x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s)) {
     DVAE_CHECK_LAUNCH();
     return 0;
   }
@@ -649,7 +820,8 @@ int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, 
 int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
                         float* ws, size_t ws_floats, hipStream_t s) {
   // dx[M,K] = dy[M,N] w[N,K]: contraction length N
-  if (try_fc32<true>(dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s)) {
+  if (try_fc32<true>(dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s) ||
+      try_gemm_big<true>(dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s)) {
     DVAE_CHECK_LAUNCH();
     return 0;
   }
