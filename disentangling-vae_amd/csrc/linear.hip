@@ -7,6 +7,7 @@
 // 64x64 output tile per 256-thread workgroup (2x2 waves of one 32x32 MFMA accumulator each),
 // K staged through LDS in slices of 32 with register prefetch of the next slice.
 #include <stdint.h>
+#include <type_traits>
 #include <stdlib.h>
 #include "common.h"
 
@@ -556,72 +557,82 @@ static bool try_fcw32(const float* x, const float* dy, float* dw, float* db, int
 // 4 waves; wave w owns rows (w&1)*TM/2 .. +TM/2 and columns (w>>1)*32 .. +32 of the tile, i.e. TM/64 accumulators of
 // 32x32 that share one B fragment.  Operand tiles are double-buffered in LDS ([row][64+4] images, 16-byte operand
 // reads through the permuted contraction index kappa = h*32 + t of k_fc32; the j-fast B of the dgrad form as a
-// [kappa][64] image whose upper half is skewed by 32 floats so that the two lane halves use disjoint banks); the
-// next slab's global loads are issued before the MFMA phase of the current one; ONE barrier per slab.
+// [kappa][64] image whose upper half is skewed by 32 floats so that the two lane halves use disjoint banks).
 //   A(i,k) = a[i*lda + k];  B_JFAST ? B(k,j) = b[k*ldb + j] (dgrad)  :  B(k,j) = b[j*ldb + k] (forward)
+// Memory pipeline interleaved into the MFMA stream.  PMC on a phase-separated version of this kernel
+// (profiles/r01_run41_gemm_pmc.txt): 43 % MFMA-busy; the one wave per SIMD spent half of its cycles outside the
+// MFMA phase (address arithmetic, global-load issue, predication, LDS stores, barrier).  A wave is in-order, but
+// while an MFMA occupies the pipe (64 cycles) it can issue other work for free.  Slab j lives in register set
+// j&1 and LDS image j&1; iteration s
+// multiplies slab s while it ISSUES the global loads of slab s+2 between its first MFMAs and WRITES slab s+1
+// (loaded one iteration earlier: two-slab prefetch distance, longer than the memory latency) to LDS between its
+// later MFMAs -- the order is pinned with sched_group_barrier.  Rows / columns outside the matrices are read from
+// clamped addresses (they only feed outputs that are never stored); only A's contraction tail is zeroed.
 template <int TM, bool B_JFAST>
 __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
-                                                  float* __restrict__ c, long ldc, int M, int N, int Kc,
-                                                  const float* __restrict__ bias, int act,
-                                                  const float* __restrict__ mask, int mask_act) {
+                                                 float* __restrict__ c, long ldc, int M, int N, int Kc,
+                                                 const float* __restrict__ bias, int act,
+                                                 const float* __restrict__ mask, int mask_act) {
   extern __shared__ __attribute__((aligned(16))) float fc_lds[];
   constexpr int KS = 64, SA = KS + 4;
   constexpr int A_FLOATS = TM * SA;
   constexpr int B_FLOATS = B_JFAST ? KS * 64 + 32 : 64 * SA;
-  constexpr int NLA = TM / 16;             // 16-byte loads per thread for the A slab (TM rows x 16 chunks / 256)
-  constexpr int NACC = TM / 64;            // 32-row blocks per wave
-  float* As = fc_lds;                      // [2][A_FLOATS]
-  float* Bs = fc_lds + 2 * A_FLOATS;       // [2][B_FLOATS]
+  constexpr int NLA = TM / 16, NLB = 4, NACC = TM / 64;
+  float* As = fc_lds;
+  float* Bs = fc_lds + 2 * A_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * 64;
+  int tm, tn;
+  {
+    const int tiles_n = gridDim.x, T = gridDim.x * gridDim.y;
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3, per = T >> 3, rem = T & 7;
+    const int t = xcd * per + (xcd < rem ? xcd : rem) + slot;
+    tm = t / tiles_n; tn = t - tm * tiles_n;
+  }
+  const int m0 = tm * TM, n0 = tn * 64;
   const int r0 = (wv & 1) * (TM / 2), c0 = (wv >> 1) * 32;
+  const int trow = tid >> 4, c4 = (tid & 15) * 4;          // this thread's row (+16p) and 16-byte column in a slab
 
-  // Loads are unconditional (clamped addresses); the out-of-range zeroing happens in store(), AFTER the MFMA
-  // phase, so that nothing touches the loaded registers (= no s_waitcnt vmcnt) while the matrix core works.
-  f32x4 ra[NLA], rb[4];
-  unsigned oka = 0, okb = 0;
-  auto load = [&](int k0) {
-    oka = 0; okb = 0;
+  // invariant source pointers (slab offset added per load)
+  const float* pa[NLA];
 #pragma unroll
-    for (int p = 0; p < NLA; ++p) {
-      const int idx = tid + 256 * p;
-      const int row = idx >> 4, kk = k0 + (idx & 15) * 4;
-      const int gi = m0 + row;
-      ra[p] = *reinterpret_cast<const f32x4*>(a + (long)(gi < M ? gi : M - 1) * lda + (kk < Kc ? kk : 0));
-      oka |= (unsigned)(gi < M && kk < Kc) << p;
-    }
+  for (int p = 0; p < NLA; ++p) { const int gi = m0 + trow + 16 * p; pa[p] = a + (long)(gi < M ? gi : M - 1) * lda + c4; }
+  const float* pb[NLB];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int idx = tid + 256 * p;
-      if (!B_JFAST) {
-        const int row = idx >> 4, kk = k0 + (idx & 15) * 4;
-        const int gj = n0 + row;
-        rb[p] = *reinterpret_cast<const f32x4*>(b + (long)(gj < N ? gj : N - 1) * ldb + (kk < Kc ? kk : 0));
-        okb |= (unsigned)(gj < N && kk < Kc) << p;
-      } else {
-        const int kap = k0 + (idx >> 4), gj = n0 + (idx & 15) * 4;
-        rb[p] = *reinterpret_cast<const f32x4*>(b + (long)(kap < Kc ? kap : 0) * ldb + (gj < N ? gj : 0));
-        okb |= (unsigned)(kap < Kc && gj < N) << p;                         // N % 4 == 0
-      }
+  for (int p = 0; p < NLB; ++p) {
+    if (!B_JFAST) { const int gj = n0 + trow + 16 * p; pb[p] = b + (long)(gj < N ? gj : N - 1) * ldb + c4; }
+    else { const int gj = n0 + c4; pb[p] = b + (long)(trow + 16 * p) * ldb + (gj < N ? gj : 0); }
+  }
+  f32x4 ra[2][NLA], rb[2][NLB];
+  bool okk[2];
+  const int klast = ((Kc + KS - 1) / KS - 1) * KS;
+
+  auto load = [&](auto PAR, int k0) {
+    constexpr int P = decltype(PAR)::value;
+    k0 = k0 < klast ? k0 : klast;                          // past the end: re-load the last slab (never used)
+    okk[P] = k0 + c4 < Kc;
+    const int ka = okk[P] ? k0 : -c4;                      // contraction tail: stay inside the row (value zeroed at the store)
+#pragma unroll
+    for (int p = 0; p < NLA; ++p) ra[P][p] = *reinterpret_cast<const f32x4*>(pa[p] + ka);
+#pragma unroll
+    for (int p = 0; p < NLB; ++p) {
+      if (!B_JFAST) rb[P][p] = *reinterpret_cast<const f32x4*>(pb[p] + ka);
+      else { const int kap = k0 + trow + 16 * p; rb[P][p] = *reinterpret_cast<const f32x4*>(pb[p] + (long)(kap < Kc ? k0 : -(trow + 16 * p)) * ldb); }
     }
   };
-  auto store = [&](int bufi) {
-    float* Ab = As + bufi * A_FLOATS;
-    float* Bb = Bs + bufi * B_FLOATS;
+  auto store = [&](auto PAR) {
+    constexpr int P = decltype(PAR)::value;
+    float* Ab = As + P * A_FLOATS;
+    float* Bb = Bs + P * B_FLOATS;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < NLA; ++p) {
-      const int idx = tid + 256 * p;
-      *reinterpret_cast<f32x4*>(Ab + (idx >> 4) * SA + (idx & 15) * 4) = ((oka >> p) & 1) ? ra[p] : zero;
-    }
+    for (int p = 0; p < NLA; ++p) *reinterpret_cast<f32x4*>(Ab + (trow + 16 * p) * SA + c4) = okk[P] ? ra[P][p] : zero;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int idx = tid + 256 * p;
-      const f32x4 v = ((okb >> p) & 1) ? rb[p] : zero;
-      if (!B_JFAST) *reinterpret_cast<f32x4*>(Bb + (idx >> 4) * SA + (idx & 15) * 4) = v;
-      else { const int kap = idx >> 4; *reinterpret_cast<f32x4*>(Bb + kap * 64 + (kap >= 32 ? 32 : 0) + (idx & 15) * 4) = v; }
+    for (int p = 0; p < NLB; ++p) {
+      if (!B_JFAST) *reinterpret_cast<f32x4*>(Bb + (trow + 16 * p) * SA + c4) = rb[P][p];
+      else { const int kap = trow + 16 * p; *reinterpret_cast<f32x4*>(Bb + kap * 64 + (kap >= 32 ? 32 : 0) + c4) = rb[P][p]; }
     }
   };
 
@@ -631,15 +642,11 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
 
-  const int nslab = (Kc + KS - 1) / KS;
-  load(0);
-  store(0);
-  __syncthreads();
-  for (int sl = 0; sl < nslab; ++sl) {
-    if (sl + 1 < nslab) load((sl + 1) * KS);
-    const float* Ab = As + (sl & 1) * A_FLOATS + (r0 + i) * SA + h * 32;
-    const float* Bb = Bs + (sl & 1) * B_FLOATS + (B_JFAST ? h * (32 * 64 + 32) + c0 + i : (c0 + i) * SA + h * 32);
-    // operand registers are double-buffered: the LDS reads of step q+1 are issued before the MFMAs of step q
+  auto body = [&](auto PAR, int sl) {
+    constexpr int P = decltype(PAR)::value;
+    load(PAR, (sl + 2) * KS);                                                // slab s+2 -> register set P
+    const float* Ab = As + P * A_FLOATS + (r0 + i) * SA + h * 32;
+    const float* Bb = Bs + P * B_FLOATS + (B_JFAST ? h * (32 * 64 + 32) + c0 + i : (c0 + i) * SA + h * 32);
     f32x4 av[2][NACC], bv[2];
     auto rd = [&](int q, int slot) {
 #pragma unroll
@@ -651,9 +658,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
         bv[slot] = *reinterpret_cast<const f32x4*>(Bb + 4 * q);
       }
     };
-    constexpr int NRD = NACC + (B_JFAST ? 4 : 1);       // LDS reads per step
     rd(0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       if (q + 1 < 8) rd(q + 1, (q + 1) & 1);
@@ -662,12 +667,38 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
 #pragma unroll
         for (int t = 0; t < NACC; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][t][u], bv[q & 1][u], acc[t], 0, 0, 0);
-      // pin the order: reads of step q+1, THEN the MFMAs of step q (the scheduler otherwise re-serialises them)
-      if (q + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NACC, 0);
     }
-    if (sl + 1 < nslab) store((sl + 1) & 1);
+    store(std::integral_constant<int, 1 - P>{});                             // slab s+1 (set 1-P) -> LDS image 1-P
+    // ---- the issue order of all of the above: one non-MFMA instruction group behind every MFMA
+    constexpr int NRD = NACC + (B_JFAST ? 4 : 1), NMF = 4 * NACC, NLD = NLA + NLB;
+    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);                     // reads of step 0
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);    // reads of step q+1
+#pragma unroll
+      for (int j = 0; j < NMF; ++j) {
+        const int slot = q * NMF + j;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (slot < NLD) {                                                    // global loads of slab s+2
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        } else if (slot >= 4 * NMF && slot < 4 * NMF + NLD) {                // LDS writes of slab s+1
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+    }
     __syncthreads();
+  };
+
+  const int nslab = (Kc + KS - 1) / KS;
+  load(std::integral_constant<int, 0>{}, 0);
+  store(std::integral_constant<int, 0>{});
+  load(std::integral_constant<int, 1>{}, KS);
+  __syncthreads();
+  for (int sl = 0; sl < nslab; sl += 2) {
+    body(std::integral_constant<int, 0>{}, sl);
+    if (sl + 1 < nslab) body(std::integral_constant<int, 1>{}, sl + 1);
   }
 
   const int col = n0 + c0 + i;
@@ -694,7 +725,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
 
 template <int TM, bool BJ>
 static void launch_gemm_big_t(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
-                              const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
+                             const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
   const size_t lds = sizeof(float) * 2 * (TM * 68 + (BJ ? 64 * 64 + 32 : 64 * 68));
   static bool attr = false;
   if (!attr) {
@@ -712,8 +743,9 @@ static bool try_gemm_big(const float* a, long lda, const float* b, long ldb, flo
   static const bool off = getenv("DVAE_GEMM_BIG") && getenv("DVAE_GEMM_BIG")[0] == '0';
   if (off || Kc < 256 || N < 128 || Kc % 4 || lda % 4 || ldb % 4 || (BJ && N % 4)) return false;
   if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return false;
-  const long tiles128 = (long)((M + 127) / 128) * ((N + 63) / 64);
-  if (tiles128 >= 224) launch_gemm_big_t<128, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
+  // TM = 64 -> 2 workgroups per CU (70 KB of LDS each): measured 76.7 vs 69.6 TFLOP/s for TM = 128 at 2048x1000x1000
+  static const int force_tm = getenv("DVAE_GEMM_TM") ? atoi(getenv("DVAE_GEMM_TM")) : 0;        // A/B switch
+  if (force_tm == 128) launch_gemm_big_t<128, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
   else launch_gemm_big_t<64, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
   return true;
 }
