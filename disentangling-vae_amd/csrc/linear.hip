@@ -642,9 +642,11 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
 
+  const int abl = act >> 8;                // timing ablations (tools/gemm_one.py): 1 no global loads, 2 no LDS stores, 4 no barriers
+  act &= 0xff;
   auto body = [&](auto PAR, int sl) {
     constexpr int P = decltype(PAR)::value;
-    load(PAR, (sl + 2) * KS);                                                // slab s+2 -> register set P
+    if (!(abl & 1)) load(PAR, (sl + 2) * KS);                                // slab s+2 -> register set P
     const float* Ab = As + P * A_FLOATS + (r0 + i) * SA + h * 32;
     const float* Bb = Bs + P * B_FLOATS + (B_JFAST ? h * (32 * 64 + 32) + c0 + i : (c0 + i) * SA + h * 32);
     f32x4 av[2][NACC], bv[2];
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
         for (int t = 0; t < NACC; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][t][u], bv[q & 1][u], acc[t], 0, 0, 0);
     }
-    store(std::integral_constant<int, 1 - P>{});                             // slab s+1 (set 1-P) -> LDS image 1-P
+    if (!(abl & 2)) store(std::integral_constant<int, 1 - P>{});             // slab s+1 (set 1-P) -> LDS image 1-P
     // ---- the issue order of all of the above: one non-MFMA instruction group behind every MFMA
     constexpr int NRD = NACC + (B_JFAST ? 4 : 1), NMF = 4 * NACC, NLD = NLA + NLB;
     __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);                     // reads of step 0
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
         }
       }
     }
-    __syncthreads();
+    if (!(abl & 4)) __syncthreads();
   };
 
   const int nslab = (Kc + KS - 1) / KS;
@@ -732,8 +734,9 @@ static void launch_gemm_big_t(const float* a, long lda, const float* b, long ldb
     (void)hipFuncSetAttribute((const void*)k_gemm_big<TM, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
+  static const int abl = getenv("DVAE_GEMM_ABLATE") ? atoi(getenv("DVAE_GEMM_ABLATE")) : 0;
   hipLaunchKernelGGL((k_gemm_big<TM, BJ>), dim3((N + 63) / 64, (M + TM - 1) / TM), dim3(256), lds, s, a, lda, b, ldb, c, ldc,
-                     M, N, Kc, bias, act, mask, mask_act);
+                     M, N, Kc, bias, act | (abl << 8), mask, mask_act);
 }
 
 // true if the launch was taken: long contractions and wide outputs with 16-byte-aligned rows
