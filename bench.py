@@ -132,6 +132,10 @@ def main():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (RCCL process group, "
+                    "collectives, barriers) even with ONE rank: exercises the N>1 path of this script on a single GPU")
+    ap.add_argument("--estimator", default="global", choices=["global", "local"],
+                    help="scope of the batch-coupled estimators under data parallelism (disvae_amd.parallel.data_parallel)")
     ap.add_argument("--replay", default=None, choices=["auto", "eager", "plan", "graph"],
                     help="how the launches of an iteration are issued (disvae_amd/graph.py)")
     args = ap.parse_args()
@@ -167,9 +171,12 @@ def main():
                       save_dir="/tmp/dvae_bench_%d" % rank, is_progress_bar=False,
                       replay=None if args.replay is None else (False if args.replay == "eager" else args.replay))
     model.train()
-    if world > 1:
+    ddp = world > 1 or args.force_ddp
+    if ddp:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         parallel.init_process_group_from_env("nccl")
-        parallel.data_parallel(model, loss_f)
+        parallel.data_parallel(model, loss_f, estimator=args.estimator)
     # synthetic batch, resident in HBM; every rank draws its own shard and its own device noise, while
     # the CPU generator (FactorVAE permutations, losses.py:505) stays identical on all ranks
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -178,7 +185,7 @@ def main():
     storer = defaultdict(list)
 
     def barrier():
-        if world > 1:
+        if ddp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -190,13 +197,31 @@ def main():
         loss = trainer._train_iteration_async(data, storer)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if ddp:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+
+    def flush_c_stdio():
+        # RCCL in this image prints a banner ("Hostname", "Librccl path") through C stdio, block-buffered on a pipe:
+        # it would otherwise surface at process exit, AFTER the result line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+
+    if ddp:
+        flush_c_stdio()
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        flush_c_stdio()
     if rank != 0:
         return
+    if world > 1:
+        time.sleep(1.0)      # (outside the timed region) let the other ranks exit: the JSON line is the LAST line of the job
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     flops_img = flops_per_image_train(args.channels)
@@ -210,6 +235,7 @@ def main():
                                "n_data=202599, fwd+loss+bwd+Adam%s" % (args.loss, args.channels, args.loss, B, B * world, lr,
                                                                       "+RCCL all-reduce" if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                   "estimator": args.estimator if ddp else None,
                    "final_loss": round(final_loss, 4)},
         "step_tflops": round(flops_img * B * world / (ms * 1e-3) / 1e12, 2) if args.loss != "factor" else None,
         "step_frac_of_fp32_peak": round(flops_img * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
@@ -219,7 +245,8 @@ def main():
         out["roofline"] = dominant_kernel_roofline(B if args.loss != "factor" else B // 2, device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.loss, img, B)
-    print(json.dumps(out))
+    flush_c_stdio()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
