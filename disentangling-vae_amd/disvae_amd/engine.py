@@ -4,9 +4,11 @@ This is plumbing only: torch tensors are used as device-memory containers, every
 the network runs in libdvae_hip.so through the C-ABI (``_lib.call``).  Layout contract:
   * API boundary (input batch, reconstruction): NCHW fp32, like the reference;
   * internal conv activations: NHWC (one pixel = one 128-byte line of 32 channels);
-  * the 4x4x32 tensor between the conv stack and the FC stack is re-laid-out to the
-    reference's (c,h,w) flatten order (encoders.py:80, decoders.py:74) so that lin1 / lin3
-    weights keep their state_dict layout.
+  * the 4x4x32 tensors between the conv stack and the FC stack are kept in the reference's
+    (c,h,w) flatten order (encoders.py:80, decoders.py:74) = NCHW, so that lin1 / lin3 weights
+    keep their state_dict layout; the conv kernels at that end read / write NCHW directly.
+Two streams: the caller's (critical path) and a side stream for everything that is only due at the
+end of the backward pass (weight gradients; the loss plugins also put the B x B estimator there).
 Reference being replaced: EncoderBurgess.forward (encoders.py:69-89), VAE.reparameterize
 (vae.py:52-71), DecoderBurgess.forward (decoders.py:67-84) and their autograd backward
 (training.py:157).
