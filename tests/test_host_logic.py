@@ -111,3 +111,43 @@ def test_checkpoint_roundtrip(tmp_path):
     for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
     assert not m2.training
+
+
+def test_launch_plan_record_and_replay_order():
+    """graph.StepGraphs mode "plan": the first call with a key executes AND records, later calls with the same key
+    re-issue the recorded entries in order without running the step function; a new key records again
+    (host logic only: python callables stand in for the C-ABI launches)."""
+    from disvae_amd import _lib
+    from disvae_amd.graph import StepGraphs
+    log = []
+    runs = []
+
+    def step(tag):
+        runs.append(tag)
+        _lib.record_py(log.append, (tag, "fork"))
+        _lib.record_py(log.append, (tag, "kernel-1"))
+        _lib.record_py(log.append, (tag, "kernel-2"))
+
+    g = StepGraphs()
+    g.run(("k", 1), lambda: step("a"), "plan")            # records while executing
+    assert runs == ["a"] and log == [("a", "fork"), ("a", "kernel-1"), ("a", "kernel-2")]
+    g.run(("k", 1), lambda: step("never"), "plan")        # replay: the step function is not called
+    assert runs == ["a"] and log[3:] == [("a", "fork"), ("a", "kernel-1"), ("a", "kernel-2")]
+    assert g.replays == 1
+    g.run(("k", 2), lambda: step("b"), "plan")            # other key (e.g. another batch pointer): new plan
+    assert runs == ["a", "b"] and g.replays == 1
+    assert _lib._REC is None                              # recording always ends, also on the error path:
+    try:
+        g.run(("k", 3), lambda: 1 / 0, "plan")
+    except ZeroDivisionError:
+        pass
+    assert _lib._REC is None
+
+
+def test_allocation_generation_invalidates_plan_keys():
+    """Every (re)allocation of engine buffers bumps _lib.ALLOC_GEN; the loss plugins put it into their plan key, so a
+    plan holding stale pointers can never be replayed."""
+    from disvae_amd import _lib
+    g0 = _lib.ALLOC_GEN[0]
+    _lib.note_alloc()
+    assert _lib.ALLOC_GEN[0] == g0 + 1
