@@ -101,9 +101,12 @@ def cpu_baseline(loss, img, B, iters=6, warm=2):
         torch.set_num_threads(n)
         tr = make()
         tr.train_iteration(probe)
-        t0 = time.perf_counter()
-        tr.train_iteration(probe)
-        dt = time.perf_counter() - t0
+        dt = None
+        for _ in range(2):               # best of two: a single probe on a shared host is noisy
+            t0 = time.perf_counter()
+            tr.train_iteration(probe)
+            d_ = time.perf_counter() - t0
+            dt = d_ if dt is None or d_ < dt else dt
         if best_t is None or dt < best_t:
             best_t, best_n = dt, n
     torch.set_num_threads(best_n)
