@@ -609,31 +609,41 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
   bool okk[2];
   const int klast = ((Kc + KS - 1) / KS - 1) * KS;
 
-  auto load = [&](auto PAR, int k0) {
+  // one 16-byte global load / LDS store of the slab pipeline (index l: first the A chunks, then the B chunks)
+  int kslab[2], kofs[2];
+  auto slab_begin = [&](auto PAR, int k0) {
     constexpr int P = decltype(PAR)::value;
     k0 = k0 < klast ? k0 : klast;                          // past the end: re-load the last slab (never used)
     okk[P] = k0 + c4 < Kc;
-    const int ka = okk[P] ? k0 : -c4;                      // contraction tail: stay inside the row (value zeroed at the store)
-#pragma unroll
-    for (int p = 0; p < NLA; ++p) ra[P][p] = *reinterpret_cast<const f32x4*>(pa[p] + ka);
-#pragma unroll
-    for (int p = 0; p < NLB; ++p) {
-      if (!B_JFAST) rb[P][p] = *reinterpret_cast<const f32x4*>(pb[p] + ka);
-      else { const int kap = k0 + trow + 16 * p; rb[P][p] = *reinterpret_cast<const f32x4*>(pb[p] + (long)(kap < Kc ? k0 : -(trow + 16 * p)) * ldb); }
-    }
+    kslab[P] = k0;
+    kofs[P] = okk[P] ? k0 : -c4;                           // contraction tail: stay inside the row (value zeroed at the store)
   };
-  auto store = [&](auto PAR) {
+  auto load_one = [&](auto PAR, int l) {
+    constexpr int P = decltype(PAR)::value;
+    if (l < NLA) { ra[P][l] = *reinterpret_cast<const f32x4*>(pa[l] + kofs[P]); return; }
+    const int p = l - NLA;
+    if (!B_JFAST) rb[P][p] = *reinterpret_cast<const f32x4*>(pb[p] + kofs[P]);
+    else { const int kap = kslab[P] + trow + 16 * p; rb[P][p] = *reinterpret_cast<const f32x4*>(pb[p] + (long)(kap < Kc ? kslab[P] : -(trow + 16 * p)) * ldb); }
+  };
+  auto store_one = [&](auto PAR, int l) {
     constexpr int P = decltype(PAR)::value;
     float* Ab = As + P * A_FLOATS;
     float* Bb = Bs + P * B_FLOATS;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (l < NLA) { *reinterpret_cast<f32x4*>(Ab + (trow + 16 * l) * SA + c4) = okk[P] ? ra[P][l] : zero; return; }
+    const int p = l - NLA;
+    if (!B_JFAST) *reinterpret_cast<f32x4*>(Bb + (trow + 16 * p) * SA + c4) = rb[P][p];
+    else { const int kap = trow + 16 * p; *reinterpret_cast<f32x4*>(Bb + kap * 64 + (kap >= 32 ? 32 : 0) + c4) = rb[P][p]; }
+  };
+  constexpr int NLD = NLA + NLB;           // 16-byte chunks per thread and slab
+  auto load = [&](auto PAR, int k0) {
+    slab_begin(PAR, k0);
 #pragma unroll
-    for (int p = 0; p < NLA; ++p) *reinterpret_cast<f32x4*>(Ab + (trow + 16 * p) * SA + c4) = okk[P] ? ra[P][p] : zero;
+    for (int l = 0; l < NLD; ++l) load_one(PAR, l);
+  };
+  auto store = [&](auto PAR) {
 #pragma unroll
-    for (int p = 0; p < NLB; ++p) {
-      if (!B_JFAST) *reinterpret_cast<f32x4*>(Bb + (trow + 16 * p) * SA + c4) = rb[P][p];
-      else { const int kap = trow + 16 * p; *reinterpret_cast<f32x4*>(Bb + kap * 64 + (kap >= 32 ? 32 : 0) + c4) = rb[P][p]; }
-    }
+    for (int l = 0; l < NLD; ++l) store_one(PAR, l);
   };
 
   f32x16 acc[NACC];
@@ -644,9 +654,13 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
 
   const int abl = act >> 8;                // timing ablations (tools/gemm_one.py): 1 no global loads, 2 no LDS stores, 4 no barriers
   act &= 0xff;
+  // One slab = 8 steps of 4*NACC MFMAs.  Every step also carries its share of the memory pipeline IN PROGRAM ORDER --
+  // steps 0-3 issue the global loads of slab s+2, steps 4-7 the LDS stores of slab s+1 -- and ends with a scheduling
+  // fence, so that those instructions are issued in the shadow of this step's MFMAs instead of in phases of their own.
   auto body = [&](auto PAR, int sl) {
     constexpr int P = decltype(PAR)::value;
-    if (!(abl & 1)) load(PAR, (sl + 2) * KS);                                // slab s+2 -> register set P
+    using Q = std::integral_constant<int, 1 - P>;
+    slab_begin(PAR, (sl + 2) * KS);
     const float* Ab = As + P * A_FLOATS + (r0 + i) * SA + h * 32;
     const float* Bb = Bs + P * B_FLOATS + (B_JFAST ? h * (32 * 64 + 32) + c0 + i : (c0 + i) * SA + h * 32);
     f32x4 av[2][NACC], bv[2];
@@ -660,35 +674,27 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
         bv[slot] = *reinterpret_cast<const f32x4*>(Bb + 4 * q);
       }
     };
+    constexpr int PER = (NLD + 3) / 4;     // chunks per step
     rd(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       if (q + 1 < 8) rd(q + 1, (q + 1) & 1);
+      if (q < 4) {
+        if (!(abl & 1)) {
+#pragma unroll
+          for (int l = q * PER; l < (q + 1) * PER && l < NLD; ++l) load_one(PAR, l);
+        }
+      } else if (!(abl & 2)) {
+#pragma unroll
+        for (int l = (q - 4) * PER; l < (q - 3) * PER && l < NLD; ++l) store_one(Q{}, l);
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int t = 0; t < NACC; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][t][u], bv[q & 1][u], acc[t], 0, 0, 0);
-    }
-    if (!(abl & 2)) store(std::integral_constant<int, 1 - P>{});             // slab s+1 (set 1-P) -> LDS image 1-P
-    // ---- the issue order of all of the above: one non-MFMA instruction group behind every MFMA
-    constexpr int NRD = NACC + (B_JFAST ? 4 : 1), NMF = 4 * NACC, NLD = NLA + NLB;
-    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);                     // reads of step 0
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (q + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);    // reads of step q+1
-#pragma unroll
-      for (int j = 0; j < NMF; ++j) {
-        const int slot = q * NMF + j;
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (slot < NLD) {                                                    // global loads of slab s+2
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        } else if (slot >= 4 * NMF && slot < 4 * NMF + NLD) {                // LDS writes of slab s+1
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (!(abl & 4)) __syncthreads();
   };
