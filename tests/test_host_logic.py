@@ -1,6 +1,7 @@
 """CPU: host-side logic of the native package (no kernels): API surface, parameter arena,
 state_dict compatibility, annealing / storer cadence, log importance weights."""
 import math
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -151,3 +152,28 @@ def test_allocation_generation_invalidates_plan_keys():
     g0 = _lib.ALLOC_GEN[0]
     _lib.note_alloc()
     assert _lib.ALLOC_GEN[0] == g0 + 1
+
+
+REF_RESULTS = "/root/reference/results"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_RESULTS), reason="reference checkpoints only exist in the build container")
+@pytest.mark.parametrize("name", ["btcvae_dsprites", "factor_celeba", "VAE_mnist"])
+def test_reference_checkpoints_load_into_the_native_model(name):
+    """results/*/model.pt + specs.json written by the reference load through the native
+    load_model (modelIO.py:81-153) -- same state_dict keys / shapes, every tensor bit-identical, weights land in the
+    flat parameter arena that the HIP engine reads."""
+    from disvae_amd.utils.modelIO import load_model, load_metadata
+    d = os.path.join(REF_RESULTS, name)
+    meta = load_metadata(d)
+    model = load_model(d, is_gpu=False)
+    state = torch.load(os.path.join(d, "model.pt"), map_location="cpu")
+    own = model.state_dict()
+    assert list(own.keys()) == list(state.keys())
+    for k, v in state.items():
+        assert own[k].shape == v.shape and torch.equal(own[k], v), k
+    assert tuple(model.img_size) == tuple(meta["img_size"]) and model.latent_dim == meta["latent_dim"]
+    # the parameters ARE views of the arena
+    w = model.encoder.conv1.weight
+    assert w.data_ptr() == model.arena.view("encoder.conv1.weight").data_ptr()
+    assert not model.training
