@@ -128,8 +128,8 @@ def cpu_baseline(loss, img, B, iters=6, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--loss", default="btcvae", choices=["btcvae", "factor", "VAE", "betaH", "betaB"])
     ap.add_argument("--batch", type=int, default=None, help="tensor handed to _train_iteration PER GPU")
     ap.add_argument("--channels", type=int, default=3)
