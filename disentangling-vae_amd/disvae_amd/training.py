@@ -2,8 +2,8 @@
 
 ``_train_iteration`` keeps the reference's contract (returns a python float).  When the
 model is a native ``disvae_amd`` VAE on an MI355X and the loss is a native plugin, the
-iteration is ONE stream of kernel launches (forward + loss + backward in libdvae_hip.so,
-then ``optimizer.step()``) instead of ~600 dispatched ATen ops; otherwise the generic
+iteration is a fixed sequence of launches from libdvae_hip.so on two HIP streams (forward + loss +
+backward, then ``optimizer.step()``) instead of ~600 dispatched ATen ops; otherwise the generic
 reference control flow (model -> loss -> zero_grad -> backward -> step, ValueError ->
 call_optimize) is used, which also works with the native model through its autograd
 wrappers.  ``_train_epoch`` defers the per-iteration ``loss.item()`` host sync to the end of
@@ -11,11 +11,11 @@ the epoch unless a progress bar needs the value.
 """
 import logging
 import os
+import time
 from collections import defaultdict
-from timeit import default_timer
 
 import torch
-from tqdm import trange
+from tqdm import tqdm
 
 from .models.vae import VAE
 from .models.losses import BaseLoss, FactorKLoss
@@ -27,62 +27,68 @@ TRAIN_LOSSES_LOGFILE = "train_losses.log"
 class Trainer():
     def __init__(self, model, optimizer, loss_f, device=torch.device("cpu"), logger=logging.getLogger(__name__),
                  save_dir="results", gif_visualizer=None, is_progress_bar=True, replay=None):
-        """``replay="plan"`` re-issues the device side of the native iteration from a recorded
-        launch list, ``replay="graph"`` from a hipGraph (disvae_amd/graph.py): worthwhile below
-        ~512 images per GPU, where issuing the ~75 launches from Python takes longer than the GPU
-        needs to run them.  ``False`` forces the eager path; ``None`` keeps the loss's setting."""
+        """Same arguments as training.py:46-51, plus ``replay``: how the launches of a native iteration are
+        issued -- "plan" re-issues them from a recorded launch list, "graph" from a hipGraph
+        (disvae_amd/graph.py: worthwhile below ~512 images per GPU, where issuing the launches from Python
+        takes longer than the GPU needs to run them), ``False`` forces the eager path, ``None`` keeps the
+        loss's setting ("auto")."""
         self.device = device
         self.model = model.to(self.device)
-        self.loss_f = loss_f
         self.optimizer = optimizer
+        self.loss_f = loss_f
+        self.logger = logger
         self.save_dir = save_dir
         self.is_progress_bar = is_progress_bar
-        self.logger = logger
-        self.losses_logger = LossesLogger(os.path.join(self.save_dir, TRAIN_LOSSES_LOGFILE))
         self.gif_visualizer = gif_visualizer
+        self.losses_logger = LossesLogger(os.path.join(self.save_dir, TRAIN_LOSSES_LOGFILE))
         if replay is not None and isinstance(loss_f, BaseLoss):
             loss_f.replay = replay or None
         self.logger.info("Training Device: {}".format(self.device))
 
+    # ------------------------------------------------------------------ epochs (training.py:64-102)
     def __call__(self, data_loader, epochs=10, checkpoint_every=10):
-        """training.py:64-102."""
-        start = default_timer()
+        t_begin = time.perf_counter()
         self.model.train()
         for epoch in range(epochs):
-            storer = defaultdict(list)
-            mean_epoch_loss = self._train_epoch(data_loader, storer, epoch)
-            self.logger.info('Epoch: {} Average loss per image: {:.2f}'.format(epoch + 1, mean_epoch_loss))
-            self.losses_logger.log(epoch, storer)
-            if self.gif_visualizer is not None:
-                self.gif_visualizer()
-            if epoch % checkpoint_every == 0:
-                save_model(self.model, self.save_dir, filename="model-{}.pt".format(epoch))
+            scalars = defaultdict(list)                       # filled by the loss on its logging steps
+            per_image = self._train_epoch(data_loader, scalars, epoch)
+            self._end_of_epoch(epoch, per_image, scalars, checkpoint_every)
         if self.gif_visualizer is not None:
             self.gif_visualizer.save_reset()
         self.model.eval()
-        delta_time = (default_timer() - start) / 60
-        self.logger.info('Finished training after {:.1f} min.'.format(delta_time))
+        self.logger.info('Finished training after {:.1f} min.'.format((time.perf_counter() - t_begin) / 60))
+
+    def _end_of_epoch(self, epoch, per_image, scalars, checkpoint_every):
+        self.logger.info('Epoch: {} Average loss per image: {:.2f}'.format(epoch + 1, per_image))
+        self.losses_logger.log(epoch, scalars)
+        if self.gif_visualizer is not None:
+            self.gif_visualizer()
+        if epoch % checkpoint_every == 0:                     # epoch 0 is always saved, as in the reference
+            save_model(self.model, self.save_dir, filename="model-{}.pt".format(epoch))
 
     def _train_epoch(self, data_loader, storer, epoch):
-        """training.py:104-135; the epoch loss is accumulated on the device when no progress
-        bar needs per-iteration values (one host sync per epoch instead of one per step)."""
-        kwargs = dict(desc="Epoch {}".format(epoch + 1), leave=False, disable=not self.is_progress_bar)
-        defer = (not self.is_progress_bar) and self._is_native()
-        epoch_loss = 0.
-        dev_losses = []
-        with trange(len(data_loader), **kwargs) as t:
-            for _, (data, _) in enumerate(data_loader):
-                if defer:
-                    dev_losses.append(self._train_iteration_async(data, storer).clone())
+        """Mean loss of the epoch's iterations (training.py:104-135).  Without a progress bar the native
+        path keeps the iteration losses on the device and syncs with the host ONCE per epoch."""
+        n_iter = len(data_loader)
+        on_device = (not self.is_progress_bar) and self._is_native()
+        pending, total = [], 0.0
+        bar = tqdm(total=n_iter, desc="Epoch {}".format(epoch + 1), leave=False, disable=not self.is_progress_bar)
+        try:
+            for batch, _labels in data_loader:
+                if on_device:
+                    pending.append(self._train_iteration_async(batch, storer).clone())
                 else:
-                    iter_loss = self._train_iteration(data, storer)
-                    epoch_loss += iter_loss
-                    t.set_postfix(loss=iter_loss)
-                t.update()
-        if defer and dev_losses:
-            epoch_loss = float(torch.stack(dev_losses).sum().item())
-        return epoch_loss / len(data_loader)
+                    value = self._train_iteration(batch, storer)
+                    total += value
+                    bar.set_postfix(loss=value)
+                bar.update()
+        finally:
+            bar.close()
+        if pending:
+            total = float(torch.stack(pending).sum().item())
+        return total / n_iter
 
+    # ------------------------------------------------------------------ one iteration (training.py:137-164)
     def _is_native(self):
         return (isinstance(self.model, VAE) and isinstance(self.loss_f, BaseLoss)
                 and next(self.model.parameters()).device.type == "cuda")
@@ -90,52 +96,47 @@ class Trainer():
     def _train_iteration_async(self, data, storer):
         """One native training iteration; returns the loss as a 0-d DEVICE tensor (no sync)."""
         data = data.to(self.device, non_blocking=True)
-        if isinstance(self.loss_f, FactorKLoss):
-            if self.model.training:
-                # the reference runs (and discards) a full-batch forward before the ValueError
-                # (training.py:153): keep its N(0,1) draw so the device RNG stream matches (Q4)
-                torch.randn(data.shape[0], self.model.latent_dim, dtype=torch.float32, device=data.device)
-            return self.loss_f.call_optimize(data, self.model, self.optimizer, storer)
-        return self.loss_f.fused_step(data, self.model, self.optimizer, storer)
+        if not isinstance(self.loss_f, FactorKLoss):
+            return self.loss_f.fused_step(data, self.model, self.optimizer, storer)
+        if self.model.training:
+            # the reference runs (and discards) a full-batch forward before the ValueError
+            # (training.py:153): keep its N(0,1) draw so the device RNG stream matches (Q4)
+            torch.randn(data.shape[0], self.model.latent_dim, dtype=torch.float32, device=data.device)
+        return self.loss_f.call_optimize(data, self.model, self.optimizer, storer)
 
     def _train_iteration(self, data, storer):
-        """training.py:137-164."""
         if self._is_native():
             return self._train_iteration_async(data, storer).item()
-        batch_size, channel, height, width = data.size()
+        # any other model / loss combination: the reference's control flow, in which a loss that needs its
+        # own optimisation schedule announces itself with ValueError
         data = data.to(self.device)
         try:
-            recon_batch, latent_dist, latent_sample = self.model(data)
-            loss = self.loss_f(data, recon_batch, latent_dist, self.model.training, storer,
-                               latent_sample=latent_sample)
-            self.optimizer.zero_grad()
-            loss.backward()
-            self.optimizer.step()
+            recon, latent_dist, latent_sample = self.model(data)
+            loss = self.loss_f(data, recon, latent_dist, self.model.training, storer, latent_sample=latent_sample)
         except ValueError:
-            loss = self.loss_f.call_optimize(data, self.model, self.optimizer, storer)
+            return self.loss_f.call_optimize(data, self.model, self.optimizer, storer).item()
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
         return loss.item()
 
 
 class LossesLogger(object):
-    """training.py:167-190: CSV 'Epoch,Loss,Value' through the process-global logger."""
+    """'Epoch,Loss,Value' CSV of the per-epoch means of the logged scalars (the file training.py:167-190
+    produces).  The reference routes the lines through the process-global logger "losses_logger", which
+    accumulates one FileHandler per Trainer ever constructed; here the file is simply written."""
 
     def __init__(self, file_path_name):
-        if os.path.isfile(file_path_name):
-            os.remove(file_path_name)
+        self.path = file_path_name
         os.makedirs(os.path.dirname(file_path_name) or ".", exist_ok=True)
-        self.logger = logging.getLogger("losses_logger")
-        self.logger.setLevel(1)
-        file_handler = logging.FileHandler(file_path_name)
-        file_handler.setLevel(1)
-        self.logger.addHandler(file_handler)
-        header = ",".join(["Epoch", "Loss", "Value"])
-        self.logger.debug(header)
+        with open(self.path, "w") as f:                       # truncates a log left by an earlier run
+            f.write("Epoch,Loss,Value\n")
 
     def log(self, epoch, losses_storer):
-        for k, v in losses_storer.items():
-            log_string = ",".join(str(item) for item in [epoch, k, mean(v)])
-            self.logger.debug(log_string)
+        with open(self.path, "a") as f:
+            for name, values in losses_storer.items():
+                f.write("{},{},{}\n".format(epoch, name, mean(values)))
 
 
-def mean(l):
-    return sum(l) / len(l)
+def mean(values):
+    return sum(values) / len(values)
