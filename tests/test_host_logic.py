@@ -177,3 +177,15 @@ def test_reference_checkpoints_load_into_the_native_model(name):
     w = model.encoder.conv1.weight
     assert w.data_ptr() == model.arena.view("encoder.conv1.weight").data_ptr()
     assert not model.training
+
+
+def test_bench_algorithmic_flops_match_survey():
+    """bench.py's step_tflops / roofline figures are computed from SURVEY 8d's algorithmic FLOPs per image
+    (6 MACs_fwd - 2 MACs_conv1): 84.19 MFLOP at 64x64x3, 73.71 MFLOP at 64x64x1; the dominant kernel's launch
+    (conv2 forward, 1024 images) is 8.59 GFLOP."""
+    import importlib
+    bench = importlib.import_module("bench")
+    assert abs(bench.flops_per_image_train(3) / 1e6 - 84.19) < 0.01
+    assert abs(bench.flops_per_image_train(1) / 1e6 - 73.71) < 0.01
+    assert abs(2.0 * 4194304 * 1024 / 1e9 - 8.59) < 0.01
+    assert bench.PEAK_FP32_MFMA_TFLOPS == 157.3 and bench.PEAK_HBM_GBS == 8000.0
