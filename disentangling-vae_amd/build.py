@@ -14,8 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libdvae_hip.so")
-HEADERS = [os.path.join(SRC, "common.h"), os.path.join(HERE, "..", "include", "dvae_hip.h")]
-SOURCES = ["conv_generic", "conv_mfma", "conv_thin", "linear", "loss", "capi"]
+HEADERS = [os.path.join(SRC, "common.h"), os.path.join(SRC, "conv_mfma_common.h"),
+           os.path.join(HERE, "..", "include", "dvae_hip.h")]
+SOURCES = ["conv_generic", "conv_mfma", "conv_up_r2", "conv_thin", "linear", "loss", "capi"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

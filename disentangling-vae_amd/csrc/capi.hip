@@ -34,7 +34,10 @@ static int run_down(const ConvArgs& a, hipStream_t s) {
 }
 static int run_up(const ConvArgs& a, hipStream_t s) {
   if (!use_generic_only()) {
-    int r = launch_up_mfma32(a, s);
+    static const bool r2 = getenv("DVAE_UP_R2") != nullptr;      // round-2 draft kernel, never the default
+    int r = r2 ? launch_up_mfma32_r2(a, s) : 1;
+    if (r <= 0) return r;
+    r = launch_up_mfma32(a, s);
     if (r <= 0) return r;
     r = launch_up_thin(a, s);
     if (r <= 0) return r;

@@ -106,6 +106,7 @@ int launch_wgrad_generic(const float* big, int big_layout, const float* small, i
 // MFMA paths (32 <-> 32 channels, NHWC, Hs == Ws in {4,8,16}); return 1 if not applicable
 int launch_down_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_up_mfma32(const ConvArgs& a, hipStream_t s);
+int launch_up_mfma32_r2(const ConvArgs& a, hipStream_t s);   // round-2 draft (conv_up_r2.hip), DVAE_UP_R2=1 only
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big,
                         int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0);
 // thin paths (Cb in {1,3}, Cs == 32, big NCHW 64x64 / small NHWC 32x32)
