@@ -56,8 +56,17 @@ def force_generic(flag):
             os.environ["DVAE_FORCE_GENERIC"] = old
 
 
+STATS = {}   # what -> worst (max abs err / max |ref|, err / tolerance) seen; dumped by conftest.py (DVAE_PARITY_STATS)
+
+
+def record_stat(what, rel_to_max, frac_of_tol):
+    cur = STATS.get(what, (0.0, 0.0))
+    STATS[what] = (max(cur[0], float(rel_to_max)), max(cur[1], float(frac_of_tol)))
+
+
 def check(got, ref, rtol=1e-4, atol_rel=2e-5, what=""):
-    """got: device/cpu fp32 tensor; ref: cpu tensor (fp64 preferred)."""
+    """got: device/cpu fp32 tensor; ref: cpu tensor (fp64 preferred).
+    |got - ref| <= rtol * |ref| + atol_rel * max|ref|, element-wise."""
     got = got.detach().cpu().double()
     ref = ref.detach().cpu().double()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
@@ -65,6 +74,7 @@ def check(got, ref, rtol=1e-4, atol_rel=2e-5, what=""):
     scale = ref.abs().max().item()
     err = (got - ref).abs()
     tol = atol_rel * scale + rtol * ref.abs()
+    record_stat(what, err.max().item() / (scale + 1e-300), (err / (tol + 1e-300)).max().item())
     bad = err > tol
     if bad.any():
         idx = torch.nonzero(bad)[0].tolist()
