@@ -1,23 +1,36 @@
 """Benchmark of the hot path: Trainer._train_iteration-equivalent steps (forward + loss +
-backward + Adam [+ RCCL all-reduce]) of the native HIP engine on synthetic 64x64x3 batches.
+backward + Adam [+ RCCL collectives]) of the native HIP engine on synthetic batches resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W           (N = 1)
+    python bench.py [--config NAME] --gpus N --steps K --warmup W           (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json metric / configs[3]): btcvae_celeba -- Burgess VAE, 64x64x3,
-btcvae loss (alpha 1, beta 6.4, gamma 1, n_data 202599, reg_anneal 10000), Adam lr 5e-4,
-B = 1024 images per GPU (weak scaling: global batch = 1024 x N, the B x B estimator runs over
-the GLOBAL batch).  `--loss factor` times the two-optimizer FactorVAE step instead
-(configs[4]: tensor of 2048 = 1024 + 1024 per GPU).
+Workloads = BASELINE.json configs[1..4] (hyper-parameters: /root/reference/hyperparam.ini:6,76-81,123-137,
+main.py:190-193; dataset sizes: utils/datasets.py:148,223):
 
-One JSON line on rank 0:  value = images/s of the whole job (inputs resident in HBM),
-`roofline` = algorithmic FLOPs of the dominant kernel / its HIP-event-timed duration vs the
-157.3 TFLOP/s fp32 MFMA peak, `cpu_baseline` = the CPU oracle (port of the reference Trainer,
-torch CPU) timed on this box's host cores on a bounded sample.
+    --config btcvae_celeba   (default; the config BASELINE.json's metric is quoted on)
+             64x64x3, btcvae (alpha 1, beta 6.4, gamma 1), B = 1024, n_data 202599, Adam lr 5e-4
+    --config factor_celeba   64x64x3, factor (gamma 6.4), tensor 2048 = 1024 + 1024, lr 1e-4, lr_disc 1e-5
+    --config btcvae_dsprites 64x64x1, btcvae, B = 256, n_data 737280, lr 5e-4
+    --config factor_dsprites 64x64x1, factor, tensor 256 = 128 + 128, lr 1e-4, lr_disc 1e-4
+
+B always denotes the tensor handed to `_train_iteration`.  With N > 1 GPUs the default is
+`--scaling strong`: the config's batch IS the global batch (configs[3]: "b=1024 ... DDP over 8xMI355X"), every
+rank gets B/N images and the batch-coupled estimators (B x B log-density matrix, permute_dims) run over the
+GLOBAL batch; `--scaling weak` keeps B images per GPU (global batch B x N).
+
+One JSON line on rank 0.  `value` = images/s of the whole job over EXACTLY --steps iterations bracketed by
+barrier + synchronize on both sides (max over ranks).  Also reported: HIP-event timing of the same iterations on the
+compute stream in 5 segments (`hip_event_ms_per_step`: segments + median), `roofline` = algorithmic FLOPs of the
+dominant kernel family / its HIP-event-timed duration vs the 157.3 TFLOP/s fp32 MFMA peak (+ the other two 32-channel
+conv families in `roofline_kernels`), `parity_check` = the first iteration of this very workload (same weights, batch,
+injected noise) against the oracle, `cpu_baseline` = the CPU oracle (port of the reference Trainer, torch CPU) timed on
+this box's host cores on a bounded sample.
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 from collections import defaultdict
@@ -31,8 +44,15 @@ import torch  # noqa: E402
 
 HP = dict(rec_dist="bernoulli", reg_anneal=10000, betaH_B=4, betaB_initC=0, betaB_finC=25, betaB_G=1000,
           factor_G=6.4, latent_dim=10, btcvae_A=1, btcvae_B=6.4, btcvae_G=1)
-PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz
+CONFIGS = {
+    "btcvae_celeba": dict(loss="btcvae", img=(3, 64, 64), batch=1024, n_data=202599, lr=5e-4, lr_disc=1e-5, baseline_config=3),
+    "factor_celeba": dict(loss="factor", img=(3, 64, 64), batch=2048, n_data=202599, lr=1e-4, lr_disc=1e-5, baseline_config=4),
+    "btcvae_dsprites": dict(loss="btcvae", img=(1, 64, 64), batch=256, n_data=737280, lr=5e-4, lr_disc=1e-4, baseline_config=1),
+    "factor_dsprites": dict(loss="factor", img=(1, 64, 64), batch=256, n_data=737280, lr=1e-4, lr_disc=1e-4, baseline_config=2),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4 at 2.4 GHz
 PEAK_HBM_GBS = 8000.0
+N_SEGMENTS = 5
 
 
 def flops_per_image_train(C):
@@ -43,57 +63,114 @@ def flops_per_image_train(C):
     return 6 * macs - 2 * conv[0]
 
 
-# HBM traffic of ONE launch of the dominant kernel at B = 1024, from rocprofv3 PMC passes over this
-# same command (profiles/r01_run31_pmc_summary.md): FETCH_SIZE 7.81e4 KiB (x2: the gfx950 counter
-# reports half of a wide coalesced streaming read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
-# 3.28e4 KiB = 160.0 MB + 33.6 MB.  Algorithmic bytes: 134.2 MB in + 33.6 MB out (the extra 19 % of
-# reads are the 2-row halos of the 64-pixel units).
-PMC_TRAFFIC_BYTES_B1024 = 2 * 7.81e4 * 1024 + 3.28e4 * 1024
+def flops_per_image_factor(C):
+    """SURVEY.md 8d, per image of the full tensor B: 0.5 train + 0.5 encoder forward + 28.1 MFLOP discriminator."""
+    conv = [524288 * C, 4194304, 1048576, 262144]
+    enc_fwd = 2 * (sum(conv) + 131072 + 65536 + 5120)
+    disc = 2 * 8.024e6 + 2 * 16.05e6 + 8.024e6
+    return 0.5 * flops_per_image_train(C) + 0.5 * enc_fwd + 0.5 * disc
 
 
-def dominant_kernel_roofline(B, device):
-    """HIP-event timing of the dominant kernel of the step -- k_down32ws<16>: the 32->32 channel,
-    32x32 -> 16x16 'down' MFMA kernel that runs conv2 forward and the convT2 dgrad (largest
-    share of GPU time in profiles/r01_run31_kernel_stats.md) -- launched through the C-ABI on the
-    stream the engine uses (torch's current stream)."""
-    from disvae_amd import _lib
-    from disvae_amd._lib import call, ptr
-    x = torch.rand(B, 32, 32, 32, device=device)
-    w = torch.rand(32, 32, 4, 4, device=device) - 0.5
-    b = torch.zeros(32, device=device)
-    y = torch.empty(B, 16, 16, 32, device=device)
-    s = torch.cuda.current_stream().cuda_stream
-    for _ in range(3):
-        call("dvae_conv4s2_fwd", ptr(x), _lib.NHWC, ptr(w), ptr(b), ptr(y), _lib.NHWC, B, 32, 32, 32, 32, _lib.ACT_RELU, s)
-    n = 20
+# ---------------------------------------------------------------------------------- roofline
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of `kernel_prefix` at B = 1024 (64x64x3) from the newest committed rocprofv3 PMC
+    summary under profiles/ (tools/pmc_collect.sh -> tools/pmc_summary.py: separate --pmc passes for FETCH_SIZE and
+    WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for 16-byte coalesced streaming
+    reads on gfx950).  Returns (bytes, file) or (None, None)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.md")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    for f in reversed(files):
+        rows = [l for l in open(f).read().splitlines() if l.startswith("| " + kernel_prefix)]
+        tot, n = 0.0, 0
+        for l in rows:
+            cells = [c.strip() for c in l.strip("|").split("|")]
+            try:
+                tot += (float(cells[-3]) + float(cells[-2])) * 1e6
+                n += 1
+            except ValueError:
+                pass
+        if n:
+            return tot / n, os.path.relpath(f, ROOT)
+    return None, None
+
+
+def _time_launch(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        call("dvae_conv4s2_fwd", ptr(x), _lib.NHWC, ptr(w), ptr(b), ptr(y), _lib.NHWC, B, 32, 32, 32, 32, _lib.ACT_RELU, s)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
-    flops = 2.0 * 4194304 * B              # algorithmic: 2 x MACs/img of conv2 (SURVEY 2b) x images per launch
-    achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_down32ws<16> (conv2 fwd / convT2 dgrad), %d images per launch" % B,
-            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "us_per_launch": round(ms * 1e3, 2),
-            "algorithmic_bytes": 167772160.0 * B / 1024,
-            "traffic": round(PMC_TRAFFIC_BYTES_B1024 * B / 1024) if B == 1024 else None}
+    return e0.elapsed_time(e1) / n
 
 
-def cpu_baseline(loss, img, B, iters=6, warm=2):
-    """CPU oracle (port of the reference Trainer iteration) on this box's host cores.  The
-    thread count is calibrated (torch's default of one thread per logical CPU oversubscribes
-    large hosts badly): the fastest of {8,16,32,64,all} on a B=128 probe is used."""
+def kernel_rooflines(B, device):
+    """HIP-event timing (events on torch's current stream = the stream the launches go to) of the three
+    32 <-> 32 channel MFMA conv families at their largest geometry (32x32 <-> 16x16, 8.59 GFLOP per 1024 images:
+    2 x 4.19 M MACs per image), launched through the C-ABI.  Per training step each family runs twice
+    at this geometry: k_up32<16> = convT2 fwd + conv2 dgrad (masked), k_down32ws<16> = conv2 fwd + convT2 dgrad
+    (masked), k_wgrad32<16> = conv2 wgrad + convT2 wgrad."""
+    from disvae_amd import _lib
+    from disvae_amd._lib import call, ptr
+    f = lambda *s: torch.rand(*s, device=device)
+    big, small = f(B, 32, 32, 32), f(B, 16, 16, 32)
+    obig, osmall = torch.empty_like(big), torch.empty_like(small)
+    w = f(32, 32, 4, 4) - 0.5
+    b = torch.zeros(32, device=device)
+    dw, db = torch.empty_like(w), torch.empty_like(b)
+    ws = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), device=device)
+    s = torch.cuda.current_stream().cuda_stream
+    NH, RELU = _lib.NHWC, _lib.ACT_RELU
+    fams = {
+        "k_up32<16>": [("convT2 fwd", lambda: call("dvae_convT4s2_fwd", ptr(small), NH, ptr(w), ptr(b), ptr(obig), NH, B, 32, 16, 16, 32, RELU, s)),
+                       ("conv2 dgrad (masked)", lambda: call("dvae_conv4s2_dgrad", ptr(small), NH, ptr(w), ptr(big), ptr(obig), NH, B, 32, 32, 32, 32, s))],
+        "k_down32ws<16>": [("conv2 fwd", lambda: call("dvae_conv4s2_fwd", ptr(big), NH, ptr(w), ptr(b), ptr(osmall), NH, B, 32, 32, 32, 32, RELU, s)),
+                           ("convT2 dgrad (masked)", lambda: call("dvae_convT4s2_dgrad", ptr(big), NH, ptr(w), ptr(small), ptr(osmall), NH, B, 32, 16, 16, 32, s))],
+        "k_wgrad32<16>": [("conv2 wgrad (+reduce)", lambda: call("dvae_conv4s2_wgrad", ptr(big), NH, ptr(small), NH, ptr(dw), ptr(db), B, 32, 32, 32, 32, ptr(ws), s))],
+    }
+    flops = 2.0 * 4194304 * B              # algorithmic FLOPs per launch: 2 x MACs/img x images per launch
+    # algorithmic HBM bytes per launch: big tensor (B x 32x32x32 fp32) + small tensor (B x 16x16x32) moved once
+    # (+ the mask read of the masked variants)
+    algo_bytes = {"k_up32<16>": (131072 + 32768) * 4.0 * B + 131072 * 4.0 * B / 2,     # avg of plain and masked
+                  "k_down32ws<16>": (131072 + 32768) * 4.0 * B + 32768 * 4.0 * B / 2,
+                  "k_wgrad32<16>": (131072 + 32768) * 4.0 * B}
+    out = []
+    for name, launches in fams.items():
+        ms = [(_time_launch(fn), what) for what, fn in launches]
+        tot = sum(m for m, _ in ms)
+        achieved = flops * len(ms) / (tot * 1e-3) / 1e12
+        traffic, src = pmc_traffic(name.split("<")[0] + "<16")
+        out.append({"bound": "mfma", "kernel": name, "launches": {what: round(m * 1e3, 2) for m, what in ms},
+                    "us_per_launch": round(tot / len(ms) * 1e3, 2), "us_per_step": round(tot * 1e3 * (2 // len(ms)), 2),
+                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "images_per_launch": B,
+                    "algorithmic_bytes": algo_bytes[name],
+                    "traffic": round(traffic * B / 1024) if traffic is not None else None,
+                    "traffic_source": src})
+    out.sort(key=lambda r: -r["us_per_step"])
+    return out
+
+
+# ---------------------------------------------------------------------------------- CPU legs
+def _oracle_hp(cfg):
+    return dict(HP, n_data=cfg["n_data"], lr_disc=cfg["lr_disc"])
+
+
+def cpu_baseline(cfg, B, iters=6, warm=2):
+    """CPU oracle (port of the reference Trainer iteration, incl. the wasted full-batch forward of
+    training.py:153 for factor) on this box's host cores.  The thread count is calibrated (torch's
+    default of one thread per logical CPU oversubscribes large hosts badly): the fastest of
+    {8,16,32,64,all} on a B=128 probe is used."""
     from oracle import disvae_oracle as O
     ncpu = os.cpu_count() or 1
-    hp = dict(HP, n_data=202599, lr_disc=1e-5)
+    loss, img = cfg["loss"], cfg["img"]
+    hp = _oracle_hp(cfg)
 
     def make():
         torch.manual_seed(1234)
-        return O.OracleTrainer(loss, hp, img, 10, lr=5e-4 if loss != "factor" else 1e-4, lr_disc=1e-5,
-                               steps_anneal=HP["reg_anneal"])
+        return O.OracleTrainer(loss, hp, img, 10, lr=cfg["lr"], lr_disc=cfg["lr_disc"], steps_anneal=HP["reg_anneal"])
 
     probe = torch.rand((128,) + tuple(img))
     best_t, best_n = None, 1
@@ -125,16 +202,77 @@ def cpu_baseline(loss, img, B, iters=6, warm=2):
                       "%d-CPU host" % (loss, img[0], B, iters, warm, med * 1e3, best_n, ncpu)}
 
 
+def parity_check(cfg, B, device):
+    """First training iteration of THIS workload (fresh seed-1234 weights, the same kind of synthetic batch,
+    injected noise) on the HIP engine vs the oracle: loss vs the fp32 oracle (= the reference's arithmetic),
+    gradients vs the fp64 oracle.  Outside the timed region; the oracle is the checker, never the measured path."""
+    from oracle import disvae_oracle as O
+    from disvae_amd.models.vae import init_specific_model
+    from disvae_amd.models.losses import get_loss_f
+    loss, img = cfg["loss"], cfg["img"]
+    hp = _oracle_hp(cfg)
+    torch.manual_seed(1234)
+    model = init_specific_model("Burgess", img, 10)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
+    loss_f = get_loss_f(loss, n_data=cfg["n_data"], device=device, lr_disc=cfg["lr_disc"], **HP)
+    loss_f.replay = None
+    model.to(device).train()
+    torch.manual_seed(1234)
+    p0 = O.init_vae_params(img, 10)
+    gen = torch.Generator().manual_seed(4321)
+    data = torch.rand((B,) + tuple(img), generator=gen)
+    st = lambda: O.LossState(steps_anneal=HP["reg_anneal"])
+    c64 = lambda p: O.clone_params(p, dtype=torch.float64, requires_grad=True)
+    t0 = time.perf_counter()
+    if loss == "factor":
+        d0 = O.init_disc_params(10)
+        Bh = B // 2
+        eps1, eps2 = torch.randn(Bh, 10, generator=gen), torch.randn(Bh, 10, generator=gen)
+        perms = torch.stack([torch.randperm(Bh, generator=gen) for _ in range(10)])
+        ref_loss = O.factor_iteration_grads(hp, st(), O.clone_params(p0, requires_grad=True),
+                                            O.clone_params(d0, requires_grad=True), data, eps1, eps2, list(perms))[0]
+        _, _, g64, gd64, _ = O.factor_iteration_grads(hp, st(), c64(p0), c64(d0), data.double(), eps1.double(),
+                                                      eps2.double(), list(perms))
+        out = loss_f.call_optimize(data.to(device), model, opt, None, noise=(eps1.to(device), eps2.to(device), perms))
+        grads = [(k, p.grad, g64[k]) for k, p in model.named_parameters()]
+        grads += [("disc." + k, p.grad, gd64[k]) for k, p in loss_f.discriminator.named_parameters()]
+    else:
+        eps = torch.randn(B, 10, generator=gen)
+        ref_loss = O.train_iteration_grads(loss, hp, st(), O.clone_params(p0, requires_grad=True), data, eps)[0]
+        _, _, g64, _ = O.train_iteration_grads(loss, hp, st(), c64(p0), data.double(), eps.double())
+        out = loss_f.fused_step(data.to(device), model, opt, None, eps=eps.to(device))
+        grads = [(k, p.grad, g64[k]) for k, p in model.named_parameters()]
+    got = float(out.item())
+    worst, worst_name = 0.0, ""
+    for k, g, r in grads:
+        r = r.double()
+        e = ((g.detach().cpu().double() - r).abs().max() / (r.abs().max() + 1e-300)).item()
+        if e > worst:
+            worst, worst_name = e, k
+    loss_err = abs(got - float(ref_loss)) / abs(float(ref_loss))
+    return {"ok": bool(loss_err <= 1e-5 and worst <= 1e-4), "loss": got, "oracle_fp32_loss": float(ref_loss),
+            "loss_rel_err": loss_err, "loss_rtol": 1e-5, "worst_grad_err_over_max_abs_grad_vs_fp64": worst,
+            "worst_grad_tensor": worst_name, "grad_gate": 1e-4, "batch": B, "seconds": round(time.perf_counter() - t0, 1)}
+
+
+# ---------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--loss", default="btcvae", choices=["btcvae", "factor", "VAE", "betaH", "betaB"])
-    ap.add_argument("--batch", type=int, default=None, help="tensor handed to _train_iteration PER GPU")
-    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="BASELINE.json workload (default btcvae_celeba)")
+    ap.add_argument("--loss", default=None, choices=["btcvae", "factor", "VAE", "betaH", "betaB"],
+                    help="override the config's loss (legacy: --loss factor == --config factor_celeba)")
+    ap.add_argument("--batch", type=int, default=None, help="override the tensor handed to _train_iteration (the GLOBAL "
+                    "batch under --scaling strong, the per-GPU batch under --scaling weak)")
+    ap.add_argument("--channels", type=int, default=None)
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="N > 1: strong (default) = the config's batch is the global batch, split over the ranks; "
+                         "weak = the config's batch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="run the data-parallel code path (RCCL process group, "
                     "collectives, barriers) even with ONE rank: exercises the N>1 path of this script on a single GPU")
     ap.add_argument("--estimator", default="global", choices=["global", "local"],
@@ -155,20 +293,41 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
+    name = args.config or ("factor_celeba" if args.loss == "factor" else "btcvae_celeba")
+    cfg = dict(CONFIGS[name])
+    if args.loss:
+        cfg["loss"] = args.loss
+        if args.loss == "factor" and CONFIGS[name]["loss"] != "factor":
+            cfg["lr"] = 1e-4
+    if args.channels:
+        cfg["img"] = (args.channels, 64, 64)
+    if args.batch:
+        cfg["batch"] = args.batch
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    if scaling == "strong" and world > 1:
+        if cfg["batch"] % (world * (2 if cfg["loss"] == "factor" else 1)):
+            raise SystemExit("global batch %d does not split over %d ranks" % (cfg["batch"], world))
+        B = cfg["batch"] // world
+    else:
+        B = cfg["batch"]
+    B_global = B * world
+    loss_name, img, lr = cfg["loss"], cfg["img"], cfg["lr"]
+
     from disvae_amd.models.vae import init_specific_model
     from disvae_amd.models.losses import get_loss_f
     from disvae_amd.training import Trainer
     from disvae_amd import parallel
 
-    img = (args.channels, 64, 64)
-    B = args.batch or (2048 if args.loss == "factor" else 1024)
-    lr = 1e-4 if args.loss == "factor" else 5e-4
+    parity = None
+    if world == 1 and not args.no_parity_check:
+        parity = parity_check(cfg, B, device)
+
     torch.manual_seed(1234)
     model = init_specific_model("Burgess", img, 10).to(device)
     # torch.optim.Adam as in main.py:208, fused=True = torch's single-kernel multi-tensor variant, on the
-    # parameter arena viewed as ONE tensor (element-wise identical to Adam over the 28 state_dict views)
+    # parameter arena viewed as equal chunks (element-wise identical to Adam over the 28 state_dict views)
     optimizer = torch.optim.Adam(model.flat_parameters(), lr=lr, fused=True)
-    loss_f = get_loss_f(args.loss, n_data=202599, device=device, lr_disc=1e-5, **HP)
+    loss_f = get_loss_f(loss_name, n_data=cfg["n_data"], device=device, lr_disc=cfg["lr_disc"], **HP)
     import logging
     trainer = Trainer(model, optimizer, loss_f, device=device, logger=logging.getLogger("bench"),
                       save_dir="/tmp/dvae_bench_%d" % rank, is_progress_bar=False,
@@ -183,7 +342,7 @@ def main():
     # synthetic batch, resident in HBM; every rank draws its own shard and its own device noise, while
     # the CPU generator (FactorVAE permutations, losses.py:505) stays identical on all ranks
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    data = torch.rand((B,) + img, device=device, generator=gen)
+    data = torch.rand((B,) + tuple(img), device=device, generator=gen)
     torch.cuda.manual_seed(1234 + rank)
     storer = defaultdict(list)
 
@@ -194,12 +353,23 @@ def main():
 
     for _ in range(args.warmup):
         trainer._train_iteration_async(data, storer)
+    # HIP events on the compute stream (torch's current stream = the stream the engine launches on) at the
+    # boundaries of N_SEGMENTS equal segments of the timed region
+    nseg = N_SEGMENTS if args.steps >= N_SEGMENTS else 1
+    bounds = [round(i * args.steps / nseg) for i in range(nseg + 1)]
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(nseg + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    events[0].record()
+    nxt = 1
+    for i in range(args.steps):
         loss = trainer._train_iteration_async(data, storer)
+        if i + 1 == bounds[nxt]:
+            events[nxt].record()
+            nxt += 1
     barrier()
     dt = time.perf_counter() - t0
+    seg_ms = [events[i].elapsed_time(events[i + 1]) / max(bounds[i + 1] - bounds[i], 1) for i in range(nseg)]
     if ddp:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -226,30 +396,42 @@ def main():
     if world > 1:
         time.sleep(1.0)      # (outside the timed region) let the other ranks exit: the JSON line is the LAST line of the job
     ms = dt / args.steps * 1e3
-    value = B * world * args.steps / dt
-    flops_img = flops_per_image_train(args.channels)
+    value = B_global * args.steps / dt
+    C = img[0]
+    flops_img = flops_per_image_factor(C) if loss_name == "factor" else flops_per_image_train(C)
+    step_tf = flops_img * B_global / (ms * 1e-3) / 1e12
+    dset = "celeba" if C == 3 else "dsprites"
     out = {
-        "metric": "images/sec (whole node) at 64x64x3, btcvae loss" if args.loss == "btcvae" else
-                  "images/sec (whole node) at 64x64x%d, %s loss" % (args.channels, args.loss),
+        "metric": "images/sec (whole node) at 64x64x%d, %s loss" % (C, loss_name),
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s_celeba: Burgess VAE 64x64x%d, %s loss, z=10, B=%d per GPU (global %d), Adam lr %g, "
-                               "n_data=202599, fwd+loss+bwd+Adam%s" % (args.loss, args.channels, args.loss, B, B * world, lr,
-                                                                      "+RCCL all-reduce" if world > 1 else ""),
-                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                   "estimator": args.estimator if ddp else None,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": scaling if world > 1 else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s (BASELINE.json configs[%d]): Burgess VAE 64x64x%d, %s loss, z=10, tensor handed to "
+                               "_train_iteration B=%d global (%d per GPU), Adam lr %g%s, n_data=%d, fwd+loss+bwd+Adam%s"
+                               % (name, cfg["baseline_config"], C, loss_name, B_global, B, lr,
+                                  (", lr_disc %g" % cfg["lr_disc"]) if loss_name == "factor" else "", cfg["n_data"],
+                                  "+RCCL collectives" if world > 1 else ""),
+                   "name": name, "dataset_shape": dset, "batch_per_gpu": B, "global_batch": B_global,
+                   "parallelism": "dp%d" % world, "estimator": args.estimator if ddp else None,
                    "final_loss": round(final_loss, 4)},
-        "step_tflops": round(flops_img * B * world / (ms * 1e-3) / 1e12, 2) if args.loss != "factor" else None,
-        "step_frac_of_fp32_peak": round(flops_img * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
-        if args.loss != "factor" else None,
+        "hip_event_ms_per_step": {"segments": [round(x, 4) for x in seg_ms], "median": round(sorted(seg_ms)[len(seg_ms) // 2], 4),
+                                  "note": "HIP events on the compute stream of rank 0 around %d equal segments of the timed "
+                                          "iterations" % nseg},
+        "step_tflops": round(step_tf, 2),
+        "step_frac_of_fp32_peak": round(step_tf / world / PEAK_FP32_MFMA_TFLOPS, 4),
     }
+    if parity is not None:
+        out["parity_check"] = parity
     if not args.no_roofline:
-        out["roofline"] = dominant_kernel_roofline(B if args.loss != "factor" else B // 2, device)
+        fams = kernel_rooflines(B if loss_name != "factor" else B // 2, device)
+        out["roofline"] = fams[0]           # the family with the largest share of the step
+        out["roofline_kernels"] = fams[1:]
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.loss, img, B)
+        out["cpu_baseline"] = cpu_baseline(cfg, B)
     flush_c_stdio()
     print(json.dumps(out), flush=True)
+    if parity is not None and not parity["ok"]:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -14,4 +14,4 @@ probe() { # label, command...
 }
 probe "idle" sleep 1
 probe "gemm 2048x1000x1000 x100000" python tools/gemm_one.py 2048 1000 1000 100000
-probe "btcvae step x6000" python bench.py --steps 6000 --warmup 10 --no-cpu-baseline --no-roofline
+probe "btcvae step x6000" python bench.py --steps 6000 --warmup 10 --no-cpu-baseline --no-roofline --no-parity-check

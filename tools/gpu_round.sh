@@ -23,7 +23,7 @@ timeout 600 python bench.py --steps ${BENCH_STEPS:-20} --warmup 5 2>&1 | tail -n
 if [ "${DO_PROF:-1}" = "1" ]; then
   echo "== rocprofv3 kernel stats"
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o prof -- python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$REPO/gpurun_out/prof.log" 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o prof -- python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-parity-check > "$REPO/gpurun_out/prof.log" 2>&1)
   tail -n 3 gpurun_out/prof.log
   python tools/prof_summary.py gpurun_out/prof/prof_results.db 13 | head -40
 fi
