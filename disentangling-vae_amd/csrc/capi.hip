@@ -34,9 +34,12 @@ static int run_down(const ConvArgs& a, hipStream_t s) {
 }
 static int run_up(const ConvArgs& a, hipStream_t s) {
   if (!use_generic_only()) {
-    static const bool r2 = getenv("DVAE_UP_R2") != nullptr;      // round-2 draft kernel, never the default
-    int r = r2 ? launch_up_mfma32_r2(a, s) : 1;
+    int r = 1;
+#ifdef DVAE_DEBUG_SWITCHES
+    static const bool r2 = env_on("DVAE_UP_R2");      // experimental kernel, debug builds only
+    if (r2) r = launch_up_mfma32_r2(a, s);
     if (r <= 0) return r;
+#endif
     r = launch_up_mfma32(a, s);
     if (r <= 0) return r;
     r = launch_up_thin(a, s);
@@ -123,7 +126,7 @@ int dvae_convT4s2_sigmoid_recon_fwd(const float* x, int x_layout, const float* w
   DVAE_CHECK_ARG(check_layout(x_layout));
   DVAE_CHECK_ARG(dist == DVAE_REC_BERNOULLI || dist == DVAE_REC_GAUSSIAN || dist == DVAE_REC_LAPLACE);
   ConvArgs a{nullptr, 0, x, x_layout, w, b, nullptr, recon, DVAE_NCHW, N, Cout, Cin, H, W, DVAE_ACT_SIGMOID};
-  static const bool two_pass = getenv("DVAE_RECON_TWO_PASS") != nullptr;   // A/B switch
+  static const bool two_pass = env_on("DVAE_RECON_TWO_PASS");   // A/B switch (debug builds)
   if (!use_generic_only() && !two_pass) {
     int r = launch_up_thin_recon(a, target, g, dist, coef, partials, (hipStream_t)stream);
     if (r <= 0) return r;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/dvae_hip.h"
 
@@ -106,7 +107,9 @@ int launch_wgrad_generic(const float* big, int big_layout, const float* small, i
 // MFMA paths (32 <-> 32 channels, NHWC, Hs == Ws in {4,8,16}); return 1 if not applicable
 int launch_down_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_up_mfma32(const ConvArgs& a, hipStream_t s);
-int launch_up_mfma32_r2(const ConvArgs& a, hipStream_t s);   // round-2 draft (conv_up_r2.hip), DVAE_UP_R2=1 only
+#ifdef DVAE_DEBUG_SWITCHES
+int launch_up_mfma32_r2(const ConvArgs& a, hipStream_t s);   // experimental (conv_up_r2.hip), DVAE_UP_R2=1
+#endif
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big,
                         int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0);
 // thin paths (Cb in {1,3}, Cs == 32, big NCHW 64x64 / small NHWC 32x32)
@@ -154,6 +157,19 @@ int launch_loss_epilogue(int kind, const float* rec_partials, const float* kl_di
 int launch_set_coef(float* coef, const float* v, hipStream_t s);
 int launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);
 
-bool use_generic_only();  // DVAE_FORCE_GENERIC=1 (debug / A-B reference path, still HIP)
+bool use_generic_only();  // DVAE_FORCE_GENERIC=1 (on-device reference path of the parity tests, still HIP)
+
+// A/B and timing-ablation switches (DVAE_DOWN_V1, DVAE_ABLATE, ...) and the experimental kernel variants they
+// select exist only in a library built with -DDVAE_DEBUG_SWITCHES (python build.py --debug); the shipped
+// library compiles them out.  A switch is ON only for the value "1" (integers: atoi of the value).
+#ifdef DVAE_DEBUG_SWITCHES
+static inline bool env_on(const char* name) { const char* e = getenv(name); return e && e[0] == '1' && e[1] == 0; }
+static inline bool env_off(const char* name) { const char* e = getenv(name); return e && e[0] == '0' && e[1] == 0; }
+static inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline constexpr bool env_on(const char*) { return false; }
+static inline constexpr bool env_off(const char*) { return false; }
+static inline constexpr int env_int(const char*, int dflt) { return dflt; }
+#endif
 
 }  // namespace dvae

@@ -21,6 +21,8 @@
 
 namespace dvae {
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 // ---- down: big -> small ------------------------------------------------------------------
 #define SEL4(v, g, j) ((g) == 0 ? (v)[j] : (g) == 1 ? (v)[4 + (j)] : (g) == 2 ? (v)[8 + (j)] : (v)[12 + (j)])
 template <int HS, bool MASK>
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
   }
 }
 
+#ifdef DVAE_DEBUG_SWITCHES
 // ---- down, version 2 (HS = 16, 8): no K-split ---------------------------------------------
 // 8 waves = 4 M-tiles of 16 pixels x 2 halves of the 32 output channels on v_mfma_f32_16x16x4_f32
 // (two independent accumulator chains: the instruction's 40-cycle dependent latency exceeds its
@@ -126,7 +129,6 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
 // reduction and no reduction buffer; the LDS that frees up double-buffers the activation tile:
 // one barrier per unit, and a wave that finishes its MFMAs writes the NEXT tile while the other
 // waves are still computing.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_down32v2(const float* __restrict__ big, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ mask,
@@ -215,6 +217,8 @@ __global__ __launch_bounds__(512) void k_down32v2(const float* __restrict__ big,
   }
 }
 
+#endif  // DVAE_DEBUG_SWITCHES
+
 // ---- down, version 3 (HS = 16, 8): wave-specialised ---------------------------------------
 // Waves 0-3 (one per SIMD) do nothing but MFMAs: each owns 16 pixels x all 32 output channels of the
 // unit (256 v_mfma_f32_16x16x4_f32, 8 independent accumulator chains, operands prefetched one tap
@@ -275,7 +279,11 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
   using G = Geo<HS>;
   static_assert(G::IMGS == 1, "one image per unit");
   const int act = act_flags & 0xff;
-  const int abl = act_flags >> 8;   // timing-ablation flags (DVAE_ABLATE, debugging only; results invalid)
+#ifdef DVAE_DEBUG_SWITCHES
+  const int abl = act_flags >> 8;   // timing-ablation flags (DVAE_ABLATE, debug builds only; results invalid)
+#else
+  constexpr int abl = 0;
+#endif
   constexpr int LNPF = (G::BIG_SLOTS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                          // 16384 floats
@@ -645,6 +653,7 @@ size_t wgrad32_ws_floats() { return (size_t)WG_MAX_BLOCKS * WG_STRIDE; }
 // ---- launchers -----------------------------------------------------------------------------
 static int units_for(int N, int HS) { return (int)(((long)N * HS * HS + 63) / 64); }
 
+#ifdef DVAE_DEBUG_SWITCHES
 template <int HS>
 static int launch_down_v2(const ConvArgs& a, hipStream_t s) {
   using G = Geo<HS>;
@@ -663,6 +672,8 @@ static int launch_down_v2(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+#endif
+
 template <int HS>
 static int launch_down_ws(const ConvArgs& a, hipStream_t s) {
   using G = Geo<HS>;
@@ -675,7 +686,7 @@ static int launch_down_ws(const ConvArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_down32ws<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  static const int abl = getenv("DVAE_ABLATE") ? atoi(getenv("DVAE_ABLATE")) : 0;
+  static const int abl = env_int("DVAE_ABLATE", 0);   // timing ablation, debug builds only (results invalid)
   const int af = a.act | (abl << 8);
   if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
   else hipLaunchKernelGGL((k_down32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
@@ -748,13 +759,17 @@ int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
   const int out_l = (a.Hs == 4 && a.out_layout == DVAE_NCHW) ? DVAE_NHWC : a.out_layout;
   if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.big_layout, out_l, DVAE_NHWC)) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
-  // A/B switches: DVAE_DOWN_V1 = K-split 32x32x2 kernel, DVAE_DOWN_V2 = 8 symmetric waves;
-  // default = wave-specialised (4 MFMA waves + 4 loader waves)
-  static const bool v1 = getenv("DVAE_DOWN_V1") != nullptr;
-  static const bool v2 = getenv("DVAE_DOWN_V2") != nullptr;
+  // HS = 16, 8: wave-specialised (4 MFMA waves + 4 loader waves); HS = 4: K-split 32x32x2 kernel.  Debug builds:
+  // DVAE_DOWN_V1=1 = the K-split kernel for every HS, DVAE_DOWN_V2=1 = 8 symmetric waves
+#ifdef DVAE_DEBUG_SWITCHES
+  static const bool v1 = env_on("DVAE_DOWN_V1");
+  static const bool v2 = env_on("DVAE_DOWN_V2");
+  if (a.Hs == 16 && (v1 || v2)) return v1 ? launch_down_t<16>(a, s) : launch_down_v2<16>(a, s);
+  if (a.Hs == 8 && (v1 || v2)) return v1 ? launch_down_t<8>(a, s) : launch_down_v2<8>(a, s);
+#endif
   switch (a.Hs) {
-    case 16: return v1 ? launch_down_t<16>(a, s) : v2 ? launch_down_v2<16>(a, s) : launch_down_ws<16>(a, s);
-    case 8: return v1 ? launch_down_t<8>(a, s) : v2 ? launch_down_v2<8>(a, s) : launch_down_ws<8>(a, s);
+    case 16: return launch_down_ws<16>(a, s);
+    case 8: return launch_down_ws<8>(a, s);
     default: return launch_down_t<4>(a, s);
   }
 }

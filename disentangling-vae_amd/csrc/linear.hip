@@ -409,7 +409,7 @@ static void launch_fc32_t(const float* a, long lda, const float* b, long ldb, fl
 template <bool BJ>
 static bool try_fc32(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
                      const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
-  static const bool off = getenv("DVAE_GEMM_FC") && getenv("DVAE_GEMM_FC")[0] == '0';
+  static const bool off = env_off("DVAE_GEMM_FC");   // A/B switch, debug builds only
   if (off || Kc > 512) return false;
   if ((long)((M + 63) / 64) * ((N + 63) / 64) >= 512) return false;      // big outputs: the 64x64-tile kernel
   const bool al = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void k_fcw32(const float* __restrict__ dy, con
 }
 
 static bool try_fcw32(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, hipStream_t s) {
-  static const bool off = getenv("DVAE_GEMM_FC") && getenv("DVAE_GEMM_FC")[0] == '0';
+  static const bool off = env_off("DVAE_GEMM_FC");   // A/B switch, debug builds only
   if (off || N % 4 || K % 4 || M > 4096) return false;
   if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return false;
   if ((long)((N + 63) / 64) * ((K + 63) / 64) >= 512) return false;     // big outputs: 64x64 tiles + split contraction
@@ -652,7 +652,11 @@ __global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, l
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
 
+#ifdef DVAE_DEBUG_SWITCHES
   const int abl = act >> 8;                // timing ablations (tools/gemm_one.py): 1 no global loads, 2 no LDS stores, 4 no barriers
+#else
+  constexpr int abl = 0;
+#endif
   act &= 0xff;
   // One slab = 8 steps of 4*NACC MFMAs.  Every step also carries its share of the memory pipeline IN PROGRAM ORDER --
   // steps 0-3 issue the global loads of slab s+2, steps 4-7 the LDS stores of slab s+1 -- and ends with a scheduling
@@ -740,7 +744,7 @@ static void launch_gemm_big_t(const float* a, long lda, const float* b, long ldb
     (void)hipFuncSetAttribute((const void*)k_gemm_big<TM, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  static const int abl = getenv("DVAE_GEMM_ABLATE") ? atoi(getenv("DVAE_GEMM_ABLATE")) : 0;
+  static const int abl = env_int("DVAE_GEMM_ABLATE", 0);   // timing ablation, debug builds only (results invalid)
   hipLaunchKernelGGL((k_gemm_big<TM, BJ>), dim3((N + 63) / 64, (M + TM - 1) / TM), dim3(256), lds, s, a, lda, b, ldb, c, ldc,
                      M, N, Kc, bias, act | (abl << 8), mask, mask_act);
 }
@@ -749,11 +753,11 @@ static void launch_gemm_big_t(const float* a, long lda, const float* b, long ldb
 template <bool BJ>
 static bool try_gemm_big(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
                          const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
-  static const bool off = getenv("DVAE_GEMM_BIG") && getenv("DVAE_GEMM_BIG")[0] == '0';
+  static const bool off = env_off("DVAE_GEMM_BIG");   // A/B switch, debug builds only
   if (off || Kc < 256 || N < 128 || Kc % 4 || lda % 4 || ldb % 4 || (BJ && N % 4)) return false;
   if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return false;
   // TM = 64 -> 2 workgroups per CU (70 KB of LDS each): measured 76.7 vs 69.6 TFLOP/s for TM = 128 at 2048x1000x1000
-  static const int force_tm = getenv("DVAE_GEMM_TM") ? atoi(getenv("DVAE_GEMM_TM")) : 0;        // A/B switch
+  static const int force_tm = env_int("DVAE_GEMM_TM", 0);        // A/B switch, debug builds only
   if (force_tm == 128) launch_gemm_big_t<128, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
   else launch_gemm_big_t<64, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
   return true;
@@ -764,7 +768,11 @@ static bool try_gemm_big(const float* a, long lda, const float* b, long ldb, flo
 // operands (11.2 vs 13.3 us at 1024x512x256); the lane-contiguous dgrad / wgrad forms are slower than the
 // LDS-staged split-K kernel (16.4 vs 14.0, 22.9 vs 14.6 us) -> forward only unless DVAE_GEMM_SMALL=all
 static inline bool use_small(int M, int N, int Kc, bool fwd_vec) {
-  static const char* mode = getenv("DVAE_GEMM_SMALL");
+#ifdef DVAE_DEBUG_SWITCHES
+  static const char* mode = getenv("DVAE_GEMM_SMALL");   // A/B switch, debug builds only
+#else
+  constexpr const char* mode = nullptr;
+#endif
   const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
   if (mode && mode[0] == 'n') return false;
   if (!(tiles64 < 192 && Kc <= 4096)) return false;
