@@ -169,14 +169,14 @@ int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int
 
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                         const float* coef, int B, int D, void* stream) {
-  DVAE_CHECK_ARG(ml && mu && logvar && z && B > 0 && D > 0 && D <= 16);    // kl_dim without coef: partials only
+  DVAE_CHECK_ARG(ml && mu && logvar && z && B > 0 && D > 0 && D <= DVAE_MAX_D);    // kl_dim without coef: partials only
   return launch_reparam_kl_fwd(ml, eps, mu, logvar, z, kl_dim, coef, B, D, (hipStream_t)stream);
 }
 
 int dvae_reparam_kl_bwd(const float* dz, const float* dz2, const float* dz3, const float* dmu_x, const float* dlv_x,
                         const float* mu, const float* logvar, const float* eps, const float* scal, const float* coef,
                         float* dml, int B, int D, void* stream) {
-  DVAE_CHECK_ARG(mu && logvar && scal && coef && dml && B > 0 && D > 0);
+  DVAE_CHECK_ARG(mu && logvar && scal && coef && dml && B > 0 && D > 0 && D <= DVAE_MAX_D);
   return launch_reparam_kl_bwd(dz, dz2, dz3, dmu_x, dlv_x, mu, logvar, eps, scal, coef, dml, B, D, (hipStream_t)stream);
 }
 
@@ -194,7 +194,7 @@ int dvae_sigmoid_bwd(const float* grad_y, const float* y, float* out, long n, vo
 
 int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg, int D, int row0, int Bl, int is_mss,
                     const float* log_w, float* tmp, float* rowstats, void* stream) {
-  DVAE_CHECK_ARG(z && mu && logvar && tmp && rowstats && Bg > 1 && D == 10 && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg);
+  DVAE_CHECK_ARG(z && mu && logvar && tmp && rowstats && Bg > 1 && D >= 1 && D <= DVAE_BTCVAE_MAX_D && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg);
   DVAE_CHECK_ARG(!is_mss || log_w);
   return launch_btcvae_fwd(z, mu, logvar, Bg, D, row0, Bl, is_mss, log_w, tmp, rowstats, (hipStream_t)stream);
 }
@@ -202,7 +202,7 @@ int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg
 int dvae_btcvae_bwd(const float* z, const float* mu, const float* logvar, const float* rowstats, int Bg, int D,
                     int row0, int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz,
                     float* dmu_all, float* dlv_all, void* stream) {
-  DVAE_CHECK_ARG(z && mu && logvar && rowstats && coef && tmp && dz && dmu_all && dlv_all && Bg > 1 && D == 10);
+  DVAE_CHECK_ARG(z && mu && logvar && rowstats && coef && tmp && dz && dmu_all && dlv_all && Bg > 1 && D >= 1 && D <= DVAE_BTCVAE_MAX_D);
   DVAE_CHECK_ARG(row0 >= 0 && Bl > 0 && row0 + Bl <= Bg && (!is_mss || log_w));
   return launch_btcvae_bwd(z, mu, logvar, rowstats, Bg, D, row0, Bl, is_mss, log_w, coef, tmp, dz, dmu_all, dlv_all,
                            (hipStream_t)stream);

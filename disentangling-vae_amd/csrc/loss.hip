@@ -143,28 +143,30 @@ __global__ void k_btcvae_prep(const float* __restrict__ mu, const float* __restr
 
 // one workgroup (4 waves) per row i: the columns j are split over the 4 waves x 64 lanes, so the
 // serial online-logsumexp chain per lane is Bg/256 long (the kernel is latency-, not throughput-bound)
-template <int D>
+template <int DT>
 __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z, const float* __restrict__ mu,
                                                     const float* __restrict__ lv, const float* __restrict__ tmp,
                                                     int Bg, int row0, int Bl, int is_mss,
-                                                    const float* __restrict__ log_w, float* __restrict__ rowstats) {
-  __shared__ float red[4][2 * (D + 1)];
+                                                    const float* __restrict__ log_w, float* __restrict__ rowstats, int Drt) {
+  constexpr int DM = DT ? DT : 16;          // DT = 0: latent dimension given at run time (<= 16)
+  const int D = DT ? DT : Drt;
+  __shared__ float red[4][2 * (DM + 1)];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int il = blockIdx.x;
   const int i = row0 + il;
   const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
   const float* muT = tmp; const float* cT = tmp + (long)D * Bg; const float* ivT = tmp + (long)2 * D * Bg;
-  float zi[D];
+  float zi[DM];
 #pragma unroll
-  for (int d = 0; d < D; ++d) zi[d] = z[(long)i * D + d];
-  float mS = -INFINITY, sS = 0.f, md[D], sd[D];
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) zi[d] = z[(long)i * D + d];
+  float mS = -INFINITY, sS = 0.f, md[DM], sd[DM];
 #pragma unroll
-  for (int d = 0; d < D; ++d) { md[d] = -INFINITY; sd[d] = 0.f; }
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) { md[d] = -INFINITY; sd[d] = 0.f; }
   for (int j = threadIdx.x; j < Bg; j += 256) {
     const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
     float S = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
       const float diff = zi[d] - muT[(long)d * Bg + j];
       const float ld = (cT[(long)d * Bg + j] - 0.5f * (diff * diff * ivT[(long)d * Bg + j])) + lw;
       S += ld;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
     float m2 = __shfl_xor(mS, o, 64), s2 = __shfl_xor(sS, o, 64);
     lse_merge(mS, sS, m2, s2);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
       m2 = __shfl_xor(md[d], o, 64); s2 = __shfl_xor(sd[d], o, 64);
       lse_merge(md[d], sd[d], m2, s2);
     }
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
   if (lane == 0) {
     red[wv][0] = mS; red[wv][1] = sS;
 #pragma unroll
-    for (int d = 0; d < D; ++d) { red[wv][2 + 2 * d] = md[d]; red[wv][3 + 2 * d] = sd[d]; }
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) { red[wv][2 + 2 * d] = md[d]; red[wv][3 + 2 * d] = sd[d]; }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -194,12 +196,12 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
     for (int w2 = 1; w2 < 4; ++w2) {
       lse_merge(mS, sS, red[w2][0], red[w2][1]);
 #pragma unroll
-      for (int d = 0; d < D; ++d) lse_merge(md[d], sd[d], red[w2][2 + 2 * d], red[w2][3 + 2 * d]);
+      for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) lse_merge(md[d], sd[d], red[w2][2 + 2 * d], red[w2][3 + 2 * d]);
     }
     float* rs = rowstats + (long)il * 16;
     float log_pz = 0.f, log_qzCx = 0.f, log_prod = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
       const float m = mu[(long)i * D + d], l = lv[(long)i * D + d];
       const float diff = zi[d] - m;
       log_qzCx += -0.5f * (LOG2PI + l) - 0.5f * (diff * diff * expf(-l));
@@ -216,13 +218,15 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
 }
 
 // row pass: dz[i] (one wave per local row i)
-template <int D>
+template <int DT>
 __global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict__ z, const float* __restrict__ mu,
                                                          const float* __restrict__ lv, const float* __restrict__ tmp,
                                                          const float* __restrict__ rowstats,
                                                          int Bg, int row0, int Bl, int is_mss,
                                                          const float* __restrict__ log_w, const float* __restrict__ coef,
-                                                         float* __restrict__ dz) {
+                                                         float* __restrict__ dz, int Drt) {
+  constexpr int DM = DT ? DT : 16;          // DT = 0: latent dimension given at run time (<= 16)
+  const int D = DT ? DT : Drt;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int il = blockIdx.x * 4 + wv;
   if (il >= Bl) return;
@@ -234,15 +238,15 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict
   const float* muT = tmp; const float* cT = tmp + (long)D * Bg; const float* ivT = tmp + (long)2 * D * Bg;
   const float* rs = rowstats + (long)il * 16;
   const float lqz = rs[1];
-  float zi[D], lse[D], g[D];
+  float zi[DM], lse[DM], g[DM];
 #pragma unroll
-  for (int d = 0; d < D; ++d) { zi[d] = z[(long)i * D + d]; lse[d] = rs[4 + d]; g[d] = 0.f; }
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) { zi[d] = z[(long)i * D + d]; lse[d] = rs[4 + d]; g[d] = 0.f; }
   for (int j = lane; j < Bg; j += 64) {
     const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
-    float ld[D], r[D];
+    float ld[DM], r[DM];
     float S = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
       const float iv = ivT[(long)d * Bg + j];
       const float diff = zi[d] - muT[(long)d * Bg + j];
       r[d] = diff * iv;
@@ -251,16 +255,16 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict
     }
     const float P = __expf(S - lqz);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
       const float G = cP * P + cQ * __expf(ld[d] - lse[d]);
       g[d] -= G * r[d];
     }
   }
 #pragma unroll
-  for (int d = 0; d < D; ++d) g[d] = wave_sum(g[d]);
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) g[d] = wave_sum(g[d]);
   if (lane == 0) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
       // diagonal terms: alpha * log q(z_i|x_i) / B  and  -gamma' * log p(z_i) / B
       const float m = mu[(long)i * D + d], l = lv[(long)i * D + d];
       const float r = (zi[d] - m) * expf(-l);
@@ -270,12 +274,14 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict
 }
 
 // column pass: dmu[j], dlv[j] summed over the local rows (one wave per column j)
-template <int D>
+template <int DT>
 __global__ __launch_bounds__(256) void k_btcvae_bwd_cols(const float* __restrict__ z, const float* __restrict__ mu,
                                                          const float* __restrict__ lv, const float* __restrict__ rowstats,
                                                          int Bg, int row0, int Bl, int is_mss,
                                                          const float* __restrict__ log_w, const float* __restrict__ coef,
-                                                         float* __restrict__ dmu, float* __restrict__ dlv) {
+                                                         float* __restrict__ dmu, float* __restrict__ dlv, int Drt) {
+  constexpr int DM = DT ? DT : 16;          // DT = 0: latent dimension given at run time (<= 16)
+  const int D = DT ? DT : Drt;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = blockIdx.x * 4 + wv;
   if (j >= Bg) return;
@@ -283,19 +289,19 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_cols(const float* __restrict
   const float alpha = coef[DVAE_C_ALPHA], beta = coef[DVAE_C_BETA], gam = coef[DVAE_C_GAMMA] * coef[DVAE_C_ANNEAL];
   const float invB = 1.f / (float)Bg;
   const float cP = (beta - alpha) * invB, cQ = (gam - beta) * invB;
-  float mj[D], lj[D], ivj[D], gm[D], gl[D];
+  float mj[DM], lj[DM], ivj[DM], gm[DM], gl[DM];
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
     mj[d] = mu[(long)j * D + d]; lj[d] = lv[(long)j * D + d]; ivj[d] = expf(-lj[d]); gm[d] = 0.f; gl[d] = 0.f;
   }
   for (int il = lane; il < Bl; il += 64) {
     const int i = row0 + il;
     const float* rs = rowstats + (long)il * 16;
     const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
-    float ld[D], r[D], diff[D];
+    float ld[DM], r[DM], diff[DM];
     float S = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
       diff[d] = z[(long)i * D + d] - mj[d];
       r[d] = diff[d] * ivj[d];
       ld[d] = (-0.5f * (LOG2PI + lj[d]) - 0.5f * (diff[d] * diff[d] * ivj[d])) + lw;
@@ -303,18 +309,18 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_cols(const float* __restrict
     }
     const float P = __expf(S - rs[1]);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
       const float G = cP * P + cQ * __expf(ld[d] - rs[4 + d]);
       gm[d] += G * r[d];
       gl[d] += G * (-0.5f + 0.5f * r[d] * diff[d]);
     }
   }
 #pragma unroll
-  for (int d = 0; d < D; ++d) { gm[d] = wave_sum(gm[d]); gl[d] = wave_sum(gl[d]); }
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) { gm[d] = wave_sum(gm[d]); gl[d] = wave_sum(gl[d]); }
   if (lane == 0) {
     const bool local = (j >= row0 && j < row0 + Bl);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
       float a = gm[d], b = gl[d];
       if (local) {  // diagonal term alpha * log q(z_j|x_j) / B
         const float diff = z[(long)j * D + d] - mj[d];
@@ -526,12 +532,14 @@ int launch_recon_loss(const float* recon, const float* target, long n, int dist,
 
 int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, int D, int row0, int Bl, int is_mss,
                       const float* log_w, float* tmp, float* rowstats, hipStream_t s) {
-  if (D != 10) return 1;
+  // latent_dim 10 (every reference experiment) has fully unrolled kernels; any other D <= 12 (rowstats holds
+  // 4 + D floats per row) runs the same code with the dimension as a run-time bound
+  if (D < 1 || D > 12) return 1;
   const long n = (long)Bg * D;
   hipLaunchKernelGGL(k_btcvae_prep, dim3((n + 255) / 256), dim3(256), 0, s, mu, lv, Bg, D, tmp);
   DVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_btcvae_fwd<10>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, Bg, row0, Bl, is_mss, log_w,
-                     rowstats);
+  if (D == 10) hipLaunchKernelGGL(k_btcvae_fwd<10>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, Bg, row0, Bl, is_mss, log_w, rowstats, D);
+  else hipLaunchKernelGGL(k_btcvae_fwd<0>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, Bg, row0, Bl, is_mss, log_w, rowstats, D);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -539,12 +547,16 @@ int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, 
 int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const float* rowstats, int Bg, int D, int row0,
                       int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz, float* dmu,
                       float* dlv, hipStream_t s) {
-  if (D != 10) return 1;
-  hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
-                     is_mss, log_w, coef, dz);
+  if (D < 1 || D > 12) return 1;
+  if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
+                                  is_mss, log_w, coef, dz, D);
+  else hipLaunchKernelGGL(k_btcvae_bwd_rows<0>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
+                          is_mss, log_w, coef, dz, D);
   DVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_btcvae_bwd_cols<10>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
-                     is_mss, log_w, coef, dmu, dlv);
+  if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_cols<10>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
+                                  is_mss, log_w, coef, dmu, dlv, D);
+  else hipLaunchKernelGGL(k_btcvae_bwd_cols<0>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
+                          is_mss, log_w, coef, dmu, dlv, D);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

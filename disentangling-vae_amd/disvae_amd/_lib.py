@@ -18,6 +18,8 @@ S_LOSS, S_REC, S_KL, S_KL0, S_MI, S_TC, S_DWKL, S_KLW, S_DTC, NSCAL = 0, 1, 2, 3
 C_INV_B, C_ANNEAL, C_BETA, C_ALPHA, C_GAMMA, C_CAP, NCOEF = 0, 1, 2, 3, 4, 5, 8
 REC_NPART = 2048
 NPACK = 32
+MAX_LATENT_DIM = 16          # DVAE_MAX_D
+BTCVAE_MAX_LATENT_DIM = 12   # DVAE_BTCVAE_MAX_D
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

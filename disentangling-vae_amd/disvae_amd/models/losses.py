@@ -120,7 +120,10 @@ class BaseLoss(abc.ABC):
         # results); "graph" = hipGraph; "auto" (default) = plan while the iteration is launch-bound
         # (batch tensor <= AUTO_PLAN_ELEMS elements: measured cross-over), eager
         # above.  Single-process only (collectives stay eager)
-        self.replay = {"plan": "plan", "graph": "graph", "eager": None, "auto": "auto"}[os.environ.get("DVAE_REPLAY", "auto")]
+        mode = os.environ.get("DVAE_REPLAY", "auto")
+        if mode not in ("plan", "graph", "eager", "auto"):
+            raise ValueError("DVAE_REPLAY={!r}: expected one of auto, eager, plan, graph".format(mode))
+        self.replay = {"plan": "plan", "graph": "graph", "eager": None, "auto": "auto"}[mode]
         self._graphs = StepGraphs()
         self._static = {}
 
@@ -334,6 +337,7 @@ class _SingleOptimizerLoss(BaseLoss):
         sc.set_coef(INV_B=1.0 / (B * world), **self._coefs(is_train))
         data = data.contiguous()
         if self.KIND == _lib.LOSS_BTCVAE:
+            self._check_latent_dim(D)
             sc.set_log_w(B * self._est_world()[0], self.n_data)
         mode = self._replay_mode(is_train, data)
         if mode:
@@ -511,6 +515,12 @@ class BtcvaeLoss(_SingleOptimizerLoss):
         anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
         return dict(ANNEAL=anneal, ALPHA=self.alpha, BETA=self.beta, GAMMA=self.gamma)
 
+    @staticmethod
+    def _check_latent_dim(D):
+        if D > _lib.BTCVAE_MAX_LATENT_DIM:
+            raise ValueError("btcvae: latent_dim={} > {}: the fused B x B estimator kernels keep 4 + latent_dim row "
+                             "statistics in 16 floats".format(D, _lib.BTCVAE_MAX_LATENT_DIM))
+
     def _store(self, storer, vals, D):
         storer['recon_loss'].append(vals[_lib.S_REC])
         storer['loss'].append(vals[_lib.S_LOSS])
@@ -521,6 +531,7 @@ class BtcvaeLoss(_SingleOptimizerLoss):
 
     def __call__(self, data, recon_batch, latent_dist, is_train, storer, latent_sample=None):
         storer = self._pre_call(is_train, storer)
+        self._check_latent_dim(latent_sample.shape[1])
         sc = self.scratch(recon_batch.device)
         rec_loss = _reconstruction_loss(data, recon_batch, storer=storer, distribution=self.rec_dist, scratch=sc)
         terms = _BtcvaeFn.apply(latent_sample, latent_dist[0], latent_dist[1], self.n_data, self.is_mss, sc)

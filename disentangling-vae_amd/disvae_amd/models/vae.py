@@ -62,6 +62,9 @@ class VAE(nn.Module):
         if list(img_size[1:]) not in [[32, 32], [64, 64]]:
             raise RuntimeError("{} sized images not supported. Only (None, 32, 32) and (None, 64, 64) supported. "
                                "Build your own architecture or reshape images!".format(img_size))
+        if not (isinstance(latent_dim, int) and 1 <= latent_dim <= _lib.MAX_LATENT_DIM):
+            raise ValueError("latent_dim={!r}: the fused HIP kernels cover 1 <= latent_dim <= {} (the reference uses 10 in "
+                             "every experiment of hyperparam.ini)".format(latent_dim, _lib.MAX_LATENT_DIM))
         self.latent_dim = latent_dim
         self.img_size = tuple(img_size)
         self.num_pixels = self.img_size[1] * self.img_size[2]

@@ -139,19 +139,58 @@ def clone_params(params, dtype=None, requires_grad=False):
 # --------------------------------------------------------------------------------------
 # model
 # --------------------------------------------------------------------------------------
+# Activation gates (test infrastructure for comparing fp32 and fp64 evaluations of the SAME network):
+# torch.relu / F.leaky_relu are discontinuous in their derivative at 0, so a unit whose pre-activation is
+# within fp32 rounding of zero can be "on" in one arithmetic and "off" in the other, which changes
+# gradients by a finite amount.  ``with gates(masks):`` makes the forward functions below use the
+# given on/off pattern (name -> list of boolean tensors in reference layout, consumed in call order)
+# instead of the sign of their own pre-activation; ``with gates(None, record=log):`` leaves the
+# arithmetic untouched and appends (name, pre-activation) to ``log``.  Default: plain relu / leaky_relu.
+_GATES = None
+_GATE_LOG = None
+
+
+class gates:
+    def __init__(self, masks, record=None):
+        self.masks = None if masks is None else {k: list(v) for k, v in masks.items()}
+        self.record = record
+
+    def __enter__(self):
+        global _GATES, _GATE_LOG
+        self._old = (_GATES, _GATE_LOG)
+        _GATES, _GATE_LOG = self.masks, self.record
+        return self
+
+    def __exit__(self, *exc):
+        global _GATES, _GATE_LOG
+        _GATES, _GATE_LOG = self._old
+        return False
+
+
+def _act(pre, name, slope=0.0):
+    """relu (slope 0) / leaky_relu of layer `name`, honouring an active ``gates`` context."""
+    if _GATE_LOG is not None:
+        _GATE_LOG.append((name, pre.detach()))
+    if _GATES is not None and _GATES.get(name):
+        g = _GATES[name].pop(0).to(pre.device)
+        assert g.shape == pre.shape, (name, g.shape, pre.shape)
+        return pre * torch.where(g, torch.ones((), dtype=pre.dtype), torch.full((), slope, dtype=pre.dtype))
+    return torch.relu(pre) if slope == 0.0 else F.leaky_relu(pre, slope)
+
+
 def encoder_forward(p, x, want_acts=False):
     """EncoderBurgess.forward, disvae/models/encoders.py:69-89."""
     acts = OrderedDict()
     h = x
     names = ["conv1", "conv2", "conv3"] + (["conv_64"] if "encoder.conv_64.weight" in p else [])
     for n in names:
-        h = torch.relu(F.conv2d(h, p["encoder.%s.weight" % n], p["encoder.%s.bias" % n],
-                                stride=2, padding=1))          # encoders.py:73-77
+        h = _act(F.conv2d(h, p["encoder.%s.weight" % n], p["encoder.%s.bias" % n],
+                          stride=2, padding=1), "encoder." + n)   # encoders.py:73-77
         acts["encoder." + n] = h
     h = h.reshape(x.size(0), -1)                                 # encoders.py:80 (c,h,w order)
-    h = torch.relu(F.linear(h, p["encoder.lin1.weight"], p["encoder.lin1.bias"]))  # :81
+    h = _act(F.linear(h, p["encoder.lin1.weight"], p["encoder.lin1.bias"]), "encoder.lin1")  # :81
     acts["encoder.lin1"] = h
-    h = torch.relu(F.linear(h, p["encoder.lin2.weight"], p["encoder.lin2.bias"]))  # :82
+    h = _act(F.linear(h, p["encoder.lin2.weight"], p["encoder.lin2.bias"]), "encoder.lin2")  # :82
     acts["encoder.lin2"] = h
     ml = F.linear(h, p["encoder.mu_logvar_gen.weight"], p["encoder.mu_logvar_gen.bias"])  # :86
     acts["encoder.mu_logvar_gen"] = ml
@@ -177,13 +216,13 @@ def decoder_forward(p, z, want_acts=False):
     acts = OrderedDict()
     h = z
     for n in ["lin1", "lin2", "lin3"]:
-        h = torch.relu(F.linear(h, p["decoder.%s.weight" % n], p["decoder.%s.bias" % n]))  # :71-73
+        h = _act(F.linear(h, p["decoder.%s.weight" % n], p["decoder.%s.bias" % n]), "decoder." + n)  # :71-73
         acts["decoder." + n] = h
     h = h.view(z.size(0), HID_CHANNELS, KERNEL_SIZE, KERNEL_SIZE)                            # :74
     names = (["convT_64"] if "decoder.convT_64.weight" in p else []) + ["convT1", "convT2"]
     for n in names:
-        h = torch.relu(F.conv_transpose2d(h, p["decoder.%s.weight" % n], p["decoder.%s.bias" % n],
-                                          stride=2, padding=1))                              # :77-80
+        h = _act(F.conv_transpose2d(h, p["decoder.%s.weight" % n], p["decoder.%s.bias" % n],
+                                    stride=2, padding=1), "decoder." + n)                   # :77-80
         acts["decoder." + n] = h
     h = torch.sigmoid(F.conv_transpose2d(h, p["decoder.convT3.weight"], p["decoder.convT3.bias"],
                                          stride=2, padding=1))                               # :82
@@ -205,7 +244,7 @@ def discriminator_forward(dp, z):
     """Discriminator.forward, disvae/models/discriminator.py:60-70."""
     h = z
     for i in range(1, 6):
-        h = F.leaky_relu(F.linear(h, dp["lin%d.weight" % i], dp["lin%d.bias" % i]), DISC_SLOPE)
+        h = _act(F.linear(h, dp["lin%d.weight" % i], dp["lin%d.bias" % i]), "disc.lin%d" % i, DISC_SLOPE)
     return F.linear(h, dp["lin6.weight"], dp["lin6.bias"])
 
 

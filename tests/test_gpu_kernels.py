@@ -2,6 +2,7 @@
 seeded inputs.  Tolerance: rtol 1e-4 plus 2e-5 x max|ref| (fp32 accumulation-order noise)."""
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -245,12 +246,30 @@ def test_recon_loss(dist):
     check(out, lr.grad, rtol=1e-4, atol_rel=1e-6, what="sigmoid bwd")
 
 
-@pytest.mark.parametrize("B,n_data,mss", [(4, 100, True), (4, 100, False), (8, 737280, True), (64, 202599, True),
-                                          (256, 737280, True), (1024, 202599, True), (100, 5000, True)])
-def test_btcvae_fwd_bwd(B, n_data, mss):
-    D = 10
-    if B == 4:   # the RNG-free KAT of SURVEY 8c uses D = 3: embed it in D = 10 is not possible; use random D=10 too
-        pass
+def test_btcvae_kat_reference_values():
+    """The RNG-free known-answer vectors recorded from the REAL reference (tests/golden/kats.npz; SURVEY 8c:
+    B=4, D=3, i=arange(12).view(4,3), mu=sin(i), logvar=0.5cos(i), eps=cos(2i+1), n_data=100) through the HIP
+    estimator kernel (run-time latent dimension 3), with and without minibatch-stratified weights."""
+    from golden_util import load
+    from disvae_amd.utils.math import log_importance_weights
+    kat = load("kats")
+    B, D = 4, 3
+    i = torch.arange(12, dtype=torch.float32).view(B, D)
+    mu, lv, eps = torch.sin(i), 0.5 * torch.cos(i), torch.cos(2 * i + 1)
+    z = mu + torch.exp(0.5 * lv) * eps
+    lw = torch.zeros(4); lw[:3] = log_importance_weights(B, 100)
+    for mss in (1, 0):
+        rs = torch.empty(B, 16, device=DEV)
+        tmp = torch.empty(3 * D, B, device=DEV)
+        call("dvae_btcvae_fwd", ptr(dev(z)), ptr(dev(mu)), ptr(dev(lv)), B, D, 0, B, mss, ptr(dev(lw)), ptr(tmp), ptr(rs), stream())
+        for k, nm in enumerate(["log_pz", "log_qz", "log_prod_qzi", "log_q_zCx"]):
+            np.testing.assert_allclose(rs[:, k].cpu().numpy(), kat["kat_%s_mss%d" % (nm, mss)], rtol=1e-5, atol=1e-6, err_msg=nm)
+
+
+@pytest.mark.parametrize("B,n_data,mss,D", [(4, 100, True, 10), (4, 100, False, 10), (8, 737280, True, 10), (64, 202599, True, 10),
+                                            (256, 737280, True, 10), (1024, 202599, True, 10), (100, 5000, True, 10),
+                                            (70, 5000, True, 1), (300, 202599, True, 6), (256, 737280, True, 12)])
+def test_btcvae_fwd_bwd(B, n_data, mss, D):
     g = torch.Generator().manual_seed(B)
     mu = torch.randn(B, D, generator=g)
     lv = torch.randn(B, D, generator=g) * 0.7 - 0.5

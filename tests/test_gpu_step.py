@@ -386,3 +386,43 @@ def test_replay_device_rng_trains(loss, mode, tmp_path):
     assert all(np.isfinite(losses))
     assert len(set(losses[5:])) > 30                   # noise differs from replay to replay
     assert np.mean(losses[-5:]) < 0.95 * np.mean(losses[:5])
+
+
+@pytest.mark.parametrize("loss,D", [("btcvae", 4), ("btcvae", 12), ("betaH", 16), ("factor", 7)])
+def test_fused_step_other_latent_dims(loss, D):
+    """--latent-dim other than 10 (main.py: any value; vae.py:30): the estimator / reparameterisation kernels take
+    the latent dimension at run time (1..12 for btcvae, 1..16 otherwise)."""
+    img, B, seed, n_data, lr = (1, 64, 64), 24, 99, 737280, 5e-4
+    torch.manual_seed(seed)
+    model = init_specific_model("Burgess", img, D)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    hp = dict(HP, latent_dim=D, n_data=n_data)
+    loss_f = get_loss_f(loss, device=torch.device(DEV), **hp)
+    model.to(DEV).train()
+    torch.manual_seed(seed)
+    p0 = O.init_vae_params(img, D)
+    gen = torch.Generator().manual_seed(seed + 1)
+    data = torch.rand((B,) + img, generator=gen)
+    st = O.LossState(steps_anneal=HP["reg_anneal"])
+    c64 = lambda p: O.clone_params(p, dtype=torch.float64, requires_grad=True)
+    storer = defaultdict(list)
+    if loss == "factor":
+        d0 = O.init_disc_params(D)
+        Bh = B // 2
+        eps1, eps2 = torch.randn(Bh, D, generator=gen), torch.randn(Bh, D, generator=gen)
+        perms = torch.stack([torch.randperm(Bh, generator=gen) for _ in range(D)])
+        ref_loss, ref_logs, g64, gd64, _ = O.factor_iteration_grads(hp, st, c64(p0), c64(d0), data.double(), eps1.double(),
+                                                                    eps2.double(), list(perms))
+        out = loss_f.call_optimize(dev(data), model, opt, storer, noise=(dev(eps1), dev(eps2), perms))
+        for k, p in loss_f.discriminator.named_parameters():
+            check(p.grad, gd64[k], rtol=1e-3, atol_rel=1e-4, what="D=%d disc grad %s" % (D, k))
+    else:
+        eps = torch.randn(B, D, generator=gen)
+        ref_loss, ref_logs, g64, _ = O.train_iteration_grads(loss, hp, st, c64(p0), data.double(), eps.double())
+        out = loss_f.fused_step(dev(data), model, opt, storer, eps=dev(eps))
+    np.testing.assert_allclose(out.item(), ref_loss.item(), rtol=2e-5)
+    assert list(storer.keys()) == list(ref_logs.keys())
+    for k in ref_logs:
+        np.testing.assert_allclose(storer[k][0], ref_logs[k].item(), rtol=5e-5, atol=1e-6, err_msg=k)
+    for k, p in model.named_parameters():
+        check(p.grad, g64[k], rtol=1e-3, atol_rel=1e-4, what="D=%d grad %s" % (D, k))

@@ -189,3 +189,28 @@ def test_bench_algorithmic_flops_match_survey():
     assert abs(bench.flops_per_image_train(1) / 1e6 - 73.71) < 0.01
     assert abs(2.0 * 4194304 * 1024 / 1e9 - 8.59) < 0.01
     assert bench.PEAK_FP32_MFMA_TFLOPS == 157.3 and bench.PEAK_HBM_GBS == 8000.0
+
+
+def test_latent_dim_limits_are_reported_clearly():
+    """unsupported latent dimensions must fail at construction / first use with a clear message, not
+    with a generic 'bad argument' from the C-ABI at the first training step."""
+    import pytest
+    from disvae_amd.models.vae import init_specific_model
+    from disvae_amd.models.losses import BtcvaeLoss
+    for D in (1, 10, 16):
+        assert init_specific_model("Burgess", (1, 32, 32), D).latent_dim == D
+    with pytest.raises(ValueError, match="latent_dim"):
+        init_specific_model("Burgess", (1, 32, 32), 17)
+    with pytest.raises(ValueError, match="latent_dim"):
+        init_specific_model("Burgess", (1, 32, 32), 0)
+    with pytest.raises(ValueError, match="btcvae: latent_dim=13"):
+        BtcvaeLoss(1000)._check_latent_dim(13)
+    BtcvaeLoss(1000)._check_latent_dim(12)
+
+
+def test_unknown_replay_mode_is_reported(monkeypatch):
+    import pytest
+    from disvae_amd.models.losses import BetaHLoss
+    monkeypatch.setenv("DVAE_REPLAY", "sometimes")
+    with pytest.raises(ValueError, match="DVAE_REPLAY"):
+        BetaHLoss()
