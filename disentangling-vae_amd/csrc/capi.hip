@@ -167,6 +167,13 @@ int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int
   return launch_linear_wgrad(x, dy, dw, db, M, K, N, ws, dvae_conv_wgrad_ws_floats(), (hipStream_t)stream);
 }
 
+int dvae_linear_wgrad_grouped(const dvae_linear_wgrad_desc* descs, int n, void* stream) {
+  DVAE_CHECK_ARG(descs && n >= 1 && n <= DVAE_FCW_MAX);
+  for (int q = 0; q < n; ++q)
+    DVAE_CHECK_ARG(descs[q].x && descs[q].dy && descs[q].dw && descs[q].M > 0 && descs[q].K > 0 && descs[q].N > 0);
+  return launch_linear_wgrad_grouped(descs, n, (hipStream_t)stream);
+}
+
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                         const float* coef, int B, int D, void* stream) {
   DVAE_CHECK_ARG(ml && mu && logvar && z && B > 0 && D > 0 && D <= DVAE_MAX_D);    // kl_dim without coef: partials only

@@ -132,6 +132,8 @@ int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int
 int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, float* ws,
                         size_t ws_floats, hipStream_t s);
 
+int launch_linear_wgrad_grouped(const dvae_linear_wgrad_desc* d, int n, hipStream_t s);
+
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                           const float* coef, int B, int D, hipStream_t s);
 int launch_reparam_kl_bwd(const float* dz, const float* dz2, const float* dz3, const float* dmu_x, const float* dlv_x, const float* mu, const float* logvar,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "dvae_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "dvae_linear_dgrad": [_p, _p, _p, _i, _p, _i, _i, _i, _p, _p],
     "dvae_linear_wgrad": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
+    "dvae_linear_wgrad_grouped": [_p, _i, _p],
     "dvae_reparam_kl_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_recon_loss": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
@@ -56,6 +57,23 @@ SIGNATURES = {
     "dvae_add": [_p, _p, _p, _l, _p],
 }
 _RESTYPE = {"dvae_last_error": ctypes.c_char_p, "dvae_conv_wgrad_ws_floats": ctypes.c_size_t}
+
+
+FCW_MAX = 8
+
+
+class LinearWgradDesc(ctypes.Structure):
+    """dvae_linear_wgrad_desc (include/dvae_hip.h)."""
+    _fields_ = [("x", _p), ("dy", _p), ("dw", _p), ("db", _p), ("M", _i), ("K", _i), ("N", _i)]
+
+
+def wgrad_descs(problems):
+    """[(x, dy, dw, db, M, K, N), ...] (device pointers as ints) -> (host array, its address).  The array must stay
+    alive as long as a recorded launch plan may replay the call: callers keep it."""
+    arr = (LinearWgradDesc * len(problems))()
+    for d, (x, dy, dw, db, M, K, N) in zip(arr, problems):
+        d.x, d.dy, d.dw, d.db, d.M, d.K, d.N = x, dy, dw, db, M, K, N
+    return arr, ctypes.addressof(arr)
 
 
 class DvaeHipError(RuntimeError):

@@ -158,6 +158,8 @@ class VAEEngine:
         self._ws = None
         self._ws_side = None
         self._side = None      # side HIP stream: the FC weight-gradient GEMMs run beside the dgrad chain
+        self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
+        self._fc_descs = {}    # host descriptor arrays of the grouped launches, kept alive for recorded plans
 
     @property
     def device(self):
@@ -198,6 +200,19 @@ class VAEEngine:
         current stream does next."""
         call("dvae_linear_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(db), M, K, N, ptr(self._ws_side),
              self._side.cuda_stream)
+
+    def _side_wgrad_grouped(self, problems):
+        """All FC weight gradients of `problems` = [(x, dy, dw, db, M, K, N)] (tensors) in ONE launch on the side stream
+        (dvae_linear_wgrad_grouped): ~400 short-lived workgroups instead of six launches that each leave most of
+        the chip idle and delay the conv weight gradients queued behind them."""
+        key = tuple((ptr(x), ptr(dy), ptr(dw), ptr(db), M, K, N) for x, dy, dw, db, M, K, N in problems)
+        ent = self._fc_descs.get(key)
+        if ent is None:
+            if len(self._fc_descs) >= 64:        # recorded plans hold the addresses of these arrays: invalidate them
+                self._fc_descs.clear()
+                _lib.note_alloc()
+            ent = self._fc_descs[key] = _lib.wgrad_descs(key)
+        call("dvae_linear_wgrad_grouped", ent[1], len(problems), self._side.cuda_stream)
 
     def _conv_wgrad(self, fn, *args, fork=True):
         """Conv / convT weight gradient `fn(*args, ws, stream)`: off the dgrad critical path, so it
@@ -273,8 +288,10 @@ class VAEEngine:
                  ptr(coef), ptr(partials), B, HID, h, h, c, s)
 
     # ------------------------------------------------------------------ backward
-    def decode_backward(self, z, buf, n=None, join=True):
-        """buf.g_logit (grad w.r.t. the pre-sigmoid output) -> decoder weight grads, buf.dz."""
+    def decode_backward(self, z, buf, n=None, join=True, defer_fc_wgrad=False):
+        """buf.g_logit (grad w.r.t. the pre-sigmoid output) -> decoder weight grads, buf.dz.
+        defer_fc_wgrad: the three FC weight gradients are not launched here but handed to the next
+        encode_backward, which computes all six FC weight gradients of the step in one grouped launch."""
         s = _stream()
         B = z.shape[0] if n is None else n
         D = self.latent_dim
@@ -325,9 +342,13 @@ class VAEEngine:
         self.fork_side()
         for wargs in deferred:
             self._conv_wgrad(*wargs, fork=False)
-        self._side_wgrad(buf.d2, buf.gd3, self.g("decoder.lin3.weight"), self.g("decoder.lin3.bias"), B, HIDDEN_DIM, HID * 16)
-        self._side_wgrad(buf.d1, buf.gd2, self.g("decoder.lin2.weight"), self.g("decoder.lin2.bias"), B, HIDDEN_DIM, HIDDEN_DIM)
-        self._side_wgrad(z, buf.gd1, self.g("decoder.lin1.weight"), self.g("decoder.lin1.bias"), B, D, HIDDEN_DIM)
+        fc = [(buf.d2, buf.gd3, self.g("decoder.lin3.weight"), self.g("decoder.lin3.bias"), B, HIDDEN_DIM, HID * 16),
+              (buf.d1, buf.gd2, self.g("decoder.lin2.weight"), self.g("decoder.lin2.bias"), B, HIDDEN_DIM, HIDDEN_DIM),
+              (z, buf.gd1, self.g("decoder.lin1.weight"), self.g("decoder.lin1.bias"), B, D, HIDDEN_DIM)]
+        if defer_fc_wgrad:
+            self._fc_pending = fc
+        else:
+            self._side_wgrad_grouped(fc)
         if join:
             self._join_side()
 
@@ -343,13 +364,17 @@ class VAEEngine:
              B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
              ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, ws, s)
-        # weight gradients wait for the next fork (they only have to be done by the end of the backward pass)
-        deferred = [lambda: self._side_wgrad(buf.h2, buf.dml, self.g("encoder.mu_logvar_gen.weight"),
-                                             self.g("encoder.mu_logvar_gen.bias"), B, HIDDEN_DIM, 2 * self.latent_dim),
-                    lambda: self._side_wgrad(buf.h1, buf.gh2, self.g("encoder.lin2.weight"), self.g("encoder.lin2.bias"),
-                                             B, HIDDEN_DIM, HIDDEN_DIM),
-                    lambda: self._side_wgrad(buf.a_flat, buf.gh1, self.g("encoder.lin1.weight"), self.g("encoder.lin1.bias"),
-                                             B, HID * 16, HIDDEN_DIM)]
+        # weight gradients wait for the next fork (they only have to be done by the end of the backward pass): the
+        # encoder's three FC layers + the decoder's three when decode_backward deferred them = one grouped launch
+        pend, self._fc_pending = [p_ for p_ in self._fc_pending if p_[4] == B], []
+        # largest problems first (128, 128, 64, 64, 8, 8 tiles): the long-running workgroups start first
+        fc = ([(buf.a_flat, buf.gh1, self.g("encoder.lin1.weight"), self.g("encoder.lin1.bias"), B, HID * 16, HIDDEN_DIM)]
+              + pend[:1]
+              + [(buf.h1, buf.gh2, self.g("encoder.lin2.weight"), self.g("encoder.lin2.bias"), B, HIDDEN_DIM, HIDDEN_DIM)]
+              + pend[1:]
+              + [(buf.h2, buf.dml, self.g("encoder.mu_logvar_gen.weight"), self.g("encoder.mu_logvar_gen.bias"),
+                  B, HIDDEN_DIM, 2 * self.latent_dim)])
+        deferred = [lambda fc=fc: self._side_wgrad_grouped(fc)]
         last = len(self.enc_names) - 1
         for k in range(last, -1, -1):
             name = self.enc_names[k]

@@ -423,7 +423,9 @@ class _SingleOptimizerLoss(BaseLoss):
                  ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), s)
         if not is_train:
             return
-        eng.decode_backward(buf.z, buf, join=world > 1)     # single process: one join, at the end of the backward pass
+        # single process: one join, at the end of the backward pass, and ONE grouped launch for all six FC weight
+        # gradients (issued by encode_backward); sharded: the decoder's gradients are all-reduced early, so they are final here
+        eng.decode_backward(buf.z, buf, join=world > 1, defer_fc_wgrad=world == 1)
         pending = []
         if world > 1:      # decoder gradients are final: their all-reduce overlaps the encoder backward
             pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
@@ -623,7 +625,7 @@ class FactorKLoss(BaseLoss):
         dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
         # tc term of vae_loss through D: dgrad only, first half (its disc weight grads are zeroed at :303)
         dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2")
-        eng.decode_backward(buf.z, buf, n=Bh, join=world > 1)   # single process: joined at the end of encode_backward
+        eng.decode_backward(buf.z, buf, n=Bh, join=world > 1, defer_fc_wgrad=world == 1)   # single process: joined at the end of encode_backward
         # dz_a: quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1); dz_b: the tc term through D
         call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dz_a), ptr(dz_b), None, None, ptr(buf.mu), ptr(buf.logvar), ptr(eps1), ptr(sc.scal),
              ptr(sc.coef), ptr(buf.dml), Bh, D, s)

@@ -255,7 +255,7 @@ class _VAEFn(torch.autograd.Function):
         dz = g_z.contiguous() if g_z is not None else None
         if ctx.decode and g_recon is not None:
             call("dvae_sigmoid_bwd", ptr(g_recon.contiguous()), ptr(buf.recon), ptr(buf.g_logit), buf.recon.numel(), s)
-            eng.decode_backward(buf.z, buf)
+            eng.decode_backward(buf.z, buf, defer_fc_wgrad=True)     # encode_backward below launches all six FC wgrads
             if dz is not None:
                 call("dvae_add", ptr(buf.dz), ptr(dz), ptr(buf.dz), buf.dz.numel(), s)
             dz = buf.dz

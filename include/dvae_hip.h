@@ -103,6 +103,21 @@ int dvae_linear_dgrad(const float* dy, const float* w, const float* x_act, int a
 int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N,
                       float* ws, void* stream);
 
+/* Grouped form of dvae_linear_wgrad: n <= DVAE_FCW_MAX independent problems (the weight gradients of the six
+ * fully-connected layers of the VAE, encoders.py:63-67 / decoders.py:53-55 under training.py:157) in ONE launch of
+ * ~400 short-lived workgroups instead of six chip-starving ones.  `descs` is a HOST array read during the call (not
+ * retained).  Fixed summation order (deterministic), no workspace; rows need no alignment (16-byte loads are used
+ * where a problem's rows allow them).                                                                               */
+#define DVAE_FCW_MAX 8
+typedef struct {
+  const float* x;   /* [M,K] layer input                    */
+  const float* dy;  /* [M,N] gradient w.r.t. the pre-activation output */
+  float* dw;        /* [N,K] */
+  float* db;        /* [N] or NULL */
+  int M, K, N;
+} dvae_linear_wgrad_desc;
+int dvae_linear_wgrad_grouped(const dvae_linear_wgrad_desc* descs, int n, void* stream);
+
 /* ---- reparameterisation + per-dim Gaussian KL: vae.py:52-71, losses.py:452-480 -----------
  * ml[B,2D] is the interleaved output of mu_logvar_gen (encoders.py:87: mu = ml[:,0::2],
  * logvar = ml[:,1::2]).  z = mu + exp(.5 logvar) eps (eps == NULL: z = mu, eval mode).

@@ -436,3 +436,32 @@ def test_4x4_end_of_the_conv_stack_reads_nchw(N, generic):
         call("dvae_conv4s2_wgrad", ptr(nhwc(xin)), _lib.NHWC, ptr(dev(g)), _lib.NCHW, ptr(dw2), ptr(db2), N, C, 8, 8, C, ptr(ws), stream())
         check(dw2, wr2.grad, what="conv wgrad <- NCHW dy")
         check(db2, br2.grad, what="conv bias grad <- NCHW dy")
+
+
+@pytest.mark.parametrize("M", [3, 64, 100, 128, 1024, 1500])
+def test_linear_wgrad_grouped(M):
+    """dvae_linear_wgrad_grouped: the six FC weight gradients of a training step (encoder lin1/lin2/mu_logvar_gen,
+    decoder lin1/lin2/lin3: encoders.py:63-67, decoders.py:53-55) + ragged shapes in ONE launch, vs fp64."""
+    shapes = [(512, 256), (256, 512), (256, 256), (10, 256), (256, 20), (7, 33), (100, 36), (256, 256)]   # (K, N)
+    probs, refs, outs = [], [], []
+    for q, (K, N) in enumerate(shapes):
+        x, dy = _rand(M, K, seed=10 + q), _rand(M, N, seed=30 + q)
+        xd, dyd = dev(x), dev(dy)
+        dw, db = torch.full((N, K), 7.0, device=DEV), torch.full((N,), 7.0, device=DEV)
+        if q == 5:
+            db = None                                  # db is optional
+        probs.append((ptr(xd), ptr(dyd), ptr(dw), ptr(db), M, K, N))
+        refs.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+        outs.append((dw, db))
+    arr, addr = _lib.wgrad_descs(probs)
+    call("dvae_linear_wgrad_grouped", addr, len(probs), stream())
+    for q, ((dw, db), (rw, rb)) in enumerate(zip(outs, refs)):
+        check(dw, rw, rtol=1e-5, atol_rel=2e-6, what="grouped wgrad dw[%d] M=%d" % (q, M))
+        if db is not None:
+            check(db, rb, rtol=1e-5, atol_rel=2e-6, what="grouped wgrad db[%d] M=%d" % (q, M))
+    # a sub-group (3 problems) gives bit-identical results: the decomposition of a problem does not depend on its neighbours
+    dw2, db2 = torch.empty_like(outs[0][0]), torch.empty_like(outs[0][1])
+    p0 = probs[0]
+    arr2, addr2 = _lib.wgrad_descs([probs[3], (p0[0], p0[1], ptr(dw2), ptr(db2), M, p0[5], p0[6]), probs[4]])
+    call("dvae_linear_wgrad_grouped", addr2, 3, stream())
+    assert torch.equal(dw2, outs[0][0]) and torch.equal(db2, outs[0][1])
