@@ -738,7 +738,11 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
   using G = Geo<HS>;
   const int n_units = units_for(N, HS);
   // (capping the persistent grid to leave CUs to the dgrad stream was measured: 128 -> +10 % step time)
-  const int grid = n_units < WG_MAX_BLOCKS ? n_units : WG_MAX_BLOCKS;
+  int grid = n_units < WG_MAX_BLOCKS ? n_units : WG_MAX_BLOCKS;
+  {
+    static const int cap = env_int("DVAE_WGRAD_GRID", WG_MAX_BLOCKS);   // debug builds: A/B of the persistent grid size
+    if (cap > 0 && cap < grid) grid = cap;
+  }
   const size_t lds = (G::BIG_FLOATS + 64 * 32) * sizeof(float);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }

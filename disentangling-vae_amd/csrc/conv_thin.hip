@@ -473,7 +473,11 @@ int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db
                       int Hs, float* ws, hipStream_t s) {
   if (!(Cb == 1 || Cb == 3) || Hs != 32) return 1;
   const int n_units = N * 8;
-  const int grid = n_units < WT_MAX_BLOCKS ? n_units : WT_MAX_BLOCKS;
+  int grid = n_units < WT_MAX_BLOCKS ? n_units : WT_MAX_BLOCKS;
+  {
+    static const int cap = env_int("DVAE_WGRAD_THIN_GRID", WT_MAX_BLOCKS);   // debug builds: A/B of the persistent grid size
+    if (cap > 0 && cap < grid) grid = cap;
+  }
   if (Cb == 1) {
     hipLaunchKernelGGL(k_wgrad_thin<1>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
