@@ -138,6 +138,41 @@ int dvae_convT4s2_sigmoid_recon_fwd(const float* x, int x_layout, const float* w
   return launch_recon_loss(recon, target, n, dist, coef, partials, g, 1, (hipStream_t)stream);
 }
 
+// ---- uint8 input pipeline (utils/datasets.py:204-213,282-291: ToTensor fused into the consumers) ----------
+static bool u8_fused_shape(int C, int H, int W, int Cout) { return (C == 1 || C == 3) && H == 64 && W == 64 && Cout == 32; }
+
+int dvae_u8_to_f32(const uint8_t* src, float* dst, long n, void* stream) {
+  DVAE_CHECK_ARG(src && dst && n > 0 && (((uintptr_t)src & 15) == 0) && (((uintptr_t)dst & 15) == 0));
+  return launch_u8_to_f32(src, dst, n, (hipStream_t)stream);
+}
+
+int dvae_u8_fused_supported(int C, int H, int W) { return u8_fused_shape(C, H, W, 32) ? 1 : 0; }
+
+int dvae_conv4s2_fwd_u8(const uint8_t* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,
+                        int Cout, int act, void* stream) {
+  DVAE_CHECK_ARG(x && w && y && N > 0);
+  DVAE_CHECK_ARG(u8_fused_shape(Cin, H, W, Cout));
+  DVAE_CHECK_ARG(act == DVAE_ACT_NONE || act == DVAE_ACT_RELU);
+  return launch_down_thin_u8(x, w, b, y, N, Cin, act, (hipStream_t)stream);
+}
+
+int dvae_conv4s2_wgrad_u8(const uint8_t* x, const float* dy, float* dw, float* db, int N, int Cin, int H, int W,
+                          int Cout, float* ws, void* stream) {
+  DVAE_CHECK_ARG(x && dy && dw && ws && N > 0);
+  DVAE_CHECK_ARG(u8_fused_shape(Cin, H, W, Cout));
+  return launch_wgrad_thin_u8(x, dy, dw, db, N, Cin, ws, (hipStream_t)stream);
+}
+
+int dvae_convT4s2_sigmoid_recon_fwd_u8(const float* x, const float* w, const float* b, const uint8_t* target,
+                                       float* recon, float* g, int dist, const float* coef, float* partials, int N,
+                                       int Cin, int H, int W, int Cout, void* stream) {
+  DVAE_CHECK_ARG(x && w && target && recon && g && coef && partials && N > 0);
+  DVAE_CHECK_ARG(Cin == 32 && u8_fused_shape(Cout, 2 * H, 2 * W, 32));
+  DVAE_CHECK_ARG(dist == DVAE_REC_BERNOULLI || dist == DVAE_REC_GAUSSIAN || dist == DVAE_REC_LAPLACE);
+  ConvArgs a{nullptr, 0, x, DVAE_NHWC, w, b, nullptr, recon, DVAE_NCHW, N, Cout, Cin, H, W, DVAE_ACT_SIGMOID};
+  return launch_up_thin_recon_u8(a, target, g, dist, coef, partials, (hipStream_t)stream);
+}
+
 size_t dvae_conv_wgrad_ws_floats(void) {
   size_t a = wgrad32_ws_floats(), b = wgrad_thin_ws_floats();
   return a > b ? a : b;

@@ -120,6 +120,12 @@ int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int d
                          float* partials, hipStream_t s);
 int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big,
                       int N, int Cb, int Hs, float* ws, hipStream_t s);
+// uint8 input image x[N,C,64,64] (NCHW), converted on the fly with ToTensor's float(v)/255; return 1 if C is not 1 or 3
+int launch_down_thin_u8(const uint8_t* x, const float* w, const float* bias, float* out, int N, int C, int act, hipStream_t s);
+int launch_up_thin_recon_u8(const ConvArgs& a, const uint8_t* target, float* g, int dist, const float* coef,
+                            float* partials, hipStream_t s);
+int launch_wgrad_thin_u8(const uint8_t* x, const float* small, float* dw, float* db, int N, int C, float* ws, hipStream_t s);
+int launch_u8_to_f32(const uint8_t* src, float* dst, long n, hipStream_t s);
 
 size_t wgrad32_ws_floats();
 size_t wgrad_thin_ws_floats();

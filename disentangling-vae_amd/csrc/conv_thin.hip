@@ -27,8 +27,15 @@ namespace dvae {
 template <int C>
 struct BigThinRegs { float v[(C * TB_ROWS + 3) / 4]; };
 
-template <int C>
-__device__ __forceinline__ void load_big_thin(BigThinRegs<C>& r, const float* __restrict__ big, int n, int sy0,
+// Input elements: fp32, or uint8 pixels as the datasets store them (dSprites imgs * 255, CelebA imread:
+// utils/datasets.py:204-213,282-291) converted on the fly with ToTensor's arithmetic, float(v) / 255 (IEEE
+// division: bit-identical to torchvision's .div(255)).  The batch then stays uint8 in HBM: the three kernels that
+// read the input image (conv1 forward, conv1 weight gradient, reconstruction likelihood) fetch 1 byte per pixel.
+__device__ __forceinline__ float to_unit(float v) { return v; }
+__device__ __forceinline__ float to_unit(uint8_t v) { return (float)v / 255.0f; }
+
+template <int C, typename TB>
+__device__ __forceinline__ void load_big_thin(BigThinRegs<C>& r, const TB* __restrict__ big, int n, int sy0,
                                               bool valid, int tid) {
   const int tx = tid & 63, ty = tid >> 6;
 #pragma unroll
@@ -38,7 +45,7 @@ __device__ __forceinline__ void load_big_thin(BigThinRegs<C>& r, const float* __
     const int by = 2 * sy0 - 1 + rr;
     const bool ok = valid && pr < C * TB_ROWS && by >= 0 && by < 64;
     const long off = ok ? ((((long)n * C + cb) * 64 + by) * 64 + tx) : 0;
-    const float v = big[off];
+    const float v = to_unit(big[off]);
     r.v[k] = ok ? v : 0.f;
   }
 }
@@ -67,8 +74,8 @@ __device__ __forceinline__ void store_big_thin(const BigThinRegs<C>& r, float* b
 // persistent workgroups (4 waves = 4 small rows of 32 pixels per unit); weights go through LDS
 // once per workgroup (coalesced read, transposed [k][cs] image) into 8*C VGPRs per lane; the
 // next unit's big tile is prefetched into registers during the MFMA phase.
-template <int C, bool MASK>
-__global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big, const float* __restrict__ w,
+template <int C, bool MASK, typename TB = float>
+__global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, const float* __restrict__ w,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    float* __restrict__ out, int N, int act, int n_units) {
   __shared__ float bt[C * TB_PLANE];
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big
   }
   BigThinRegs<C> pf;
   int unit = blockIdx.x;
-  if (unit < n_units) load_big_thin<C>(pf, big, unit >> 3, (unit & 7) * 4, true, tid);
+  if (unit < n_units) load_big_thin<C, TB>(pf, big, unit >> 3, (unit & 7) * 4, true, tid);
   __syncthreads();
   float wreg[8 * C];                                     // B operand: w[cs = i][k = 2*kk + h]
 #pragma unroll
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big
     store_big_thin<C>(pf, bt, tid);
     __syncthreads();
     const int nu = unit + gridDim.x;
-    if (nu < n_units) load_big_thin<C>(pf, big, nu >> 3, (nu & 7) * 4, true, tid);
+    if (nu < n_units) load_big_thin<C, TB>(pf, big, nu >> 3, (nu & 7) * 4, true, tid);
     const long rowbase = ((((long)n * 32 + sy0 + sy_l) * 32)) * 32 + i;
     float mv[16];
     if (MASK) {
@@ -137,10 +144,10 @@ __global__ __launch_bounds__(256) void k_down_thin(const float* __restrict__ big
 // reconstruction likelihood, its per-workgroup partial sum and dL/dlogit come out of the same pass.
 #define UT_ROWS 6
 #define UT_COLS 34
-template <int C, bool FUSE>
+template <int C, bool FUSE, typename TT = float>
 __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small, const float* __restrict__ w,
                                                  const float* __restrict__ bias, float* __restrict__ out, int N,
-                                                 int act, int n_units, const float* __restrict__ target,
+                                                 int act, int n_units, const TT* __restrict__ target,
                                                  float* __restrict__ g, int dist, const float* __restrict__ coef,
                                                  float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) float st[UT_ROWS * UT_COLS * 32];
@@ -231,10 +238,17 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
           const long o = ((((long)n * C + cb) * 64) + 2 * sy + py) * 64 + 2 * l;
           *reinterpret_cast<float2*>(out + o) = make_float2(v0, v1);
           if (FUSE) {
-            const float2 xt = *reinterpret_cast<const float2*>(target + o);
+            float xt0, xt1;
+            if constexpr (sizeof(TT) == 4) {
+              const float2 xt = *reinterpret_cast<const float2*>(target + o);
+              xt0 = xt.x; xt1 = xt.y;
+            } else {
+              const uchar2 xt = *reinterpret_cast<const uchar2*>(target + o);
+              xt0 = to_unit(xt.x); xt1 = to_unit(xt.y);
+            }
             float gl0, gl1, gr;
-            lsum += recon_elem(v0, xt.x, dist, &gl0, &gr);
-            lsum += recon_elem(v1, xt.y, dist, &gl1, &gr);
+            lsum += recon_elem(v0, xt0, dist, &gl0, &gr);
+            lsum += recon_elem(v1, xt1, dist, &gl1, &gr);
             *reinterpret_cast<float2*>(g + o) = make_float2(gs * gl0, gs * gl1);
           }
         }
@@ -253,8 +267,8 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
 
 // ---- wgrad_thin ----------------------------------------------------------------------------
 #define WT_MAX_BLOCKS 512
-template <int C>
-__global__ __launch_bounds__(256) void k_wgrad_thin(const float* __restrict__ big, const float* __restrict__ small,
+template <int C, typename TB = float>
+__global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, const float* __restrict__ small,
                                                     float* __restrict__ ws, int N, int n_units) {
   constexpr int NT = (16 * C + 31) / 32;   // N-tiles of 32 (cb,tap) columns
   __shared__ __attribute__((aligned(16))) float bt[C * TB_PLANE];
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const float* __restrict__ bi
   f32x4 pfs[4];
   auto load_unit = [&](int u) {
     const int n = u >> 3, sy0 = (u & 7) * 4;
-    load_big_thin<C>(pfb, big, n, sy0, true, tid);
+    load_big_thin<C, TB>(pfb, big, n, sy0, true, tid);
     const float* src = small + ((((long)n * 32 + sy0) * 32)) * 32;  // 128 pixels x 32 ch contiguous
 #pragma unroll
     for (int k = 0; k < 4; ++k) pfs[k] = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
@@ -465,6 +479,46 @@ int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int d
   const int grid = n_units < 1536 ? n_units : 1536;
   if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
   else hipLaunchKernelGGL((k_up_thin<3, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- uint8 input image (conv1 forward, conv1 weight gradient, fused likelihood target) ----------
+int launch_down_thin_u8(const uint8_t* x, const float* w, const float* bias, float* out, int N, int C, int act, hipStream_t s) {
+  const int n_units = N * 8;
+  const int grid = n_units < 1536 ? n_units : 1536;
+  if (C == 1) hipLaunchKernelGGL((k_down_thin<1, false, uint8_t>), dim3(grid), dim3(256), 0, s, x, w, bias, (const float*)nullptr, out, N, act, n_units);
+  else if (C == 3) hipLaunchKernelGGL((k_down_thin<3, false, uint8_t>), dim3(grid), dim3(256), 0, s, x, w, bias, (const float*)nullptr, out, N, act, n_units);
+  else return 1;
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_up_thin_recon_u8(const ConvArgs& a, const uint8_t* target, float* g, int dist, const float* coef,
+                            float* partials, hipStream_t s) {
+  if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
+  const int n_units = a.N * 8;
+  const int grid = n_units < 1536 ? n_units : 1536;
+  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true, uint8_t>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  else hipLaunchKernelGGL((k_up_thin<3, true, uint8_t>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_wgrad_thin_u8(const uint8_t* x, const float* small, float* dw, float* db, int N, int C, float* ws, hipStream_t s) {
+  const int n_units = N * 8;
+  const int grid = n_units < WT_MAX_BLOCKS ? n_units : WT_MAX_BLOCKS;
+  if (C == 1) {
+    hipLaunchKernelGGL((k_wgrad_thin<1, uint8_t>), dim3(grid), dim3(256), 0, s, x, small, ws, N, n_units);
+    DVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(32 + 2), dim3(256), 0, s, ws, dw, db, 0, grid);
+  } else if (C == 3) {
+    hipLaunchKernelGGL((k_wgrad_thin<3, uint8_t>), dim3(grid), dim3(256), 0, s, x, small, ws, N, n_units);
+    DVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(96 + 2), dim3(256), 0, s, ws, dw, db, 0, grid);
+  } else {
+    return 1;
+  }
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -485,6 +485,25 @@ __global__ void k_sigmoid_bwd(const float* __restrict__ gy, const float* __restr
     out[i] = gy[i] * ((1.f - y[i]) * y[i]);
 }
 
+// ToTensor of a uint8 image batch (utils/datasets.py:207-209): dst = float(src) / 255, 16 pixels per thread
+__global__ void k_u8_to_f32(const uint8_t* __restrict__ src, float* __restrict__ dst, long n) {
+  const long n16 = n >> 4;
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < n16; q += (long)gridDim.x * blockDim.x) {
+    const uint4 v = reinterpret_cast<const uint4*>(src)[q];
+    const unsigned int wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (float)((wds[k] >> (8 * j)) & 0xff) / 255.0f;
+      reinterpret_cast<f32x4*>(dst)[q * 4 + k] = o;
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (long i = (n16 << 4) + threadIdx.x; i < n; i += blockDim.x) dst[i] = (float)src[i] / 255.0f;
+  }
+}
+
 struct Coef8 { float v[8]; };
 __global__ void k_set_coef(float* __restrict__ coef, Coef8 c) {
   if (threadIdx.x < 8) coef[threadIdx.x] = c.v[threadIdx.x];
@@ -605,6 +624,13 @@ int launch_loss_finalize(int kind, const float* packed, int D, int Bg, const flo
 int launch_sigmoid_bwd(const float* gy, const float* y, float* out, long n, hipStream_t s) {
   long g = (n + 255) / 256; if (g > 4096) g = 4096;
   hipLaunchKernelGGL(k_sigmoid_bwd, dim3(g), dim3(256), 0, s, gy, y, out, n);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_u8_to_f32(const uint8_t* src, float* dst, long n, hipStream_t s) {
+  long g = ((n >> 4) + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_u8_to_f32, dim3(g), dim3(256), 0, s, src, dst, n);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -37,6 +37,11 @@ SIGNATURES = {
     "dvae_convT4s2_wgrad": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "dvae_convT4s2_sigmoid_recon_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "dvae_conv_wgrad_ws_floats": [],
+    "dvae_u8_to_f32": [_p, _p, _l, _p],
+    "dvae_u8_fused_supported": [_i, _i, _i],
+    "dvae_conv4s2_fwd_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "dvae_conv4s2_wgrad_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "dvae_convT4s2_sigmoid_recon_fwd_u8": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "dvae_relayout": [_p, _i, _p, _i, _i, _i, _i, _p],
     "dvae_linear_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "dvae_linear_dgrad": [_p, _p, _p, _i, _p, _i, _i, _i, _p, _p],

@@ -228,9 +228,33 @@ class VAEEngine:
     def _join_side(self):
         record_py(torch.cuda.current_stream().wait_stream, self._side)
 
+    # ------------------------------------------------------------------ input
+    @property
+    def u8_fused(self):
+        """uint8 batches are consumed as they are (ToTensor's /255 fused into conv1 forward, conv1 weight gradient
+        and the likelihood target: dvae_*_u8) for the tuned geometry: 64x64 images with 1 or 3 channels."""
+        c, h, w = self.img_size
+        return h == 64 and w == 64 and c in (1, 3)
+
+    def input(self, x, buf):
+        """Batch as the kernels will read it.  fp32 [B,C,H,W]: itself.  uint8 [B,C,H,W] (pixels 0..255 as the datasets
+        store them, utils/datasets.py:204-213,282-291): itself when the fused uint8 kernels cover the geometry, else its
+        ToTensor image (float(v)/255, dvae_u8_to_f32) in the engine workspace."""
+        if x.dtype == torch.float32:
+            return x
+        if x.dtype != torch.uint8:
+            raise _lib.DvaeHipError("input batches must be float32 in [0,1] or uint8 pixels, got %s" % x.dtype)
+        if self.u8_fused:
+            return x
+        if getattr(buf, "x_f32", None) is None or buf.x_f32.shape != x.shape:
+            _lib.note_alloc()
+            buf.x_f32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        call("dvae_u8_to_f32", ptr(x), ptr(buf.x_f32), x.numel(), _stream())
+        return buf.x_f32
+
     # ------------------------------------------------------------------ forward
     def encode(self, x, buf, n=None):
-        """x[B,C,H,W] (NCHW) -> buf.ml[B,2D] (interleaved mu/logvar)."""
+        """x[B,C,H,W] (NCHW; fp32, or uint8 for the fused geometry: see input()) -> buf.ml[B,2D] (interleaved mu/logvar)."""
         s = _stream()
         ws = ptr(self._ws)
         B = x.shape[0] if n is None else n
@@ -241,8 +265,12 @@ class VAEEngine:
             # the last conv writes its 4x4x32 output NCHW = the (c,h,w) flatten order lin1 consumes
             # (encoders.py:80), straight into a_flat: no relayout pass; no conv kernel reads that tensor
             dst, dst_layout = (buf.a_flat, NCHW) if k == last else (act, NHWC)
-            call("dvae_conv4s2_fwd", ptr(src), src_layout, ptr(self.p("encoder.%s.weight" % name)),
-                 ptr(self.p("encoder.%s.bias" % name)), ptr(dst), dst_layout, B, cin, h, h, HID, ACT_RELU, s)
+            if k == 0 and x.dtype == torch.uint8:
+                call("dvae_conv4s2_fwd_u8", ptr(src), ptr(self.p("encoder.%s.weight" % name)),
+                     ptr(self.p("encoder.%s.bias" % name)), ptr(dst), B, cin, h, h, HID, ACT_RELU, s)
+            else:
+                call("dvae_conv4s2_fwd", ptr(src), src_layout, ptr(self.p("encoder.%s.weight" % name)),
+                     ptr(self.p("encoder.%s.bias" % name)), ptr(dst), dst_layout, B, cin, h, h, HID, ACT_RELU, s)
             src, src_layout, cin, h = act, NHWC, HID, h // 2
         call("dvae_linear_fwd", ptr(buf.a_flat), ptr(self.p("encoder.lin1.weight")), ptr(self.p("encoder.lin1.bias")),
              ptr(buf.h1), B, HID * 16, HIDDEN_DIM, ACT_RELU, ws, s)
@@ -283,9 +311,14 @@ class VAEEngine:
                  ptr(self.p("decoder.convT3.bias")), ptr(buf.recon), NCHW, B, HID, h, h, c, ACT_SIGMOID, s)
         else:
             target, dist_code, coef, partials = fuse_loss
-            call("dvae_convT4s2_sigmoid_recon_fwd", ptr(src), NHWC, ptr(self.p("decoder.convT3.weight")),
-                 ptr(self.p("decoder.convT3.bias")), ptr(target), ptr(buf.recon), ptr(buf.g_logit), dist_code,
-                 ptr(coef), ptr(partials), B, HID, h, h, c, s)
+            if target.dtype == torch.uint8:
+                call("dvae_convT4s2_sigmoid_recon_fwd_u8", ptr(src), ptr(self.p("decoder.convT3.weight")),
+                     ptr(self.p("decoder.convT3.bias")), ptr(target), ptr(buf.recon), ptr(buf.g_logit), dist_code,
+                     ptr(coef), ptr(partials), B, HID, h, h, c, s)
+            else:
+                call("dvae_convT4s2_sigmoid_recon_fwd", ptr(src), NHWC, ptr(self.p("decoder.convT3.weight")),
+                     ptr(self.p("decoder.convT3.bias")), ptr(target), ptr(buf.recon), ptr(buf.g_logit), dist_code,
+                     ptr(coef), ptr(partials), B, HID, h, h, c, s)
 
     # ------------------------------------------------------------------ backward
     def decode_backward(self, z, buf, n=None, join=True, defer_fc_wgrad=False):
@@ -398,7 +431,11 @@ class VAEEngine:
                 if deferred:
                     self.fork_side()
                     side, deferred = deferred, []
-                call(wargs[0], *wargs[1:], ptr(self._ws), s)
+                if x.dtype == torch.uint8:
+                    call("dvae_conv4s2_wgrad_u8", ptr(x), ptr(dy), ptr(self.g("encoder.%s.weight" % name)),
+                         ptr(self.g("encoder.%s.bias" % name)), B, cin, h_in, h_in, HID, ptr(self._ws), s)
+                else:
+                    call(wargs[0], *wargs[1:], ptr(self._ws), s)
             elif big:
                 self.fork_side()
                 side, deferred = deferred + [lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False)], []

@@ -276,12 +276,22 @@ class _BtcvaeFn(torch.autograd.Function):
         return dz, dmu, dlv, None, None, None
 
 
+def u8_to_f32(x):
+    """ToTensor's arithmetic on a uint8 device tensor: float(v) / 255 (dvae_u8_to_f32)."""
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    call("dvae_u8_to_f32", ptr(x), ptr(out), x.numel(), _stream())
+    return out
+
+
 def _reconstruction_loss(data, recon_data, distribution="bernoulli", storer=None, scratch=None):
     """losses.py:394-449."""
     if distribution not in _lib.REC:
         assert distribution not in RECON_DIST
         raise ValueError("Unkown distribution: {}".format(distribution))
     scratch = scratch or _Scratch(recon_data.device)
+    if data.dtype == torch.uint8:              # pixel batches: ToTensor (utils/datasets.py:207-209) on the device
+        data = u8_to_f32(data)
     loss = _ReconLossFn.apply(recon_data, data, _lib.REC[distribution], scratch)
     if distribution == "laplace":
         loss = loss * (loss != 0)
@@ -367,6 +377,7 @@ class _SingleOptimizerLoss(BaseLoss):
         Bg = B * world
         buf = eng.buffers(B)
         s = _stream()
+        data = eng.input(data, buf)            # uint8 pixel batches: fused /255 (or one ToTensor pass), see engine.input
         if is_train and eps is None:
             eps = sc.latent("eps", B, D)
             record_py(eps.normal_)             # = torch.randn_like (vae.py:67): same Philox consumption
@@ -585,6 +596,7 @@ class FactorKLoss(BaseLoss):
             record_py(eps1.normal_)            # losses.py:254 (forward on data1)
             record_py(eps2.normal_)            # losses.py:286 (sample_latent(data2))
         buf = eng.buffers(B)
+        data = eng.input(data, buf)
         eng.encode(data, buf, n=2 * Bh)                               # data1 and data2 in one pass
         # reparameterise the two halves (KL only over data1, denominator = half batch; losses.py:255-259)
         call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps1), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(sc.kl_dim),
@@ -676,6 +688,7 @@ class FactorKLoss(BaseLoss):
                 self._device_step(data, model, sc, eps1, eps2, perms.to(device=dev).contiguous())
         else:
             buf = eng.buffers(B)
+            data = eng.input(data, buf)
             eng.encode(data, buf, n=Bh)
             # z = mean; KL over data1 with the half batch as denominator (losses.py:255-259)
             call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps1), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(sc.kl_dim),

@@ -206,8 +206,15 @@ class VAE(nn.Module):
 
 
 def _check_input(model, x):
-    if x.dtype != torch.float32 or x.device != model.arena.flat.device:
-        raise _lib.DvaeHipError("input must be fp32 on %s" % model.arena.flat.device)
+    if x.device != model.arena.flat.device:
+        raise _lib.DvaeHipError("input must be on %s" % model.arena.flat.device)
+    if x.dtype == torch.uint8:                 # pixel batch: ToTensor on the device (the fused step skips even this pass)
+        x = x.contiguous()
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        call("dvae_u8_to_f32", ptr(x), ptr(out), x.numel(), _stream())
+        return out
+    if x.dtype != torch.float32:
+        raise _lib.DvaeHipError("input must be fp32 (or uint8 pixels) on %s" % model.arena.flat.device)
     return x.contiguous()
 
 

@@ -83,6 +83,24 @@ int dvae_convT4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_la
                         float* db, int N, int Cin, int H, int W, int Cout, float* ws, void* stream);
 size_t dvae_conv_wgrad_ws_floats(void);
 
+/* ---- uint8 input pipeline: utils/datasets.py:204-213 (dSprites: imgs * 255 -> ToTensor), :282-291 (CelebA:
+ * imread -> ToTensor).  The batch stays uint8 [N,C,H,W] in HBM (NCHW = ToTensor's output order, 1 byte per pixel);
+ * ToTensor's arithmetic, float(v) / 255 with IEEE division, is applied by the three consumers of the input image
+ * while they stage it: conv1 forward, conv1 weight gradient and the reconstruction-likelihood target of the fused last
+ * decoder layer.  Results are bit-identical to running the fp32 entry points on dvae_u8_to_f32's output.
+ * Fused shapes: C in {1,3}, 64x64 images, 32 output channels (dvae_u8_fused_supported); other geometries convert once
+ * with dvae_u8_to_f32 and use the fp32 entry points.                                                             */
+int dvae_u8_to_f32(const uint8_t* src, float* dst, long n, void* stream);       /* both 16-byte aligned */
+int dvae_u8_fused_supported(int C, int H, int W);
+int dvae_conv4s2_fwd_u8(const uint8_t* x, const float* w, const float* b, float* y /* NHWC */, int N, int Cin,
+                        int H, int W, int Cout, int act, void* stream);
+int dvae_conv4s2_wgrad_u8(const uint8_t* x, const float* dy /* NHWC */, float* dw, float* db, int N, int Cin,
+                          int H, int W, int Cout, float* ws, void* stream);
+int dvae_convT4s2_sigmoid_recon_fwd_u8(const float* x /* NHWC */, const float* w, const float* b,
+                                       const uint8_t* target, float* recon, float* g, int dist,
+                                       const float* coef, float* partials, int N, int Cin, int H, int W,
+                                       int Cout, void* stream);
+
 /* NCHW <-> NHWC re-layout of a [N,C,H,W] tensor (the flatten of encoders.py:80 /
  * the view of decoders.py:74 are in c,h,w order; the engine's conv activations are NHWC).  */
 int dvae_relayout(const float* src, int src_layout, float* dst, int N, int C, int H, int W, void* stream);
