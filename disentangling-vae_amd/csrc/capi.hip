@@ -209,6 +209,17 @@ int dvae_linear_wgrad_grouped(const dvae_linear_wgrad_desc* descs, int n, void* 
   return launch_linear_wgrad_grouped(descs, n, (hipStream_t)stream);
 }
 
+size_t dvae_latent_entropy_ws_floats(long N, int D, int S) {
+  if (N <= 0 || D <= 0 || S <= 0) return 0;
+  return latent_entropy_ws_floats(N, D, S);
+}
+
+int dvae_latent_entropy(const float* z_ds, const float* mean, const float* logvar, long N, int D, int S, float* ws,
+                        float* H, void* stream) {
+  DVAE_CHECK_ARG(z_ds && mean && logvar && ws && H && N > 0 && D > 0 && D <= DVAE_MAX_D && S > 0);
+  return launch_latent_entropy(z_ds, mean, logvar, N, D, S, ws, H, (hipStream_t)stream);
+}
+
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                         const float* coef, int B, int D, void* stream) {
   DVAE_CHECK_ARG(ml && mu && logvar && z && B > 0 && D > 0 && D <= DVAE_MAX_D);    // kl_dim without coef: partials only

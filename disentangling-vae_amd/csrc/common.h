@@ -138,6 +138,9 @@ int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int
 int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, float* ws,
                         size_t ws_floats, hipStream_t s);
 
+size_t latent_entropy_ws_floats(long N, int D, int S);
+int launch_latent_entropy(const float* z_ds, const float* mean, const float* logvar, long N, int D, int S, float* ws,
+                          float* H, hipStream_t s);
 int launch_linear_wgrad_grouped(const dvae_linear_wgrad_desc* d, int n, hipStream_t s);
 
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,

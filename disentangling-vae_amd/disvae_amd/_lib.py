@@ -54,6 +54,8 @@ SIGNATURES = {
     "dvae_btcvae_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "dvae_btcvae_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "dvae_permute_dims": [_p, _p, _p, _i, _i, _p],
+    "dvae_latent_entropy_ws_floats": [_l, _i, _i],
+    "dvae_latent_entropy": [_p, _p, _p, _l, _i, _i, _p, _p, _p],
     "dvae_disc_losses": [_p, _i, _p, _p, _p, _p, _p],
     "dvae_loss_pack": [_p, _p, _i, _p, _i, _p, _p, _p],
     "dvae_loss_finalize": [_i, _p, _i, _i, _p, _p, _p],
@@ -61,7 +63,8 @@ SIGNATURES = {
     "dvae_set_coef": [_p] + [ctypes.c_float] * 8 + [_p],
     "dvae_add": [_p, _p, _p, _l, _p],
 }
-_RESTYPE = {"dvae_last_error": ctypes.c_char_p, "dvae_conv_wgrad_ws_floats": ctypes.c_size_t}
+_RESTYPE = {"dvae_last_error": ctypes.c_char_p, "dvae_conv_wgrad_ws_floats": ctypes.c_size_t,
+            "dvae_latent_entropy_ws_floats": ctypes.c_size_t}
 
 
 FCW_MAX = 8

@@ -199,6 +199,15 @@ int dvae_permute_dims(const float* z, const int64_t* perm, float* out, int B, in
 int dvae_disc_losses(const float* dlogits, int Bh, const float* coef, float* sums, float* g_dtc,
                      float* g_tc, void* stream);
 
+/* ---- entropy estimator of the MIG / AAM metrics: evaluate.py:233-297 (_estimate_latent_entropies) -------
+ * H[d] = 1/S sum_s [ log N - logsumexp_n log N(z_ds[d,s]; mean[n,d], exp(logvar[n,d])) ],  d < D <= DVAE_MAX_D.
+ * z_ds[D,S]: the S sampled latents exactly as the reference lays them out -- the [S,D] gather of sampled rows
+ * re-viewed as [D,S] (evaluate.py:262, a reshape, not a transpose); mean, logvar: [N,D] (the whole data set or a
+ * conditional slice of it).  ws: dvae_latent_entropy_ws_floats(N, D, S) floats.                          */
+size_t dvae_latent_entropy_ws_floats(long N, int D, int S);
+int dvae_latent_entropy(const float* z_ds, const float* mean, const float* logvar, long N, int D, int S,
+                        float* ws, float* H, void* stream);
+
 /* ---- scalar epilogue of the loss plugins: losses.py:139-153,186-202,268-274,369-389 -------
  * dvae_loss_pack reduces this rank's partial sums into packed[DVAE_NPACK]:
  *   [0] sum of rec_partials, [1..16] kl_dim, [17..20] column sums of rowstats[:,0..3]

@@ -19,6 +19,8 @@ re-derived.
 Every function cites the reference file:line (relative to /root/reference) it follows.
 """
 import math
+
+import numpy as np
 from collections import OrderedDict
 
 import torch
@@ -512,3 +514,67 @@ class OracleTrainer:
                 p_.grad = g[k]
             self.opt.step()
         return float(loss), logs
+
+
+# --------------------------------------------------------------------------------------
+# MIG / AAM disentanglement metrics (disvae/evaluate.py:119-317) -- SURVEY 8 f-4
+# --------------------------------------------------------------------------------------
+def estimate_latent_entropies(samples_zCx, mean, logvar, sample_idx, n_samples, mini_batch_size=10):
+    """Evaluator._estimate_latent_entropies (evaluate.py:233-297).  ``sample_idx`` = the
+    ``torch.randperm(len_dataset)[:n_samples]`` draw (:259), injected.  Quirk reproduced: the [n_samples, D] gather is
+    re-VIEWED as [D, n_samples] (:262) -- a reshape, not a transpose."""
+    N, D = samples_zCx.shape
+    z = samples_zCx.index_select(0, sample_idx).view(D, n_samples)                     # :259-262
+    H = torch.zeros(D, dtype=samples_zCx.dtype)
+    log_N = math.log(N)
+    m3, l3 = mean.unsqueeze(-1), logvar.unsqueeze(-1)
+    for k in range(0, n_samples, mini_batch_size):                                     # :270
+        zc = z[:, k:k + mini_batch_size].unsqueeze(0)                                  # [1, D, mb] broadcast over N
+        log_q_zCx = log_density_gaussian(zc, m3, l3)                                   # :273-275 -> [N, D, mb]
+        log_q_z = -log_N + torch.logsumexp(log_q_zCx, dim=0)                           # :282
+        H += (-log_q_z).sum(1)                                                         # :285
+    return H / n_samples                                                               # :289
+
+
+def estimate_H_zCv(samples_zCx, mean, logvar, lat_sizes, sample_idx_list, n_samples):
+    """Evaluator._estimate_H_zCv (evaluate.py:299-317); inputs shaped [*lat_sizes, D]; one injected randperm per
+    (factor, value) in the reference's loop order."""
+    D = samples_zCx.size(-1)
+    N = 1
+    for k in lat_sizes:
+        N *= int(k)
+    H = torch.zeros(len(lat_sizes), D, dtype=samples_zCx.dtype)
+    it = iter(sample_idx_list)
+    for f, lat_size in enumerate(lat_sizes):
+        lat_size = int(lat_size)
+        for i in range(lat_size):
+            idcs = [slice(None)] * len(lat_sizes)
+            idcs[f] = i
+            sl = tuple(idcs)
+            s_ = samples_zCx[sl].contiguous().view(N // lat_size, D)                    # :310
+            m_ = mean[sl].contiguous().view(N // lat_size, D)
+            l_ = logvar[sl].contiguous().view(N // lat_size, D)
+            H[f] += estimate_latent_entropies(s_, m_, l_, next(it), n_samples) / lat_size   # :315
+    return H
+
+
+def mutual_information_gap(sorted_mut_info, lat_sizes):
+    """Evaluator._mutual_information_gap (evaluate.py:160-180)."""
+    delta = sorted_mut_info[:, 0] - sorted_mut_info[:, 1]
+    H_v = torch.as_tensor(np.asarray(lat_sizes)).float().log()
+    return (delta / H_v).mean()
+
+
+def axis_aligned_metric(sorted_mut_info):
+    """Evaluator._axis_aligned_metric (evaluate.py:182-194)."""
+    num = (sorted_mut_info[:, 0] - sorted_mut_info[:, 1:].sum(dim=1)).clamp(min=0)
+    aam_k = num / sorted_mut_info[:, 0]
+    aam_k[torch.isnan(aam_k)] = 0
+    return aam_k.mean()
+
+
+def metrics_from_entropies(H_z, H_zCv, lat_sizes):
+    """evaluate.py:148-157: mutual information table -> (MIG, AAM, sorted table)."""
+    mut_info = -H_zCv + H_z
+    sorted_mi = torch.sort(mut_info, dim=1, descending=True)[0].clamp(min=0)
+    return mutual_information_gap(sorted_mi, lat_sizes), axis_aligned_metric(sorted_mi), sorted_mi

@@ -154,7 +154,57 @@ def run_case(ref, loss_name, img_size, batch, n_steps, seed, n_data, lr, rec_dis
     return out
 
 
+def metrics_case():
+    """MIG / AAM pieces of the REAL reference Evaluator (disvae/evaluate.py:119-317) on a small synthetic latent table:
+    marginal entropies (two sample counts), conditional entropies, the whole metric.  The Evaluator object is built
+    without a model (its estimator methods only use device / logger / progress-bar flag); `_estimate_H_zCv` calls
+    `_estimate_latent_entropies` with its default n_samples = 10000, which requires every conditional slice to hold
+    >= 10000 points -- the slices here are tiny, so the default is overridden (the arithmetic is unchanged)."""
+    import_reference()
+    from disvae import evaluate as ev_mod
+    import functools
+    lat_sizes = np.array([3, 4, 5])
+    N, D, S = 60, 4, 10
+    gen = torch.Generator().manual_seed(2024)
+    mean = torch.randn(N, D, generator=gen) * 1.5
+    logvar = torch.randn(N, D, generator=gen) * 0.8 - 1.0
+    # make two latent dims informative about two factors so that MIG / AAM are not ~0
+    grid = np.stack(np.meshgrid(*[np.arange(k) for k in lat_sizes], indexing="ij"), -1).reshape(N, 3)
+    mean[:, 0] += torch.from_numpy(grid[:, 0]).float() * 2.0
+    mean[:, 2] += torch.from_numpy(grid[:, 2]).float() * 1.2
+    samples = mean.clone()                                   # Evaluator.__call__ puts the model in eval mode: z = mean
+    ev = object.__new__(ev_mod.Evaluator)
+    ev.device, ev.is_progress_bar, ev.logger, ev.save_dir = torch.device("cpu"), True, logging.getLogger("golden"), "/tmp"
+    out = dict(lat_sizes=lat_sizes, mean=mean.numpy(), logvar=logvar.numpy(), n_samples=np.int64(S))
+    logging.disable(logging.CRITICAL)
+    with NoiseRecorder() as rec:
+        torch.manual_seed(5)
+        H_z = ev._estimate_latent_entropies(samples, (mean, logvar), n_samples=S)
+    out["H_z"], out["H_z/perm"] = H_z.numpy(), rec.perm[0].numpy()
+    with NoiseRecorder() as rec:
+        H_z40 = ev._estimate_latent_entropies(samples, (mean, logvar), n_samples=40)
+    out["H_z40"], out["H_z40/perm"] = H_z40.numpy(), rec.perm[0].numpy()
+    ev._estimate_latent_entropies = functools.partial(ev_mod.Evaluator._estimate_latent_entropies, ev, n_samples=S)
+    with NoiseRecorder() as rec:
+        H_zCv = ev._estimate_H_zCv(samples.view(*lat_sizes, D), tuple(p.view(*lat_sizes, D) for p in (mean, logvar)),
+                                   lat_sizes, ["a", "b", "c"])
+    out["H_zCv"] = H_zCv.numpy()
+    for j, p in enumerate(rec.perm):
+        out["H_zCv/perm%d" % j] = p.numpy()
+    mut_info = -H_zCv + H_z
+    sorted_mi = torch.sort(mut_info, dim=1, descending=True)[0].clamp(min=0)
+    out["sorted_mut_info"] = sorted_mi.numpy()
+    out["MIG"] = ev._mutual_information_gap(sorted_mi, lat_sizes).numpy()
+    out["AAM"] = ev._axis_aligned_metric(sorted_mi).numpy()
+    return out
+
+
 def main():
+    if "--metrics" in sys.argv:          # only the MIG / AAM fixture (the training-step fixtures stay as committed)
+        out = metrics_case()
+        np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
+        print("metrics: MIG", out["MIG"], "AAM", out["AAM"], "H_z", out["H_z"])
+        return
     ref = import_reference()
     _, losses, vae, discriminator, dmath, training = ref
     np.savez_compressed(os.path.join(HERE, "kats.npz"), **kats(losses, dmath))

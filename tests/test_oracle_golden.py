@@ -152,3 +152,24 @@ def test_eval_forward_matches_golden():
     np.testing.assert_allclose(logvar.numpy(), g["eval/logvar"], rtol=1e-4, atol=1e-6)
     assert torch.equal(z, mu)
     assert_digest_close(tensor_digest(recon, 64), g["eval/recon_digest"], rtol=1e-5, what="recon")
+
+
+def test_metrics_oracle_vs_reference_golden():
+    """MIG / AAM estimator restatement (oracle) vs the fixture recorded from the real reference Evaluator
+    (tests/golden/make_golden.py --metrics; disvae/evaluate.py:119-317), same injected randperm draws."""
+    g = load("metrics")
+    lat_sizes = [int(k) for k in g["lat_sizes"]]
+    mean, logvar = torch.from_numpy(g["mean"]), torch.from_numpy(g["logvar"])
+    samples = mean.clone()
+    S, D = int(g["n_samples"]), mean.shape[1]
+    H_z = O.estimate_latent_entropies(samples, mean, logvar, torch.from_numpy(g["H_z/perm"])[:S], S)
+    np.testing.assert_allclose(H_z.numpy(), g["H_z"], rtol=2e-6)
+    H_z40 = O.estimate_latent_entropies(samples, mean, logvar, torch.from_numpy(g["H_z40/perm"])[:40], 40)
+    np.testing.assert_allclose(H_z40.numpy(), g["H_z40"], rtol=2e-6)
+    perms = [torch.from_numpy(g["H_zCv/perm%d" % j])[:S] for j in range(sum(lat_sizes))]
+    H_zCv = O.estimate_H_zCv(samples.view(*lat_sizes, D), mean.view(*lat_sizes, D), logvar.view(*lat_sizes, D), lat_sizes, perms, S)
+    np.testing.assert_allclose(H_zCv.numpy(), g["H_zCv"], rtol=2e-6)
+    mig, aam, sorted_mi = O.metrics_from_entropies(H_z, H_zCv, lat_sizes)
+    np.testing.assert_allclose(sorted_mi.numpy(), g["sorted_mut_info"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mig.item(), g["MIG"], rtol=1e-5)
+    np.testing.assert_allclose(aam.item(), g["AAM"], rtol=1e-5)
