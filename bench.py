@@ -277,6 +277,9 @@ def main():
                     "collectives, barriers) even with ONE rank: exercises the N>1 path of this script on a single GPU")
     ap.add_argument("--estimator", default="global", choices=["global", "local"],
                     help="scope of the batch-coupled estimators under data parallelism (disvae_amd.parallel.data_parallel)")
+    ap.add_argument("--transport", default=None, choices=["torch", "rccl"],
+                    help="collectives of the data-parallel step: torch.distributed (nccl = RCCL; default) or the C-ABI's "
+                         "dvae_comm_* (RCCL enqueued by libdvae_hip.so); DVAE_COMM sets the default")
     ap.add_argument("--replay", default=None, choices=["auto", "eager", "plan", "graph"],
                     help="how the launches of an iteration are issued (disvae_amd/graph.py)")
     args = ap.parse_args()
@@ -338,7 +341,7 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         parallel.init_process_group_from_env("nccl")
-        parallel.data_parallel(model, loss_f, estimator=args.estimator)
+        comm = parallel.data_parallel(model, loss_f, estimator=args.estimator, transport=args.transport)
     # synthetic batch, resident in HBM; every rank draws its own shard and its own device noise, while
     # the CPU generator (FactorVAE permutations, losses.py:505) stays identical on all ranks
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -388,6 +391,7 @@ def main():
 
     if ddp:
         flush_c_stdio()
+        comm.close()
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
         flush_c_stdio()
@@ -413,6 +417,7 @@ def main():
                                   "+RCCL collectives" if world > 1 else ""),
                    "name": name, "dataset_shape": dset, "batch_per_gpu": B, "global_batch": B_global,
                    "parallelism": "dp%d" % world, "estimator": args.estimator if ddp else None,
+                   "transport": (args.transport or os.environ.get("DVAE_COMM", "torch")) if ddp else None,
                    "final_loss": round(final_loss, 4)},
         "hip_event_ms_per_step": {"segments": [round(x, 4) for x in seg_ms], "median": round(sorted(seg_ms)[len(seg_ms) // 2], 4),
                                   "note": "HIP events on the compute stream of rank 0 around %d equal segments of the timed "

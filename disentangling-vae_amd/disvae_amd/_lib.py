@@ -61,6 +61,18 @@ SIGNATURES = {
     "dvae_loss_finalize": [_i, _p, _i, _i, _p, _p, _p],
     "dvae_loss_epilogue": [_i, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p],
     "dvae_set_coef": [_p] + [ctypes.c_float] * 8 + [_p],
+    "dvae_comm_load": [ctypes.c_char_p],
+    "dvae_comm_unique_id": [_p],
+    "dvae_comm_init": [_p, _p, _i, _i],
+    "dvae_comm_destroy": [_p],
+    "dvae_comm_world": [_p],
+    "dvae_comm_rank": [_p],
+    "dvae_comm_allreduce": [_p, _p, _l, _p],
+    "dvae_comm_allgather": [_p, _p, _p, _l, _p],
+    "dvae_comm_reducescatter": [_p, _p, _p, _l, _p],
+    "dvae_comm_broadcast": [_p, _p, _l, _i, _p],
+    "dvae_comm_group_start": [],
+    "dvae_comm_group_end": [],
     "dvae_add": [_p, _p, _p, _l, _p],
 }
 _RESTYPE = {"dvae_last_error": ctypes.c_char_p, "dvae_conv_wgrad_ws_floats": ctypes.c_size_t,

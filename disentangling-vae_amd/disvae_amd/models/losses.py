@@ -635,15 +635,20 @@ class FactorKLoss(BaseLoss):
                  Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), s)
         # discriminator backward of d_tc_loss (weight grads + dz), losses.py:303-304
         dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
+        pending = []
+        if world > 1:      # the 16 MB discriminator gradients are final: their all-reduce runs under the whole VAE backward
+            pending.append(self.comm.all_reduce_async(disc.arena.grad))
         # tc term of vae_loss through D: dgrad only, first half (its disc weight grads are zeroed at :303)
         dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2")
         eng.decode_backward(buf.z, buf, n=Bh, join=world > 1, defer_fc_wgrad=world == 1)   # single process: joined at the end of encode_backward
+        if world > 1:      # decoder gradients are final: overlapped with the encoder backward
+            pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
         # dz_a: quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1); dz_b: the tc term through D
         call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dz_a), ptr(dz_b), None, None, ptr(buf.mu), ptr(buf.logvar), ptr(eps1), ptr(sc.scal),
              ptr(sc.coef), ptr(buf.dml), Bh, D, s)
         eng.encode_backward(data, buf, n=Bh)
         if world > 1:
-            pending = [self.comm.all_reduce_async(model.arena.grad), self.comm.all_reduce_async(disc.arena.grad)]
+            pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))
             for h_ in pending:
                 h_.wait()
 

@@ -1,25 +1,41 @@
-"""Data parallelism over the GPUs of one node: one process per GPU, torch.distributed
-(backend "nccl" == RCCL over xGMI on ROCm; "gloo" for the CPU tests).
+"""Data parallelism over the GPUs of one node: one process per GPU.
 
 The reference is single-process; this is new.  What is exchanged per step:
-  * every loss      : ONE sum-all-reduce of the flat gradient arena (2.0 MB VAE, +16 MB
-                      discriminator for factor) and one of the 32-float packed loss sums;
-  * btcvae          : all-gather of (z, mu, logvar) so every rank evaluates its ROW block of
-                      the global B x B estimator (reference parity at the global batch), and a
-                      sum-all-reduce of the [2, B_global, D] column gradients;
-  * factor          : all-gather of the second half-batch latents (permute_dims permutes
-                      across the GLOBAL half batch; every rank applies the same, shared-seed,
-                      CPU-generated permutations and keeps its slice).
+  * every loss      : sum-all-reduce of the flat gradient arena in two spans (decoder half as soon as the decoder's
+                      gradients are final, encoder half at the end; 2.0 MB together) and one of the 32-float packed
+                      loss sums;
+  * btcvae          : all-gather of (z, mu, logvar) so every rank evaluates its ROW block of the global B x B estimator
+                      (reference parity at the global batch), and a reduce-scatter of the [B_global, D] column gradients;
+  * factor          : all-gather of the second half-batch latents (permute_dims permutes across the GLOBAL half batch;
+                      every rank applies the same, shared-seed, CPU-generated permutations and keeps its slice); the
+                      16 MB discriminator gradient arena is all-reduced as soon as the discriminator's backward pass has
+                      produced it, under the whole VAE backward.
 Encoder / decoder / reconstruction / KL are independent per image: no exchange.
+
+Two transports with the same interface:
+  * ``Comm``      -- torch.distributed collectives (backend "nccl" == RCCL over xGMI on ROCm; "gloo" for CPU tests);
+  * ``RcclComm``  -- the collectives of libdvae_hip.so's C-ABI (``dvae_comm_*``: RCCL enqueued on the caller's HIP
+                     stream, no torch types in the data path); torch.distributed is then only the rendezvous that ships
+                     the 128-byte RCCL unique id.  Select with ``data_parallel(..., transport="rccl")`` / DVAE_COMM=rccl.
+Gather / scatter buffers are allocated once per shape and reused.
 """
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
+from . import _lib
+from ._lib import call, ptr
+
+
+class _Done:
+    def wait(self):
+        return None
+
 
 class Comm:
-    """Thin wrapper over a torch.distributed process group (plumbing, not compute)."""
+    """Collectives over a torch.distributed process group (plumbing, not compute)."""
 
     def __init__(self, group=None):
         if not dist.is_initialized():
@@ -27,54 +43,150 @@ class Comm:
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        # gloo (CPU test backend) cannot all_gather device tensors: stage those through the host
-        self._host_gather = dist.get_backend(group) == "gloo"
+        self._bufs = {}
 
+    # ---- primitives --------------------------------------------------------------------------
     def all_reduce(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_reduce_async(self, t):
-        """Start a sum-all-reduce of `t` (ordered after the work already enqueued on the current
-        stream) and return the handle; `handle.wait()` orders the current stream after it.  Used to
-        overlap the decoder half of the gradient arena with the encoder backward."""
+        """Start a sum-all-reduce of `t` (ordered after the work already enqueued on the current stream) and return a
+        handle; ``handle.wait()`` orders the current stream after it.  Used to overlap the decoder half of the gradient
+        arena (and the discriminator arena) with the rest of the backward pass."""
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def _all_gather(self, t):
-        t = t.contiguous()
-        if self._host_gather and t.is_cuda:
-            h = t.cpu()
-            out = [torch.empty_like(h) for _ in range(self.world_size)]
-            dist.all_gather(out, h, group=self.group)
-            return [o.to(t.device) for o in out]
-        out = [torch.empty_like(t) for _ in range(self.world_size)]
-        dist.all_gather(out, t, group=self.group)
-        return out
+    def all_gather_into(self, out, t):
+        """out[world * n] <- concatenation of every rank's t[n] in rank order."""
+        dist.all_gather_into_tensor(out, t, group=self.group)
 
-    def all_gather_rows(self, t):
-        """t[B, D] on every rank -> [world*B, D] in rank order."""
-        return torch.cat(self._all_gather(t), dim=0)
-
-    def all_gather_latents(self, z, mu, logvar):
-        """(z, mu, logvar) local [B, D] -> global [world*B, D] each (one collective)."""
-        packed = torch.stack((z, mu, logvar)).contiguous()           # [3, B, D]
-        out = self._all_gather(packed)
-        g = torch.stack(out, dim=1)                                   # [3, world, B, D]
-        g = g.reshape(3, -1, z.shape[1]).contiguous()
-        return g[0], g[1], g[2]
-
-    def reduce_scatter_cols(self, dmu_all, dlv_all):
-        """Column gradients [B_global, D] summed over ranks -> this rank's rows [B, D].
-        (sum-all-reduce + slice: the message is <= 0.7 MB, and gloo has no reduce_scatter)."""
-        packed = torch.stack((dmu_all, dlv_all)).contiguous()         # [2, Bg, D]
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
-        B = dmu_all.shape[0] // self.world_size
-        sl = slice(self.rank * B, (self.rank + 1) * B)
-        return packed[0, sl].contiguous(), packed[1, sl].contiguous()
+    def reduce_scatter_into(self, out, t):
+        """out[n] <- this rank's chunk of the element-wise sum over ranks of t[world * n]."""
+        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast(self, t, src=0):
         dist.broadcast(t, src=src, group=self.group)
         return t
+
+    def group_start(self):
+        pass
+
+    def group_end(self):
+        pass
+
+    # ---- buffers ------------------------------------------------------------------------------
+    def _buf(self, name, shape, like):
+        key = (name, tuple(shape), like.dtype, like.device)
+        b = self._bufs.get(key)
+        if b is None:
+            _lib.note_alloc()
+            b = self._bufs[key] = torch.empty(shape, dtype=like.dtype, device=like.device)
+        return b
+
+    # ---- what the loss plugins call -----------------------------------------------------------------
+    def all_gather_rows(self, t, name="rows"):
+        """t[B, D] on every rank -> [world*B, D] in rank order (persistent buffer)."""
+        t = t.contiguous()
+        out = self._buf(name, (self.world_size * t.shape[0],) + tuple(t.shape[1:]), t)
+        self.all_gather_into(out, t)
+        return out
+
+    def all_gather_latents(self, z, mu, logvar):
+        """(z, mu, logvar) local [B, D] -> global [world*B, D] each (three collectives issued as one group)."""
+        self.group_start()
+        out = tuple(self.all_gather_rows(t, n) for t, n in ((z, "z_all"), (mu, "mu_all"), (logvar, "lv_all")))
+        self.group_end()
+        return out
+
+    def reduce_scatter_cols(self, dmu_all, dlv_all):
+        """Column gradients [B_global, D] summed over ranks -> this rank's rows [B, D] (rows of rank r are contiguous)."""
+        B = dmu_all.shape[0] // self.world_size
+        outs = []
+        self.group_start()
+        for t, n in ((dmu_all, "dmu_loc"), (dlv_all, "dlv_loc")):
+            t = t.contiguous()
+            out = self._buf(n, (B,) + tuple(t.shape[1:]), t)
+            self.reduce_scatter_into(out, t)
+            outs.append(out)
+        self.group_end()
+        return outs[0], outs[1]
+
+    def close(self):
+        pass
+
+
+class RcclComm(Comm):
+    """Same interface, data path through the C-ABI (``dvae_comm_*`` of libdvae_hip.so): RCCL collectives enqueued on the
+    current HIP stream.  The torch.distributed group is used once, to broadcast rank 0's RCCL unique id."""
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        h = _lib.lib()
+        path = os.environ.get("DVAE_RCCL_LIB")
+        if path is None:                      # prefer the RCCL torch itself is linked with (one RCCL per process)
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            path = cand if os.path.exists(cand) else None
+        call("dvae_comm_load", path.encode() if path else None)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (ctypes.c_char * 128)()
+            call("dvae_comm_unique_id", ctypes.addressof(buf))
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if self.world_size > 1:
+            backend = dist.get_backend(group)
+            t = uid.to(dev) if backend == "nccl" else uid
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = t.cpu()
+        self._uid = bytes(uid.numpy().tobytes())
+        handle = ctypes.c_void_p()
+        call("dvae_comm_init", ctypes.addressof(handle), self._uid, self.world_size, self.rank)
+        self._h = handle.value
+        self._side = torch.cuda.Stream(device=dev)
+        assert h.dvae_comm_world(self._h) == self.world_size
+
+    @staticmethod
+    def _s():
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+    def all_reduce(self, t):
+        call("dvae_comm_allreduce", self._h, ptr(t), t.numel(), self._s())
+        return t
+
+    def all_reduce_async(self, t):
+        """The collective goes to a communication stream forked from the current one; wait() joins it back."""
+        cur = torch.cuda.current_stream()
+        _lib.record_py(self._side.wait_stream, cur)
+        call("dvae_comm_allreduce", self._h, ptr(t), t.numel(), self._side.cuda_stream)
+        side = self._side
+
+        class _Handle:
+            def wait(self_inner):
+                _lib.record_py(torch.cuda.current_stream().wait_stream, side)
+
+        return _Handle()
+
+    def all_gather_into(self, out, t):
+        call("dvae_comm_allgather", self._h, ptr(t), ptr(out), t.numel(), self._s())
+
+    def reduce_scatter_into(self, out, t):
+        call("dvae_comm_reducescatter", self._h, ptr(t), ptr(out), out.numel(), self._s())
+
+    def broadcast(self, t, src=0):
+        call("dvae_comm_broadcast", self._h, ptr(t), t.numel(), src, self._s())
+        return t
+
+    def group_start(self):
+        call("dvae_comm_group_start")
+
+    def group_end(self):
+        call("dvae_comm_group_end")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize()
+            call("dvae_comm_destroy", self._h)
+            self._h = None
 
 
 def init_process_group_from_env(backend=None):
@@ -88,7 +200,7 @@ def init_process_group_from_env(backend=None):
     dist.init_process_group(backend=backend)
 
 
-def data_parallel(model, loss_f, group=None, estimator="global"):
+def data_parallel(model, loss_f, group=None, estimator="global", transport=None, comm=None):
     """Attach a communicator to a native loss plugin (and make every rank start from rank 0's
     weights).  After this, ``loss_f.fused_step`` / ``call_optimize`` treat their input as this
     rank's shard of a global batch of world_size x B images.
@@ -96,11 +208,18 @@ def data_parallel(model, loss_f, group=None, estimator="global"):
     estimator: scope of the batch-coupled terms (the beta-TCVAE B x B estimator and its minibatch
     weights, FactorVAE's permute_dims).  "global" (default): over the global batch -- equal to the
     single-process step on the concatenated batch, at the price of a latent all-gather, a column-gradient
-    all-reduce and B x (world B) estimator work per rank.  "local": over each rank's shard -- what the
-    reference computes under DistributedDataParallel (gradient all-reduce only); a different estimator."""
+    reduce-scatter and B x (world B) estimator work per rank.  "local": over each rank's shard -- what the
+    reference computes under DistributedDataParallel (gradient all-reduce only); a different estimator.
+
+    transport: "torch" (default; torch.distributed collectives, nccl == RCCL) or "rccl" (the C-ABI's dvae_comm_*);
+    DVAE_COMM overrides the default.  comm: a ready communicator object (tests)."""
     if estimator not in ("global", "local"):
         raise ValueError("estimator must be 'global' or 'local'")
-    comm = Comm(group)
+    if comm is None:
+        transport = transport or os.environ.get("DVAE_COMM", "torch")
+        if transport not in ("torch", "rccl"):
+            raise ValueError("transport must be 'torch' or 'rccl', got %r" % (transport,))
+        comm = RcclComm(group) if transport == "rccl" else Comm(group)
     loss_f.comm = comm
     loss_f.estimator = estimator
     comm.broadcast(model.arena.flat)

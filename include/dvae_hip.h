@@ -235,6 +235,29 @@ int dvae_set_coef(float* coef, float c0, float c1, float c2, float c3, float c4,
 /* out[i] = a[i] + b[i] (n elements), helper for merging latent gradients (quirk Q1).       */
 int dvae_add(const float* a, const float* b, float* out, long n, void* stream);
 
+/* ---- RCCL collectives over xGMI (data parallelism over the GPUs of one node; new, the reference is single-process) ----
+ * One communicator per process (= per GPU).  Every collective is ENQUEUED on `stream` (ordered with the kernels around
+ * it, no host synchronisation) in fp32 with sum reduction.  librccl is dlopen()ed on first use ($DVAE_RCCL_LIB, the
+ * path given to dvae_comm_load, "librccl.so", /opt/rocm/lib/librccl.so); single-GPU processes never load it.
+ * Rendezvous: rank 0 calls dvae_comm_unique_id and ships the 128 bytes to the other ranks out of band (the host
+ * side broadcasts them through its torch.distributed store); then every rank calls dvae_comm_init with the current HIP
+ * device selected.  Uses per step: all-reduce of the flat gradient arena(s) and of the packed loss
+ * sums, all-gather of (z, mu, logvar) / z2 for the global B x B estimator / permute_dims, reduce-scatter of the
+ * estimator's column gradients.                                                                                  */
+typedef struct dvae_comm dvae_comm;
+int dvae_comm_load(const char* librccl_path /* may be NULL */);
+int dvae_comm_unique_id(void* id128 /* out: 128 bytes */);
+int dvae_comm_init(dvae_comm** comm, const void* id128, int world, int rank);
+int dvae_comm_destroy(dvae_comm* comm);
+int dvae_comm_world(const dvae_comm* comm);
+int dvae_comm_rank(const dvae_comm* comm);
+int dvae_comm_allreduce(dvae_comm* comm, float* buf, long n, void* stream);                          /* in place */
+int dvae_comm_allgather(dvae_comm* comm, const float* send, float* recv, long n_per_rank, void* stream);
+int dvae_comm_reducescatter(dvae_comm* comm, const float* send, float* recv, long n_per_rank, void* stream);
+int dvae_comm_broadcast(dvae_comm* comm, float* buf, long n, int root, void* stream);                /* in place */
+int dvae_comm_group_start(void);      /* ncclGroupStart / ncclGroupEnd: fuse the collectives in between */
+int dvae_comm_group_end(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,7 +37,7 @@ def _make(loss, lr):
     return model, opt, loss_f
 
 
-def _worker(rank, world, port, loss, q, backend="gloo"):
+def _worker(rank, world, port, loss, q, backend="gloo", transport="torch", device=0):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import sys
@@ -45,8 +45,8 @@ def _worker(rank, world, port, loss, q, backend="gloo"):
         for p in (root, os.path.join(root, "disentangling-vae_amd"), os.path.join(root, "tests")):
             sys.path.insert(0, p)
         from disvae_amd import parallel
+        torch.cuda.set_device(device)
         parallel.init_process_group_from_env(backend)
-        torch.cuda.set_device(0)
         lr = 1e-4 if loss == "factor" else 5e-4
         Bl = 12
         gen = torch.Generator().manual_seed(5)
@@ -68,7 +68,11 @@ def _worker(rank, world, port, loss, q, backend="gloo"):
         ref_param = m0.arena.flat.clone()
         # ---- sharded run ----
         m1, o1, l1 = _make(loss, lr)
-        comm = parallel.data_parallel(m1, l1)
+        if backend == "gloo":
+            from ddp_util import HostStagedComm
+            comm = parallel.data_parallel(m1, l1, comm=HostStagedComm())
+        else:
+            comm = parallel.data_parallel(m1, l1, transport=transport)
         assert comm.world_size == world
         st = defaultdict(list)
         if loss == "factor":
@@ -89,6 +93,7 @@ def _worker(rank, world, port, loss, q, backend="gloo"):
         assert abs(out1.item() - ref_loss) <= 2e-6 * abs(ref_loss), (out1.item(), ref_loss)
         assert (m1.arena.flat - ref_param).abs().max().item() <= 2.5 * lr
         assert st["loss"] and abs(st["loss"][0] - ref_loss) <= 2e-6 * abs(ref_loss)
+        comm.close()
         q.put((rank, "ok"))
     except Exception:  # noqa
         import traceback
@@ -116,14 +121,38 @@ def test_sharded_step_matches_global_batch(loss):
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
+@pytest.mark.parametrize("transport", ["torch", "rccl"])
 @pytest.mark.parametrize("loss", ["btcvae", "factor"])
-def test_rccl_call_sites_single_rank(loss):
+def test_sharded_step_over_rccl_on_all_visible_gpus(loss, transport):
+    """The real thing: one rank per GPU over RCCL (backend nccl), both transports (torch.distributed collectives and
+    the C-ABI's dvae_comm_*), sharded step == single-process step on the global batch.  Needs >= 2 GPUs: skipped on the
+    1-GPU test boxes, runs on the multi-GPU node of the scaling tier."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 visible GPUs (%d here)" % n)
+    world = min(n, 4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, loss, q, "nccl", transport, r)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=280) for _ in range(world)]
+    for p_ in procs:
+        p_.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+@pytest.mark.parametrize("transport", ["torch", "rccl"])
+@pytest.mark.parametrize("loss", ["btcvae", "factor"])
+def test_rccl_call_sites_single_rank(loss, transport):
     """backend "nccl" (= RCCL) with ONE rank on the one GPU of the test box: the same collectives'
     call sites as on 8 GPUs (broadcast, list all_gather, sum all_reduce, async bucket all_reduce under
     the side-stream context) run through RCCL itself; results must equal the communicator-free step."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p_ = ctx.Process(target=_worker, args=(0, 1, _free_port(), loss, q, "nccl"))
+    p_ = ctx.Process(target=_worker, args=(0, 1, _free_port(), loss, q, "nccl", transport))
     p_.start()
     rank, msg = q.get(timeout=280)
     p_.join(timeout=60)
@@ -140,8 +169,8 @@ def _worker_local(rank, world, port, loss, q):
         for p in (root, os.path.join(root, "disentangling-vae_amd"), os.path.join(root, "tests")):
             sys.path.insert(0, p)
         from disvae_amd import parallel
-        parallel.init_process_group_from_env("gloo")
         torch.cuda.set_device(0)
+        parallel.init_process_group_from_env("gloo")
         lr = 1e-4 if loss == "factor" else 5e-4
         Bl, D = 12, 10
         gen = torch.Generator().manual_seed(5)
@@ -168,7 +197,8 @@ def _worker_local(rank, world, port, loss, q):
             if loss == "factor":
                 ref_dgrad = ref_dgrad + l0.discriminator.arena.grad.clone() / world
         m1, o1, l1 = _make(loss, lr)
-        parallel.data_parallel(m1, l1, estimator="local")
+        from ddp_util import HostStagedComm
+        parallel.data_parallel(m1, l1, estimator="local", comm=HostStagedComm())
         out1 = step(m1, o1, l1, rank)
         err = ((m1.arena.grad - ref_grad).abs().max() / ref_grad.abs().max()).item()
         assert err < 2e-5, "grad err %.3e" % err
