@@ -233,6 +233,17 @@ int dvae_reparam_kl_bwd(const float* dz, const float* dz2, const float* dz3, con
   return launch_reparam_kl_bwd(dz, dz2, dz3, dmu_x, dlv_x, mu, logvar, eps, scal, coef, dml, B, D, (hipStream_t)stream);
 }
 
+int dvae_kl_normal_bwd(const float* g_dim, const float* mu, const float* logvar, float* dmu, float* dlogvar, int B, int D,
+                       void* stream) {
+  DVAE_CHECK_ARG(g_dim && mu && logvar && dmu && dlogvar && B > 0 && D > 0);
+  return launch_kl_normal_bwd(g_dim, mu, logvar, dmu, dlogvar, B, D, (hipStream_t)stream);
+}
+
+int dvae_reduce_sum(const float* src, long n, float scale, float* dst, void* stream) {
+  DVAE_CHECK_ARG(src && dst && n > 0);
+  return launch_reduce_sum(src, n, scale, dst, (hipStream_t)stream);
+}
+
 int dvae_recon_loss(const float* recon, const float* target, long n, int dist, const float* coef, float* partials,
                     float* g, int wrt_logit, void* stream) {
   DVAE_CHECK_ARG(recon && target && coef && partials && n > 0 && (n % 4 == 0));

@@ -125,6 +125,8 @@ int launch_down_thin_u8(const uint8_t* x, const float* w, const float* bias, flo
 int launch_up_thin_recon_u8(const ConvArgs& a, const uint8_t* target, float* g, int dist, const float* coef,
                             float* partials, hipStream_t s);
 int launch_wgrad_thin_u8(const uint8_t* x, const float* small, float* dw, float* db, int N, int C, float* ws, hipStream_t s);
+int launch_kl_normal_bwd(const float* g, const float* mu, const float* lv, float* dmu, float* dlv, int B, int D, hipStream_t s);
+int launch_reduce_sum(const float* src, long n, float scale, float* dst, hipStream_t s);
 int launch_u8_to_f32(const uint8_t* src, float* dst, long n, hipStream_t s);
 
 size_t wgrad32_ws_floats();

@@ -485,6 +485,28 @@ __global__ void k_sigmoid_bwd(const float* __restrict__ gy, const float* __restr
     out[i] = gy[i] * ((1.f - y[i]) * y[i]);
 }
 
+// gradient of the per-dimension KL (losses.py:452-480: latent_kl[d] = mean_b 0.5(-1 - lv + mu^2 + e^lv)) for an arbitrary
+// upstream gradient g[d]: the autograd-compatible path (loss(data, recon, latent_dist, ...) then loss.backward())
+__global__ void k_kl_normal_bwd(const float* __restrict__ g, const float* __restrict__ mu, const float* __restrict__ lv,
+                                float* __restrict__ dmu, float* __restrict__ dlv, int B, int D) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)B * D) return;
+  const float gd = g[idx % D] / (float)B;
+  dmu[idx] = gd * mu[idx];
+  dlv[idx] = gd * 0.5f * (expf(lv[idx]) - 1.f);
+}
+
+// dst[0] = scale * sum(src[0..n)) in a fixed order (one workgroup)
+__global__ __launch_bounds__(256) void k_reduce_sum(const float* __restrict__ src, long n, float scale, float* __restrict__ dst) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) a += src[i];
+  const float v = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[0] = scale * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 // ToTensor of a uint8 image batch (utils/datasets.py:207-209): dst = float(src) / 255, 16 pixels per thread
 __global__ void k_u8_to_f32(const uint8_t* __restrict__ src, float* __restrict__ dst, long n) {
   const long n16 = n >> 4;
@@ -624,6 +646,19 @@ int launch_loss_finalize(int kind, const float* packed, int D, int Bg, const flo
 int launch_sigmoid_bwd(const float* gy, const float* y, float* out, long n, hipStream_t s) {
   long g = (n + 255) / 256; if (g > 4096) g = 4096;
   hipLaunchKernelGGL(k_sigmoid_bwd, dim3(g), dim3(256), 0, s, gy, y, out, n);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_kl_normal_bwd(const float* g, const float* mu, const float* lv, float* dmu, float* dlv, int B, int D, hipStream_t s) {
+  const long n = (long)B * D;
+  hipLaunchKernelGGL(k_kl_normal_bwd, dim3((n + 255) / 256), dim3(256), 0, s, g, mu, lv, dmu, dlv, B, D);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_reduce_sum(const float* src, long n, float scale, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, s, src, n, scale, dst);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -50,6 +50,8 @@ SIGNATURES = {
     "dvae_reparam_kl_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_recon_loss": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
+    "dvae_kl_normal_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "dvae_reduce_sum": [_p, _l, ctypes.c_float, _p, _p],
     "dvae_sigmoid_bwd": [_p, _p, _p, _l, _p],
     "dvae_btcvae_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "dvae_btcvae_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],

@@ -211,7 +211,9 @@ class _ReconLossFn(torch.autograd.Function):
         call("dvae_recon_loss", ptr(recon), ptr(data), recon.numel(), dist_code, ptr(scratch.coef),
              ptr(scratch.partials), ptr(g), 0, _stream())
         ctx.save_for_backward(g)
-        return scratch.partials.sum() / B
+        out = torch.empty((), dtype=torch.float32, device=recon.device)
+        call("dvae_reduce_sum", ptr(scratch.partials), _lib.REC_NPART, 1.0 / B, ptr(out), _stream())
+        return out
 
     @staticmethod
     def backward(ctx, gout):
@@ -237,9 +239,10 @@ class _KLFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         mu, logvar = ctx.saved_tensors
-        B = mu.shape[0]
-        gmu = gout.unsqueeze(0) * mu / B
-        glv = gout.unsqueeze(0) * 0.5 * (logvar.exp() - 1) / B
+        B, D = mu.shape
+        mu, logvar, gout = mu.contiguous(), logvar.contiguous(), gout.contiguous()
+        gmu, glv = torch.empty_like(mu), torch.empty_like(logvar)
+        call("dvae_kl_normal_bwd", ptr(gout), ptr(mu), ptr(logvar), ptr(gmu), ptr(glv), B, D, _stream())
         return gmu, glv, None
 
 
@@ -256,10 +259,14 @@ class _BtcvaeFn(torch.autograd.Function):
         tmp = torch.empty(3 * D, B, dtype=torch.float32, device=z.device)
         call("dvae_btcvae_fwd", ptr(z), ptr(mu), ptr(logvar), B, D, 0, B, int(is_mss), ptr(scratch.log_w),
              ptr(tmp), ptr(rowstats), _stream())
-        s = rowstats[:, :4].sum(0) / B   # log_pz, log_qz, log_prod_qzi, log_q_zCx
+        # batch means of the four log-densities -> (mi, tc, dw_kl) by the scalar epilogue kernels (losses.py:369-373)
+        packed = torch.empty(_lib.NPACK, dtype=torch.float32, device=z.device)
+        scal = torch.empty(_lib.NSCAL, dtype=torch.float32, device=z.device)
+        call("dvae_loss_pack", ptr(scratch.partials), None, 0, ptr(rowstats), B, None, ptr(packed), _stream())
+        call("dvae_loss_finalize", _lib.LOSS_BTCVAE, ptr(packed), 0, B, ptr(scratch.coef), ptr(scal), _stream())
         ctx.save_for_backward(z, mu, logvar, rowstats, tmp)
         ctx.is_mss, ctx.scratch = is_mss, scratch
-        return torch.stack((s[3] - s[1], s[1] - s[2], s[2] - s[0]))
+        return scal[_lib.S_MI:_lib.S_DWKL + 1].clone()       # [mi, tc, dw_kl]
 
     @staticmethod
     def backward(ctx, gout):

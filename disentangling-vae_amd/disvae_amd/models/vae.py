@@ -176,6 +176,18 @@ class VAE(nn.Module):
         for p_, g_ in pairs:
             p_.grad = g_
 
+    def unalias_grads(self):
+        """The autograd-compatible backward writes its results into the flat gradient arena and hands autograd CLONES
+        of it.  After a fused step ``Parameter.grad`` IS a view of that arena (assign_grads): autograd would then
+        accumulate the clone into the very buffer the kernels just wrote (doubling the gradient under
+        ``zero_grad(set_to_none=False)``).  Give every aliased ``.grad`` its own storage first (values kept)."""
+        lo = self._arena.grad.data_ptr()
+        hi = lo + self._arena.grad.numel() * 4
+        for p_ in list(self.parameters()) + list(self._flat_params):
+            g = p_.grad
+            if g is not None and lo <= g.data_ptr() < hi:
+                p_.grad = g.clone()
+
     # ---- reference API --------------------------------------------------------------------
     def reparameterize(self, mean, logvar):
         """vae.py:52-71 (stand-alone use by callers; forward() fuses it into a HIP kernel)."""
@@ -256,6 +268,7 @@ class _VAEFn(torch.autograd.Function):
             raise _lib.DvaeHipError("backward through a stale forward: the engine workspace was overwritten by a "
                                     "later forward of the same model")
         eng = model.engine
+        model.unalias_grads()
         B = x.shape[0]
         buf = eng.buffers(B)
         s = _stream()
@@ -306,6 +319,7 @@ class _EncodeFn(torch.autograd.Function):
         if model._fwd_version != ctx.version:
             raise _lib.DvaeHipError("backward through a stale forward")
         eng = model.engine
+        model.unalias_grads()
         buf = eng.buffers(x.shape[0])
         s = _stream()
         scal = _zeros_scal(x.device)
@@ -342,6 +356,7 @@ class _DecodeFn(torch.autograd.Function):
         if model._fwd_version != ctx.version:
             raise _lib.DvaeHipError("backward through a stale forward")
         eng = model.engine
+        model.unalias_grads()
         buf = eng.buffers(z.shape[0])
         s = _stream()
         call("dvae_sigmoid_bwd", ptr(g_recon.contiguous()), ptr(buf.recon), ptr(buf.g_logit), buf.recon.numel(), s)

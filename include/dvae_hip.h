@@ -153,6 +153,13 @@ int dvae_reparam_kl_bwd(const float* dz, const float* dz2, const float* dz3, con
                         const float* logvar, const float* eps, const float* scal, const float* coef,
                         float* dml, int B, int D, void* stream);
 
+/* Backward of _kl_normal_loss's per-dimension KL (losses.py:470-473) for an upstream gradient g_dim[D]:
+ * dmu[b,d] = g_dim[d] mu[b,d] / B, dlogvar[b,d] = g_dim[d] 0.5 (e^logvar - 1) / B  (the autograd-compatible path). */
+int dvae_kl_normal_bwd(const float* g_dim, const float* mu, const float* logvar, float* dmu, float* dlogvar,
+                       int B, int D, void* stream);
+/* dst[0] = scale * sum(src[0..n)), fixed summation order (finishes per-workgroup partial sums of a loss).  */
+int dvae_reduce_sum(const float* src, long n, float scale, float* dst, void* stream);
+
 /* ---- reconstruction likelihood: losses.py:394-449 (F.binary_cross_entropy / mse / l1) ----
  * recon, target: [n] elements.  partials[DVAE_REC_NPART] receives per-block partial sums of
  * the un-normalised loss; g[n] (may be NULL) = coef[INV_B] * dLoss/d(pre-sigmoid logit)

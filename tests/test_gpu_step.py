@@ -426,3 +426,24 @@ def test_fused_step_other_latent_dims(loss, D):
         np.testing.assert_allclose(storer[k][0], ref_logs[k].item(), rtol=5e-5, atol=1e-6, err_msg=k)
     for k, p in model.named_parameters():
         check(p.grad, g64[k], rtol=1e-3, atol_rel=1e-4, what="D=%d grad %s" % (D, k))
+
+
+def test_autograd_path_after_fused_step_does_not_double_gradients():
+    """after a fused step Parameter.grad aliases the gradient arena; a following reference-style iteration
+    (model(x) -> loss -> zero_grad(set_to_none=False) -> backward) must still produce the plain gradient."""
+    img, B = (1, 64, 64), 6
+    m, o, l = _native("btcvae", img, 7, 737280, 5e-4)
+    gen = torch.Generator().manual_seed(3)
+    data, eps = dev(torch.rand((B,) + img, generator=gen)), dev(torch.randn(B, 10, generator=gen))
+    l.fused_step(data, m, o, None, eps=eps)                       # .grad now aliases the arena
+    m2, o2, l2 = _native("btcvae", img, 7, 737280, 5e-4)
+    m2.load_state_dict(m.state_dict())
+    l2.n_train_steps = l.n_train_steps
+    data2, eps2 = dev(torch.rand((B,) + img, generator=gen)), dev(torch.randn(B, 10, generator=gen))
+    recon, latent_dist, z = m(data2, eps=eps2)
+    loss = l(data2, recon, latent_dist, True, None, latent_sample=z)
+    o.zero_grad(set_to_none=False)
+    loss.backward()
+    l2.fused_step(data2, m2, o2, None, eps=eps2)                  # same iteration through the fused path
+    for (k, p), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        check(p.grad, p2.grad, rtol=1e-5, atol_rel=1e-6, what="grad after mixing paths " + k)
