@@ -40,6 +40,11 @@ static int run_up(const ConvArgs& a, hipStream_t s) {
     if (r2) r = launch_up_mfma32_r2(a, s);
     if (r <= 0) return r;
 #endif
+    static const bool no_ws = env_off("DVAE_UP_WS");        // debug builds: DVAE_UP_WS=0 -> k_up32 for every geometry (A/B)
+    if (!no_ws) {
+      r = launch_up_mfma32_ws(a, s);
+      if (r <= 0) return r;
+    }
     r = launch_up_mfma32(a, s);
     if (r <= 0) return r;
     r = launch_up_thin(a, s);

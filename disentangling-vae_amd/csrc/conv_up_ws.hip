@@ -1,0 +1,244 @@
+// Wave-specialised "up" MFMA kernel (small -> big: ConvTranspose2d forward = decoders.py:77-80, Conv2d dgrad =
+// encoders.py:73-77 under training.py:157) for the two large geometries of the Burgess stack, 16x16 -> 32x32 and
+// 8x8 -> 16x16, 32 <-> 32 channels, NHWC on both sides.
+//
+// Why a second kernel next to k_up32 (conv_mfma.hip): in k_up32 every wave does everything -- stage the input tile,
+// prefetch the ReLU mask with sixteen strided 4-byte loads, store its D fragment with sixteen strided 4-byte stores,
+// and the MFMAs -- in phases that the two workgroup barriers per unit keep aligned across the waves of a SIMD, so the
+// matrix core idles whenever its two waves do address arithmetic or wait for memory (MFMA-busy 0.49-0.58,
+// profiles/r01_run31_pmc_summary.md; hoisting the address arithmetic alone changed nothing, profiles/r02_run2_ab.txt).
+// Here the roles are split:
+//   waves 0-3 (one per SIMD) = compute: LDS operand reads, 128 v_mfma_f32_32x32x2_f32 per unit (one output-parity class
+//       x both 32-pixel M-tiles: the B fragments of a tap are shared by the two tiles), bias / ReLU, D fragments
+//       written to an LDS image of the unit's output block;
+//   waves 4-7 = memory: input tiles two units ahead (registers) and one unit ahead (LDS), the previous unit's output
+//       block from LDS to HBM with 16-byte coalesced stores -- a unit's output is ONE contiguous 32 KB block of the NHWC
+//       tensor -- masked by the producing layer's activation fetched with 16-byte loads one unit ahead.
+// One workgroup barrier per unit; input and output images are double-buffered in LDS (64 KB weights + 2 x 13.5 KB in
+// + 2 x 32 KB out = 155 KB: one workgroup per CU, as before).
+// Per unit a CU moves 13.5 KB in + 32 KB out (+ 32 KB mask) for 8192 matrix-core cycles: at 100 % MFMA rate that is
+// 3.5 (5.9) TB/s over the chip -- the masked variant is HBM- and MFMA-bound at the same time.
+#include "common.h"
+#include "conv_mfma_common.h"
+
+namespace dvae {
+
+template <int HS, int NTHR, int NPF>
+__device__ __forceinline__ void init_small_slots_n(SlotDesc<NPF>& d, int t) {
+  using G = Geo<HS>;
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    const int s = t + k * NTHR;
+    d.lds[k] = -1; d.gofs[k] = 0; d.rimg[k] = 0;
+    if (s < G::SH_SLOTS) {
+      const int chunk = s & 7;
+      int q = s >> 3;
+      const int col = q % G::SCOLS; q /= G::SCOLS;
+      const int row = q;                       // IMGS == 1
+      const int sx = col - 1;
+      d.lds[k] = (row * G::SCOLS + col) * 32 + ((chunk ^ swz_small<HS>(row, col)) << 2);
+      d.gofs[k] = ((row - 1) * HS + sx) * 32 + chunk * 4;
+      d.rimg[k] = row | ((sx >= 0 && sx < HS) ? (1 << 16) : 0);
+    }
+  }
+}
+
+template <int HS, int NPF>
+__device__ __forceinline__ void load_small_n(f32x4 (&pf)[NPF], const SlotDesc<NPF>& d, const float* __restrict__ small,
+                                             int unit) {
+  using G = Geo<HS>;
+  const long P0 = (long)unit * G::U;
+  const int n0 = (int)(P0 / (HS * HS));
+  const int sy0 = (int)(P0 % (HS * HS)) / HS;
+  const float* base = small + ((long)n0 * HS + sy0) * HS * 32;
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int row = d.rimg[k] & 0xff;
+    const int sy = sy0 - 1 + row;
+    if ((d.rimg[k] >> 16) && sy >= 0 && sy < HS) v = *reinterpret_cast<const f32x4*>(base + d.gofs[k]);
+    pf[k] = v;
+  }
+}
+
+template <int NPF>
+__device__ __forceinline__ void store_small_n(const f32x4 (&pf)[NPF], const SlotDesc<NPF>& d, float* st) {
+#pragma unroll
+  for (int k = 0; k < NPF; ++k)
+    if (d.lds[k] >= 0) *reinterpret_cast<f32x4*>(st + d.lds[k]) = pf[k];
+}
+
+#define UPWS_OUT_FLOATS 8192        // one unit's output block: 64 small pixels x 4 parity classes x 32 channels
+
+template <int HS, bool MASK>
+__global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small, const float* __restrict__ w,
+                                                const float* __restrict__ bias, const float* __restrict__ mask,
+                                                float* __restrict__ out, int act, int n_units) {
+  using G = Geo<HS>;
+  static_assert(G::IMGS == 1, "one image per unit");
+  constexpr int HB = 2 * HS;
+  constexpr int LNPF = (G::SH_SLOTS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                                  // 16384 floats: w[tap][cs/4][cb][cs%4]
+  float* in0 = smem + 16384;                         // 2 x G::SH_FLOATS
+  float* out0 = in0 + 2 * G::SH_FLOATS;              // 2 x UPWS_OUT_FLOATS
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_compute = wv < 4;
+  const int stride = gridDim.x;
+  const int unit0 = blockIdx.x;
+
+  SlotDesc<LNPF> sd;
+  f32x4 pf[LNPF];
+  const int ht = tid - 256;
+  if (!is_compute) {
+    init_small_slots_n<HS, 256, LNPF>(sd, ht);
+    if (unit0 < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit0);
+  }
+  stage_weights<false>(w, wl, tid);
+  if (!is_compute) {
+    if (unit0 < n_units) store_small_n<LNPF>(pf, sd, in0);
+    if (unit0 + stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit0 + stride);
+  }
+  __syncthreads();
+
+  if (is_compute) {
+    // ---------------------------------------------------------------- compute waves: class cls, both M-tiles
+    const int cls = wv;
+    const int py = cls >> 1, px = cls & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const float bv = bias ? bias[i] : 0.f;
+    // LDS float offsets of the A operand (input tile) for (M-tile, tap, 8-channel group) and of the B operand (weights)
+    int aoff[2][4][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int p = mt * 32 + i;
+      const int m = p / HS, l = p % HS;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ty = t >> 1, tx = t & 1;
+        const int row = m + (py - ty) + 1, col = l + (px - tx) + 1;
+        const int sw = swz_small<HS>(row, col);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) aoff[mt][t][q] = (row * G::SCOLS + col) * 32 + (((2 * q + h) ^ sw) << 2);
+      }
+    }
+    const int boff = i * 4 + h * 128;                // + ((kh*4+kw)*8 + 2q) * 128
+    // D-fragment row e of M-tile mt -> float offset in the output image: ((2m+py) * HB + 2l+px) * 32 + i
+    int ooff[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int pp = mt * 32 + 4 * h;                // + (e & 3) + 8 * (e >> 2)
+      const int m = pp / HS, l = pp % HS;
+      ooff[mt] = ((2 * m + py) * HB + 2 * l + px) * 32 + i;
+    }
+    __builtin_amdgcn_s_setprio(1);
+    int buf = 0;
+    for (int unit = unit0; unit < n_units; unit += stride) {
+      const float* in = in0 + buf * G::SH_FLOATS;
+      float* ob = out0 + buf * UPWS_OUT_FLOATS;
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+      f32x4 A0[2], A1[2], Bv[2];
+      auto rd = [&](int g, int slot) {
+        const int t = g >> 2, q = g & 3;
+        const int ty = t >> 1, tx = t & 1;
+        const int kh = 1 - py + 2 * ty, kw = 1 - px + 2 * tx;
+        A0[slot] = *reinterpret_cast<const f32x4*>(in + aoff[0][t][q]);
+        A1[slot] = *reinterpret_cast<const f32x4*>(in + aoff[1][t][q]);
+        Bv[slot] = *reinterpret_cast<const f32x4*>(wl + boff + ((kh * 4 + kw) * 8 + 2 * q) * 128);
+      };
+      rd(0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int cur = g & 1;
+        if (g + 1 < 16) rd(g + 1, cur ^ 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[cur][j], Bv[cur][j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[cur][j], Bv[cur][j], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 DS reads (next group)
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMAs (this group)
+      }
+      // bias / activation, D fragments -> output image (lanes 0-31 / 32-63 of a store: two pixels x 32 channels)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        // pixel pp = mt*32 + (e&3) + 8*(e>>2) + 4h: HS=16: m += (e>>3), l += (e&3) + 8*((e>>2)&1);  HS=8: m += (e>>2), l += (e&3)
+        constexpr int PPR = HS;                      // small pixels per small row
+        const int dpp = (e & 3) + 8 * (e >> 2);
+        const int dm = dpp / PPR, dl = dpp % PPR;    // (4h never carries into the row: 4h + (e&3) + 8*((e>>2)&1) < 16, < 8 for HS=8)
+        const int d = (2 * dm * HB + 2 * dl) * 32;
+        float v0 = epilogue_act(acc0[e] + bv, act), v1 = epilogue_act(acc1[e] + bv, act);
+        ob[ooff[0] + d] = v0;
+        ob[ooff[1] + d] = v1;
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    // ---------------------------------------------------------------- memory waves
+    f32x4 mk[8];
+    int k = 0;
+    int prev = -1;
+    auto drain = [&](int u, int b) {
+      // unit u's output block is contiguous: out + u * 8192 floats
+      const float* ob = out0 + b * UPWS_OUT_FLOATS;
+      float* dst = out + (long)u * UPWS_OUT_FLOATS;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = (ht + 256 * j) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ob + c);
+        if (MASK) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) v[x] = mk[j][x] > 0.f ? v[x] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dst + c) = v;
+      }
+    };
+    for (int unit = unit0; unit < n_units; unit += stride, ++k) {
+      if (prev >= 0) drain(prev, (k - 1) & 1);
+      if (MASK) {                                   // this unit's mask, consumed one iteration later
+        const float* src = mask + (long)unit * UPWS_OUT_FLOATS;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mk[j] = *reinterpret_cast<const f32x4*>(src + (ht + 256 * j) * 4);
+      }
+      if (unit + stride < n_units) store_small_n<LNPF>(pf, sd, in0 + ((k + 1) & 1) * G::SH_FLOATS);
+      if (unit + 2 * stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit + 2 * stride);
+      prev = unit;
+      __syncthreads();
+    }
+    if (prev >= 0) drain(prev, (k - 1) & 1);
+  }
+}
+
+template <int HS>
+static int launch_up_ws_t(const ConvArgs& a, hipStream_t s) {
+  using G = Geo<HS>;
+  const int n_units = (int)(((long)a.N * HS * HS) / 64);     // HS*HS is a multiple of 64: every unit is complete
+  const int grid = n_units < 256 ? n_units : 256;
+  const size_t lds = (size_t)(16384 + 2 * G::SH_FLOATS + 2 * UPWS_OUT_FLOATS) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_up32ws<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_up32ws<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (a.mask) hipLaunchKernelGGL((k_up32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.act, n_units);
+  else hipLaunchKernelGGL((k_up32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.act, n_units);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+// 32 <-> 32 channels, NHWC on both sides, Hs == Ws in {8, 16}; returns 1 if not applicable
+int launch_up_mfma32_ws(const ConvArgs& a, hipStream_t s) {
+  if (!(a.Cb == 32 && a.Cs == 32 && a.Hs == a.Ws && (a.Hs == 8 || a.Hs == 16) && a.small_layout == DVAE_NHWC &&
+        a.out_layout == DVAE_NHWC))
+    return 1;
+  if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
+  return a.Hs == 16 ? launch_up_ws_t<16>(a, s) : launch_up_ws_t<8>(a, s);
+}
+
+}  // namespace dvae
