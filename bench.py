@@ -133,9 +133,10 @@ def kernel_rooflines(B, device):
     flops = 2.0 * 4194304 * B              # algorithmic FLOPs per launch: 2 x MACs/img x images per launch
     # algorithmic HBM bytes per launch: big tensor (B x 32x32x32 fp32) + small tensor (B x 16x16x32) moved once
     # (+ the mask read of the masked variants)
-    algo_bytes = {"k_up32<16>": (131072 + 32768) * 4.0 * B + 131072 * 4.0 * B / 2,     # avg of plain and masked
-                  "k_down32ws<16>": (131072 + 32768) * 4.0 * B + 32768 * 4.0 * B / 2,
-                  "k_wgrad32<16>": (131072 + 32768) * 4.0 * B}
+    big_b, small_b = 32 * 32 * 32 * 4.0, 16 * 16 * 32 * 4.0          # bytes per image
+    algo_bytes = {"k_up32<16>": (big_b + small_b) * B + big_b * B / 2,         # avg of the plain and the masked launch
+                  "k_down32ws<16>": (big_b + small_b) * B + small_b * B / 2,
+                  "k_wgrad32<16>": (big_b + small_b) * B}
     out = []
     for name, launches in fams.items():
         ms = [(_time_launch(fn), what) for what, fn in launches]

@@ -33,10 +33,20 @@ struct BigThinRegs { float v[(C * TB_ROWS + 3) / 4]; };
 // read the input image (conv1 forward, conv1 weight gradient, reconstruction likelihood) fetch 1 byte per pixel.
 __device__ __forceinline__ float to_unit(float v) { return v; }
 __device__ __forceinline__ float to_unit(uint8_t v) { return (float)v / 255.0f; }
+// the 256 possible results as a table in LDS: one ds_read instead of the ~10-instruction IEEE division per pixel
+// (the staging code of these kernels is instruction-issue-bound, not bandwidth-bound)
+struct UnitLut {
+  float t[256];
+  __device__ __forceinline__ void init(int tid, int nthr) {
+    for (int k = tid; k < 256; k += nthr) t[k] = (float)k / 255.0f;
+  }
+};
+__device__ __forceinline__ float to_unit(float v, const UnitLut*) { return v; }
+__device__ __forceinline__ float to_unit(uint8_t v, const UnitLut* lut) { return lut->t[v]; }
 
 template <int C, typename TB>
 __device__ __forceinline__ void load_big_thin(BigThinRegs<C>& r, const TB* __restrict__ big, int n, int sy0,
-                                              bool valid, int tid) {
+                                              bool valid, int tid, const UnitLut* lut = nullptr) {
   const int tx = tid & 63, ty = tid >> 6;
 #pragma unroll
   for (int k = 0; k < (C * TB_ROWS + 3) / 4; ++k) {
@@ -45,7 +55,8 @@ __device__ __forceinline__ void load_big_thin(BigThinRegs<C>& r, const TB* __res
     const int by = 2 * sy0 - 1 + rr;
     const bool ok = valid && pr < C * TB_ROWS && by >= 0 && by < 64;
     const long off = ok ? ((((long)n * C + cb) * 64 + by) * 64 + tx) : 0;
-    const float v = to_unit(big[off]);
+    const TB raw = big[off];
+    const float v = to_unit(raw, lut);
     r.v[k] = ok ? v : 0.f;
   }
 }
@@ -80,8 +91,11 @@ __global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, c
                                                    float* __restrict__ out, int N, int act, int n_units) {
   __shared__ float bt[C * TB_PLANE];
   __shared__ float wT[16 * C * 32];
+  __shared__ UnitLut lut_s[1];
+  const UnitLut* lut = lut_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
+  if (sizeof(TB) == 1) { lut_s[0].init(tid, 256); __syncthreads(); }
   {                                                      // w[cs][k] -> wT[k][cs]; loads first, then LDS writes
     float wv[2 * C];
 #pragma unroll
@@ -95,7 +109,7 @@ __global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, c
   }
   BigThinRegs<C> pf;
   int unit = blockIdx.x;
-  if (unit < n_units) load_big_thin<C, TB>(pf, big, unit >> 3, (unit & 7) * 4, true, tid);
+  if (unit < n_units) load_big_thin<C, TB>(pf, big, unit >> 3, (unit & 7) * 4, true, tid, lut);
   __syncthreads();
   float wreg[8 * C];                                     // B operand: w[cs = i][k = 2*kk + h]
 #pragma unroll
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, c
     store_big_thin<C>(pf, bt, tid);
     __syncthreads();
     const int nu = unit + gridDim.x;
-    if (nu < n_units) load_big_thin<C, TB>(pf, big, nu >> 3, (nu & 7) * 4, true, tid);
+    if (nu < n_units) load_big_thin<C, TB>(pf, big, nu >> 3, (nu & 7) * 4, true, tid, lut);
     const long rowbase = ((((long)n * 32 + sy0 + sy_l) * 32)) * 32 + i;
     float mv[16];
     if (MASK) {
@@ -152,6 +166,9 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
                                                  float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) float st[UT_ROWS * UT_COLS * 32];
   __shared__ float redl[2];
+  __shared__ UnitLut lut_s[1];
+  const UnitLut* lut = lut_s;
+  if (FUSE && sizeof(TT) == 1) lut_s[0].init(threadIdx.x, 128);     // visible after the first __syncthreads of the unit loop
   const int tid = threadIdx.x;
   const int m = tid >> 5, l = tid & 31;
   const float gs = FUSE ? coef[DVAE_C_INV_B] : 0.f;
@@ -244,7 +261,7 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
               xt0 = xt.x; xt1 = xt.y;
             } else {
               const uchar2 xt = *reinterpret_cast<const uchar2*>(target + o);
-              xt0 = to_unit(xt.x); xt1 = to_unit(xt.y);
+              xt0 = to_unit(xt.x, lut); xt1 = to_unit(xt.y, lut);
             }
             float gl0, gl1, gr;
             lsum += recon_elem(v0, xt0, dist, &gl0, &gr);
@@ -273,8 +290,11 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, 
   constexpr int NT = (16 * C + 31) / 32;   // N-tiles of 32 (cb,tap) columns
   __shared__ __attribute__((aligned(16))) float bt[C * TB_PLANE];
   __shared__ __attribute__((aligned(16))) float sp[8192];  // 128 px x 32 ch tile; reused (8192 floats) for the cross-wave reduction
+  __shared__ UnitLut lut_s[1];
+  const UnitLut* lut = lut_s;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
+  if (sizeof(TB) == 1) { lut_s[0].init(tid, 256); __syncthreads(); }
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -295,7 +315,7 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, 
   f32x4 pfs[4];
   auto load_unit = [&](int u) {
     const int n = u >> 3, sy0 = (u & 7) * 4;
-    load_big_thin<C, TB>(pfb, big, n, sy0, true, tid);
+    load_big_thin<C, TB>(pfb, big, n, sy0, true, tid, lut);
     const float* src = small + ((((long)n * 32 + sy0) * 32)) * 32;  // 128 pixels x 32 ch contiguous
 #pragma unroll
     for (int k = 0; k < 4; ++k) pfs[k] = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
