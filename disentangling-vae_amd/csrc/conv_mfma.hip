@@ -650,6 +650,13 @@ __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict_
 
 size_t wgrad32_ws_floats() { return (size_t)WG_MAX_BLOCKS * WG_STRIDE; }
 
+// fixed-order reduction of `nblk` per-workgroup partials (also used by conv_wgrad_ws.hip, which writes the same format)
+int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_big, int nblk, hipStream_t s) {
+  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(1024 + 2), dim3(256), 0, s, ws, dw, db, bias_from_big, nblk);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- launchers -----------------------------------------------------------------------------
 static int units_for(int N, int HS) { return (int)(((long)N * HS * HS + 63) / 64); }
 
@@ -792,6 +799,8 @@ int launch_up_mfma32(const ConvArgs& a, hipStream_t s) {
 
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
                         int Hs, float* ws, hipStream_t s, int small_nchw) {
+  static const bool no_ws = env_off("DVAE_WGRAD_WS");     // debug builds: DVAE_WGRAD_WS=0 -> k_wgrad32 for every geometry (A/B)
+  if (!no_ws && !small_nchw && (Hs == 16 || Hs == 8)) return launch_wgrad_mfma32_ws(big, small, dw, db, bias_from_big, N, Hs, ws, s);
   switch (Hs) {
     case 16: return launch_wgrad_t<16>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
     case 8: return launch_wgrad_t<8>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);

@@ -24,8 +24,11 @@ namespace dvae {
 // UNCONDITIONAL (address clamped, value zeroed afterwards) so that the compiler issues them
 // back to back instead of one branch + wait per element; load and LDS-store are separate so the
 // next unit can be prefetched into registers during the MFMA phase.
-template <int C>
-struct BigThinRegs { float v[(C * TB_ROWS + 3) / 4]; };
+template <int C, typename TB = float>
+struct BigThinRegs {
+  TB v[(C * TB_ROWS + 3) / 4];     // RAW elements as loaded (uint8 pixels are converted when the tile is written to LDS:
+  unsigned ok;                     // nothing may depend on a prefetched register before the MFMA phase is over)
+};
 
 // Input elements: fp32, or uint8 pixels as the datasets store them (dSprites imgs * 255, CelebA imread:
 // utils/datasets.py:204-213,282-291) converted on the fly with ToTensor's arithmetic, float(v) / 255 (IEEE
@@ -45,9 +48,10 @@ __device__ __forceinline__ float to_unit(float v, const UnitLut*) { return v; }
 __device__ __forceinline__ float to_unit(uint8_t v, const UnitLut* lut) { return lut->t[v]; }
 
 template <int C, typename TB>
-__device__ __forceinline__ void load_big_thin(BigThinRegs<C>& r, const TB* __restrict__ big, int n, int sy0,
-                                              bool valid, int tid, const UnitLut* lut = nullptr) {
+__device__ __forceinline__ void load_big_thin(BigThinRegs<C, TB>& r, const TB* __restrict__ big, int n, int sy0,
+                                              bool valid, int tid) {
   const int tx = tid & 63, ty = tid >> 6;
+  unsigned okm = 0;
 #pragma unroll
   for (int k = 0; k < (C * TB_ROWS + 3) / 4; ++k) {
     const int pr = ty + 4 * k;
@@ -55,14 +59,14 @@ __device__ __forceinline__ void load_big_thin(BigThinRegs<C>& r, const TB* __res
     const int by = 2 * sy0 - 1 + rr;
     const bool ok = valid && pr < C * TB_ROWS && by >= 0 && by < 64;
     const long off = ok ? ((((long)n * C + cb) * 64 + by) * 64 + tx) : 0;
-    const TB raw = big[off];
-    const float v = to_unit(raw, lut);
-    r.v[k] = ok ? v : 0.f;
+    r.v[k] = big[off];
+    okm |= ok ? (1u << k) : 0u;
   }
+  r.ok = okm;
 }
 
-template <int C>
-__device__ __forceinline__ void store_big_thin(const BigThinRegs<C>& r, float* bt, int tid) {
+template <int C, typename TB>
+__device__ __forceinline__ void store_big_thin(const BigThinRegs<C, TB>& r, float* bt, int tid, const UnitLut* lut) {
   const int tx = tid & 63, ty = tid >> 6;
   const int pc = tx + 1;
   const int dst_col = (pc & 1) * TB_PAR + (pc >> 1);
@@ -71,7 +75,7 @@ __device__ __forceinline__ void store_big_thin(const BigThinRegs<C>& r, float* b
     const int pr = ty + 4 * k;
     if (pr < C * TB_ROWS) {
       const int cb = pr / TB_ROWS, rr = pr - cb * TB_ROWS;
-      bt[cb * TB_PLANE + rr * TB_ROW + dst_col] = r.v[k];
+      bt[cb * TB_PLANE + rr * TB_ROW + dst_col] = ((r.ok >> k) & 1u) ? to_unit(r.v[k], lut) : 0.f;
     }
   }
   if (tid < C * TB_ROWS * 2) {   // the two zero-padding columns pc = 0 and pc = 65
@@ -107,9 +111,9 @@ __global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, c
       wT[k * 32 + cs] = wv[r];
     }
   }
-  BigThinRegs<C> pf;
+  BigThinRegs<C, TB> pf;
   int unit = blockIdx.x;
-  if (unit < n_units) load_big_thin<C, TB>(pf, big, unit >> 3, (unit & 7) * 4, true, tid, lut);
+  if (unit < n_units) load_big_thin<C, TB>(pf, big, unit >> 3, (unit & 7) * 4, true, tid);
   __syncthreads();
   float wreg[8 * C];                                     // B operand: w[cs = i][k = 2*kk + h]
 #pragma unroll
@@ -120,10 +124,10 @@ __global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, c
   for (; unit < n_units; unit += gridDim.x) {
     const int n = unit >> 3, sy0 = (unit & 7) * 4;
     __syncthreads();                                     // previous unit's LDS reads are complete
-    store_big_thin<C>(pf, bt, tid);
+    store_big_thin<C, TB>(pf, bt, tid, lut);
     __syncthreads();
     const int nu = unit + gridDim.x;
-    if (nu < n_units) load_big_thin<C, TB>(pf, big, nu >> 3, (nu & 7) * 4, true, tid, lut);
+    if (nu < n_units) load_big_thin<C, TB>(pf, big, nu >> 3, (nu & 7) * 4, true, tid);
     const long rowbase = ((((long)n * 32 + sy0 + sy_l) * 32)) * 32 + i;
     float mv[16];
     if (MASK) {
@@ -166,9 +170,6 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
                                                  float* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) float st[UT_ROWS * UT_COLS * 32];
   __shared__ float redl[2];
-  __shared__ UnitLut lut_s[1];
-  const UnitLut* lut = lut_s;
-  if (FUSE && sizeof(TT) == 1) lut_s[0].init(threadIdx.x, 128);     // visible after the first __syncthreads of the unit loop
   const int tid = threadIdx.x;
   const int m = tid >> 5, l = tid & 31;
   const float gs = FUSE ? coef[DVAE_C_INV_B] : 0.f;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
               xt0 = xt.x; xt1 = xt.y;
             } else {
               const uchar2 xt = *reinterpret_cast<const uchar2*>(target + o);
-              xt0 = to_unit(xt.x, lut); xt1 = to_unit(xt.y, lut);
+              xt0 = to_unit(xt.x); xt1 = to_unit(xt.y);      // two IEEE divisions per output pair: noise next to ~100 FMAs
             }
             float gl0, gl1, gr;
             lsum += recon_elem(v0, xt0, dist, &gl0, &gr);
@@ -311,11 +312,11 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, 
     const int cb = bval[t] ? (nidx >> 4) : 0, kh = (nidx >> 2) & 3, kw = nidx & 3;
     boff[t] = cb * TB_PLANE + kh * TB_ROW + (kw & 1) * TB_PAR + (kw >> 1);
   }
-  BigThinRegs<C> pfb;
+  BigThinRegs<C, TB> pfb;
   f32x4 pfs[4];
   auto load_unit = [&](int u) {
     const int n = u >> 3, sy0 = (u & 7) * 4;
-    load_big_thin<C, TB>(pfb, big, n, sy0, true, tid, lut);
+    load_big_thin<C, TB>(pfb, big, n, sy0, true, tid);
     const float* src = small + ((((long)n * 32 + sy0) * 32)) * 32;  // 128 pixels x 32 ch contiguous
 #pragma unroll
     for (int k = 0; k < 4; ++k) pfs[k] = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, 
   if (unit < n_units) load_unit(unit);
   for (; unit < n_units; unit += gridDim.x) {
     __syncthreads();
-    store_big_thin<C>(pfb, bt, tid);
+    store_big_thin<C, TB>(pfb, bt, tid, lut);
 #pragma unroll
     for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(sp + (tid + k * 256) * 4) = pfs[k];
     __syncthreads();
