@@ -52,17 +52,23 @@ static int run_up(const ConvArgs& a, hipStream_t s) {
   }
   return launch_up_generic(a, s);
 }
+// partial_only: accumulate into ws and leave the reduction to dvae_conv_wgrad_reduce_grouped (tuned geometries only: 1 otherwise)
 static int run_wgrad(const float* big, int big_layout, const float* small, int small_layout, float* dw, float* db,
-                     int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws, float* ws, hipStream_t s) {
+                     int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws, float* ws, hipStream_t s,
+                     bool partial_only = false) {
   // the small side of the 4x4 end of the conv stack may be NCHW (= the FC stack's (c,h,w) order)
   if (!use_generic_only() && ws != nullptr && Hs == Ws && Cs == 32 && Cb == 32 && big_layout == DVAE_NHWC && Hs == 4 &&
       small_layout == DVAE_NCHW)
-    return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s, 1);
+    return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s, 1, partial_only);
   if (!use_generic_only() && ws != nullptr && Hs == Ws && Cs == 32 && small_layout == DVAE_NHWC) {
     if (Cb == 32 && big_layout == DVAE_NHWC && (Hs == 4 || Hs == 8 || Hs == 16))
-      return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s);
+      return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s, 0, partial_only);
     if ((Cb == 1 || Cb == 3) && Hs == 32 && big_layout == DVAE_NCHW)
-      return launch_wgrad_thin(big, small, dw, db, bias_from_big, N, Cb, Hs, ws, s);
+      return launch_wgrad_thin(big, small, dw, db, bias_from_big, N, Cb, Hs, ws, s, partial_only);
+  }
+  if (partial_only) {
+    set_error("dvae_conv*_wgrad_partial: geometry not covered by the tuned kernels (use dvae_conv*_wgrad)");
+    return 1;
   }
   return launch_wgrad_generic(big, big_layout, small, small_layout, dw, db, bias_from_big, N, Cb, Cs, Hs, Ws, s);
 }
@@ -176,6 +182,24 @@ int dvae_convT4s2_sigmoid_recon_fwd_u8(const float* x, const float* w, const flo
   DVAE_CHECK_ARG(dist == DVAE_REC_BERNOULLI || dist == DVAE_REC_GAUSSIAN || dist == DVAE_REC_LAPLACE);
   ConvArgs a{nullptr, 0, x, DVAE_NHWC, w, b, nullptr, recon, DVAE_NCHW, N, Cout, Cin, H, W, DVAE_ACT_SIGMOID};
   return launch_up_thin_recon_u8(a, target, g, dist, coef, partials, (hipStream_t)stream);
+}
+
+int dvae_conv4s2_wgrad_partial(const float* x, int x_layout, const float* dy, int dy_layout, int N, int Cin, int H, int W,
+                               int Cout, float* ws, void* stream) {
+  DVAE_CHECK_ARG(x && dy && ws && N > 0 && (H % 2 == 0) && (W % 2 == 0));
+  return run_wgrad(x, x_layout, dy, dy_layout, nullptr, nullptr, 0, N, Cin, Cout, H / 2, W / 2, ws, (hipStream_t)stream, true);
+}
+
+int dvae_convT4s2_wgrad_partial(const float* x, int x_layout, const float* dy, int dy_layout, int N, int Cin, int H, int W,
+                                int Cout, float* ws, void* stream) {
+  DVAE_CHECK_ARG(x && dy && ws && N > 0);
+  return run_wgrad(dy, dy_layout, x, x_layout, nullptr, nullptr, 1, N, Cout, Cin, H, W, ws, (hipStream_t)stream, true);
+}
+
+int dvae_conv_wgrad_reduce_grouped(const dvae_conv_wgrad_desc* descs, int n, void* stream) {
+  DVAE_CHECK_ARG(descs && n >= 1 && n <= DVAE_WGR_MAX);
+  for (int q = 0; q < n; ++q) DVAE_CHECK_ARG(descs[q].ws && descs[q].dw && descs[q].N > 0 && descs[q].H == descs[q].W);
+  return launch_wgrad_reduce_grouped(descs, n, (hipStream_t)stream);
 }
 
 size_t dvae_conv_wgrad_ws_floats(void) {

@@ -108,14 +108,15 @@ int launch_wgrad_generic(const float* big, int big_layout, const float* small, i
 int launch_down_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_up_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_wgrad_mfma32_ws(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N, int Hs,
-                           float* ws, hipStream_t s);    // wave-specialised, transposed LDS tiles (conv_wgrad_ws.hip): Hs in {8,16}
+                           float* ws, hipStream_t s, bool partial_only = false);    // wave-specialised, transposed LDS tiles (conv_wgrad_ws.hip): Hs in {8,16}
+int launch_wgrad_reduce_grouped(const dvae_conv_wgrad_desc* d, int n, hipStream_t s);
 int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_big, int nblk, hipStream_t s);
 int launch_up_mfma32_ws(const ConvArgs& a, hipStream_t s);      // wave-specialised (conv_up_ws.hip): Hs in {8,16}, NHWC
 #ifdef DVAE_DEBUG_SWITCHES
 int launch_up_mfma32_r2(const ConvArgs& a, hipStream_t s);   // experimental (conv_up_r2.hip), DVAE_UP_R2=1
 #endif
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big,
-                        int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0);
+                        int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0, bool partial_only = false);
 // thin paths (Cb in {1,3}, Cs == 32, big NCHW 64x64 / small NHWC 32x32)
 int launch_down_thin(const ConvArgs& a, hipStream_t s);
 int launch_up_thin(const ConvArgs& a, hipStream_t s);
@@ -123,7 +124,7 @@ int launch_up_thin(const ConvArgs& a, hipStream_t s);
 int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int dist, const float* coef,
                          float* partials, hipStream_t s);
 int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big,
-                      int N, int Cb, int Hs, float* ws, hipStream_t s);
+                      int N, int Cb, int Hs, float* ws, hipStream_t s, bool partial_only = false);
 // uint8 input image x[N,C,64,64] (NCHW), converted on the fly with ToTensor's float(v)/255; return 1 if C is not 1 or 3
 int launch_down_thin_u8(const uint8_t* x, const float* w, const float* bias, float* out, int N, int C, int act, hipStream_t s);
 int launch_up_thin_recon_u8(const ConvArgs& a, const uint8_t* target, float* g, int dist, const float* coef,

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "conv_mfma_common.h"
+#include "wgrad_reduce.h"
 
 namespace dvae {
 
@@ -484,10 +485,6 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
 }
 
 // ---- wgrad ---------------------------------------------------------------------------------
-#define WG_MAX_BLOCKS 256
-// stride between per-workgroup partial buffers: NOT a multiple of 64 KB, so that the reduce kernel's
-// loads of one output across all partials spread over HBM channels instead of hammering one
-#define WG_STRIDE (16384 + 320)
 template <int HS>
 __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, const float* __restrict__ small,
                                                  float* __restrict__ ws, int N, int n_units, int small_nchw) {
@@ -591,68 +588,16 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
   }
 }
 
-// bias gradient: 2 workgroups x (16 channels x 16 partial-groups)
-__device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws, float* __restrict__ db,
-                                                    int bias_from_big, int nblk, int blk) {
-  __shared__ float red[16][16];
-  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
-  const int c = blk * 16 + o;
-  const float* wsb = ws + 16384;
-  float pv[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int g = gq; g < nblk; g += 64) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int gg = g + 16 * u;
-      const float* q = wsb + (long)(gg < nblk ? gg : 0) * WG_STRIDE;
-      float v = bias_from_big ? (q[32 + c] + q[64 + c]) + (q[96 + c] + q[128 + c]) : q[c];
-      pv[u] += gg < nblk ? v : 0.f;
-    }
-  }
-  red[gq][o] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
-  __syncthreads();
-  if (gq == 0) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][o];
-    db[c] = t;
-  }
-}
-
-// 1024 workgroups x (16 outputs x 16 partial-groups), 8 loads in flight per lane, fixed order
 __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                         float* __restrict__ db, int bias_from_big, int nblk) {
-  if (blockIdx.x >= 1024) {                          // the last two workgroups reduce the bias gradient
-    if (db) wgrad32_bias_reduce(ws, db, bias_from_big, nblk, blockIdx.x - 1024);
-    return;
-  }
-  __shared__ float red[16][16];
-  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
-  const int idx = blockIdx.x * 16 + o;             // (tap, cs, cb)
-  float pv[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) pv[u] = 0.f;
-  int g = gq;
-  for (; g + 112 < nblk; g += 128) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) pv[u] += ws[(long)(g + 16 * u) * WG_STRIDE + idx];
-  }
-  for (; g < nblk; g += 16) pv[0] += ws[(long)g * WG_STRIDE + idx];
-  red[gq][o] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
-  __syncthreads();
-  if (gq == 0) {
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v += red[k][o];
-    const int tap = idx >> 10, cs = (idx >> 5) & 31, cb = idx & 31;
-    dw[(cs * 32 + cb) * 16 + tap] = v;
-  }
+  wgrad32_reduce_body(blockIdx.x, ws, dw, db, bias_from_big, nblk);
 }
 
 size_t wgrad32_ws_floats() { return (size_t)WG_MAX_BLOCKS * WG_STRIDE; }
 
 // fixed-order reduction of `nblk` per-workgroup partials (also used by conv_wgrad_ws.hip, which writes the same format)
 int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_big, int nblk, hipStream_t s) {
-  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(1024 + 2), dim3(256), 0, s, ws, dw, db, bias_from_big, nblk);
+  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(WG_REDUCE_BLOCKS), dim3(256), 0, s, ws, dw, db, bias_from_big, nblk);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -741,7 +686,7 @@ static int launch_up_t(const ConvArgs& a, hipStream_t s) {
 
 template <int HS>
 static int launch_wgrad_t(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
-                          float* ws, hipStream_t s, int small_nchw) {
+                          float* ws, hipStream_t s, int small_nchw, bool partial_only) {
   using G = Geo<HS>;
   const int n_units = units_for(N, HS);
   // (capping the persistent grid to leave CUs to the dgrad stream was measured: 128 -> +10 % step time)
@@ -755,7 +700,8 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units, small_nchw);
   DVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(1024 + 2), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+  if (partial_only) return 0;                       // dvae_conv_wgrad_reduce_grouped finishes it
+  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(WG_REDUCE_BLOCKS), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -798,13 +744,14 @@ int launch_up_mfma32(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
-                        int Hs, float* ws, hipStream_t s, int small_nchw) {
+                        int Hs, float* ws, hipStream_t s, int small_nchw, bool partial_only) {
   static const bool no_ws = env_off("DVAE_WGRAD_WS");     // debug builds: DVAE_WGRAD_WS=0 -> k_wgrad32 for every geometry (A/B)
-  if (!no_ws && !small_nchw && (Hs == 16 || Hs == 8)) return launch_wgrad_mfma32_ws(big, small, dw, db, bias_from_big, N, Hs, ws, s);
+  if (!no_ws && !small_nchw && (Hs == 16 || Hs == 8))
+    return launch_wgrad_mfma32_ws(big, small, dw, db, bias_from_big, N, Hs, ws, s, partial_only);
   switch (Hs) {
-    case 16: return launch_wgrad_t<16>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
-    case 8: return launch_wgrad_t<8>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
-    case 4: return launch_wgrad_t<4>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
+    case 16: return launch_wgrad_t<16>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw, partial_only);
+    case 8: return launch_wgrad_t<8>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw, partial_only);
+    case 4: return launch_wgrad_t<4>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw, partial_only);
     default: return 1;
   }
 }

@@ -10,6 +10,7 @@
 //   wgrad_thin (conv1 / convT3 wgrad): M = 32 cs, N = 16*C (cb,tap) columns, K = pixels.
 #include <stdlib.h>
 #include "common.h"
+#include "wgrad_reduce.h"
 
 namespace dvae {
 
@@ -284,7 +285,6 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
 }
 
 // ---- wgrad_thin ----------------------------------------------------------------------------
-#define WT_MAX_BLOCKS 512
 template <int C, typename TB = float>
 __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, const float* __restrict__ small,
                                                     float* __restrict__ ws, int N, int n_units) {
@@ -382,81 +382,10 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, 
   }
 }
 
-// bias gradient of the thin layers: (16 channels x 16 partial-groups) per workgroup
-template <int C>
-__device__ __forceinline__ void wgrad_thin_bias_reduce(const float* __restrict__ ws, float* __restrict__ db,
-                                                       int bias_from_big, int nblk, int blk) {
-  constexpr int NT = (16 * C + 31) / 32;
-  constexpr int STRIDE = NT * 1024 + 32 + NT * 32;
-  __shared__ float redb[16][16];
-  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
-  const int c = blk * 16 + o;
-  const int nout = bias_from_big ? C : 32;
-  // slot [0,32) = sum of the small side per cs; slots 32.. = per (cb,tap) column sums of the big side, of which
-  // taps (kh,kw) in {1,2}x{1,2} cover every big pixel exactly once
-  const int cc = c < nout ? c : 0;
-  const int t5 = cc * 16 + 5, t6 = cc * 16 + 6, t9 = cc * 16 + 9, t10 = cc * 16 + 10;
-  float pv[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int g = gq; g < nblk; g += 64) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int gg = g + 16 * u;
-      const float* q = ws + (long)(gg < nblk ? gg : 0) * STRIDE + NT * 1024;
-      float v;
-      if (bias_from_big)
-        v = (q[32 + (t5 >> 5) * 32 + (t5 & 31)] + q[32 + (t6 >> 5) * 32 + (t6 & 31)]) +
-            (q[32 + (t9 >> 5) * 32 + (t9 & 31)] + q[32 + (t10 >> 5) * 32 + (t10 & 31)]);
-      else
-        v = q[cc];
-      pv[u] += gg < nblk ? v : 0.f;
-    }
-  }
-  redb[gq][o] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
-  __syncthreads();
-  if (gq == 0 && c < nout) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += redb[k][o];
-    db[c] = t;
-  }
-}
-
-// 16 outputs x 16 partial-groups per workgroup; 8 loads in flight per lane; fixed summation order
 template <int C>
 __global__ __launch_bounds__(256) void k_wgrad_thin_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                            float* __restrict__ db, int bias_from_big, int nblk) {
-  constexpr int NT = (16 * C + 31) / 32;
-  constexpr int STRIDE = NT * 1024 + 32 + NT * 32;
-  constexpr int NB = (32 * 16 * C + 15) / 16;        // workgroups reducing dw; two more reduce db
-  if ((int)blockIdx.x >= NB) {
-    if (db) wgrad_thin_bias_reduce<C>(ws, db, bias_from_big, nblk, blockIdx.x - NB);
-    return;
-  }
-  __shared__ float red[16][16];
-  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
-  // dw[cs][cb][tap] : element idx = cs * 16C + nidx, nidx = cb*16 + tap
-  const int idx = blockIdx.x * 16 + o;
-  float pv[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) pv[u] = 0.f;
-  if (idx < 32 * 16 * C) {
-    const int cs = idx / (16 * C), nidx = idx % (16 * C);
-    const int off = (nidx >> 5) * 1024 + cs * 32 + (nidx & 31);
-    int g = gq;
-    for (; g + 112 < nblk; g += 128) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pv[u] += ws[(long)(g + 16 * u) * STRIDE + off];
-    }
-    for (; g < nblk; g += 16) pv[0] += ws[(long)g * STRIDE + off];
-  }
-  red[gq][o] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
-  __syncthreads();
-  if (gq == 0 && idx < 32 * 16 * C) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][o];
-    dw[idx] = t;
-  }
+  wgrad_thin_reduce_body<C>(blockIdx.x, ws, dw, db, bias_from_big, nblk);
 }
 
 size_t wgrad_thin_ws_floats() { return (size_t)WT_MAX_BLOCKS * (2 * 1024 + 32 + 2 * 32); }
@@ -532,11 +461,11 @@ int launch_wgrad_thin_u8(const uint8_t* x, const float* small, float* dw, float*
   if (C == 1) {
     hipLaunchKernelGGL((k_wgrad_thin<1, uint8_t>), dim3(grid), dim3(256), 0, s, x, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(32 + 2), dim3(256), 0, s, ws, dw, db, 0, grid);
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(WT_REDUCE_BLOCKS(1)), dim3(256), 0, s, ws, dw, db, 0, grid);
   } else if (C == 3) {
     hipLaunchKernelGGL((k_wgrad_thin<3, uint8_t>), dim3(grid), dim3(256), 0, s, x, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(96 + 2), dim3(256), 0, s, ws, dw, db, 0, grid);
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(WT_REDUCE_BLOCKS(3)), dim3(256), 0, s, ws, dw, db, 0, grid);
   } else {
     return 1;
   }
@@ -545,7 +474,7 @@ int launch_wgrad_thin_u8(const uint8_t* x, const float* small, float* dw, float*
 }
 
 int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N, int Cb,
-                      int Hs, float* ws, hipStream_t s) {
+                      int Hs, float* ws, hipStream_t s, bool partial_only) {
   if (!(Cb == 1 || Cb == 3) || Hs != 32) return 1;
   const int n_units = N * 8;
   int grid = n_units < WT_MAX_BLOCKS ? n_units : WT_MAX_BLOCKS;
@@ -556,11 +485,13 @@ int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db
   if (Cb == 1) {
     hipLaunchKernelGGL(k_wgrad_thin<1>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(32 + 2), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+    if (partial_only) return 0;
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(WT_REDUCE_BLOCKS(1)), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   } else {
     hipLaunchKernelGGL(k_wgrad_thin<3>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(96 + 2), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
+    if (partial_only) return 0;
+    hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(WT_REDUCE_BLOCKS(3)), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   }
   DVAE_CHECK_LAUNCH();
   return 0;

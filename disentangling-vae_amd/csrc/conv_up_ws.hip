@@ -199,14 +199,17 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
       }
     };
     for (int unit = unit0; unit < n_units; unit += stride, ++k) {
+      // Order matters: vector-memory operations retire in order (one vmcnt counter for loads AND stores on gfx950), so a
+      // wait for the input tile must not have this unit's 32 KB of output stores in front of it.  The tile (loaded one
+      // iteration ago) is consumed FIRST, the next tile's loads are issued, and only then the stores / mask loads.
+      if (unit + stride < n_units) store_small_n<LNPF>(pf, sd, in0 + ((k + 1) & 1) * G::SH_FLOATS);
+      if (unit + 2 * stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit + 2 * stride);
       if (prev >= 0) drain(prev, (k - 1) & 1);
       if (MASK) {                                   // this unit's mask, consumed one iteration later
         const float* src = mask + (long)unit * UPWS_OUT_FLOATS;
 #pragma unroll
         for (int j = 0; j < 8; ++j) mk[j] = *reinterpret_cast<const f32x4*>(src + (ht + 256 * j) * 4);
       }
-      if (unit + stride < n_units) store_small_n<LNPF>(pf, sd, in0 + ((k + 1) & 1) * G::SH_FLOATS);
-      if (unit + 2 * stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit + 2 * stride);
       prev = unit;
       __syncthreads();
     }

@@ -16,11 +16,12 @@
 // sums go to the workspace in k_wgrad32's format and k_wgrad32_reduce (conv_mfma.hip) finishes them in a fixed order.
 #include "common.h"
 #include "conv_mfma_common.h"
+#include "wgrad_reduce.h"
 
 namespace dvae {
 
-#define WGW_MAX_BLOCKS 256
-#define WGW_STRIDE (16384 + 320)            // = WG_STRIDE of conv_mfma.hip (the reduce kernel is shared)
+#define WGW_MAX_BLOCKS WG_MAX_BLOCKS
+#define WGW_STRIDE WG_STRIDE               // the reduce kernel (and its partial format) is shared with k_wgrad32
 
 template <int HS>
 struct WGeo {
@@ -147,8 +148,10 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
       }
     }
     // small tile: 64 pixels x 8 chunks = 512 slots, two per loader thread
-    f32x4 pb[W::BIG_NPF], ps[2];
-    auto load_unit = [&](int u) {
+    // two register sets: tiles k+2 and k+3 are in flight from HBM while tile k+1 sits in LDS (the whole chip issues its tile
+    // loads in the same few hundred cycles after a barrier: one unit time of look-ahead does not cover the queueing delay)
+    f32x4 pbA[W::BIG_NPF], psA[2], pbB[W::BIG_NPF], psB[2];
+    auto load_unit = [&](int u, f32x4 (&pb)[W::BIG_NPF], f32x4 (&ps)[2]) {
       const long P0 = (long)u * G::U;
       const int n0 = (int)(P0 / (HS * HS));
       const int sy0 = (int)(P0 % (HS * HS)) / HS;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
 #pragma unroll
       for (int k = 0; k < 2; ++k) ps[k] = *reinterpret_cast<const f32x4*>(sbase_g + (lt + k * 256) * 4);
     };
-    auto store_unit = [&](int b) {
+    auto store_unit = [&](int b, const f32x4 (&pb)[W::BIG_NPF], const f32x4 (&ps)[2]) {
       float* bt = smem + b * W::BUF_FLOATS;
       float* st = bt + W::BT_FLOATS;
 #pragma unroll
@@ -183,21 +186,29 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
         for (int u = 0; u < 4; ++u) st[(4 * chunk + u) * W::SSTR + p] = ps[k][u];
       }
     };
-    if (unit0 < n_units) { load_unit(unit0); store_unit(0); }
-    if (unit0 + stride < n_units) load_unit(unit0 + stride);
+    if (unit0 < n_units) { load_unit(unit0, pbA, psA); store_unit(0, pbA, psA); }
+    if (unit0 + stride < n_units) load_unit(unit0 + stride, pbA, psA);
+    if (unit0 + 2 * stride < n_units) load_unit(unit0 + 2 * stride, pbB, psB);
     __syncthreads();
-    int k = 0;
-    for (int unit = unit0; unit < n_units; unit += stride, ++k) {
-      if (unit + stride < n_units) store_unit((k + 1) & 1);
-      if (unit + 2 * stride < n_units) load_unit(unit + 2 * stride);
+    // set A holds tiles k+1 (k even), set B tiles k+1 (k odd); the loop is unrolled by two so that the sets stay static
+    int unit = unit0;
+    while (unit < n_units) {
+      if (unit + stride < n_units) store_unit(1, pbA, psA);
+      if (unit + 3 * stride < n_units) load_unit(unit + 3 * stride, pbA, psA);
       __syncthreads();
+      unit += stride;
+      if (unit >= n_units) break;
+      if (unit + stride < n_units) store_unit(0, pbB, psB);
+      if (unit + 3 * stride < n_units) load_unit(unit + 3 * stride, pbB, psB);
+      __syncthreads();
+      unit += stride;
     }
   }
 }
 
 template <int HS>
 static int launch_wgrad_ws_t(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
-                             float* ws, hipStream_t s) {
+                             float* ws, hipStream_t s, bool partial_only) {
   using W = WGeo<HS>;
   const int n_units = (int)(((long)N * HS * HS) / 64);
   const int grid = n_units < WGW_MAX_BLOCKS ? n_units : WGW_MAX_BLOCKS;
@@ -206,14 +217,15 @@ static int launch_wgrad_ws_t(const float* big, const float* small, float* dw, fl
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32ws<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(k_wgrad32ws<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, n_units);
   DVAE_CHECK_LAUNCH();
+  if (partial_only) return 0;
   return launch_wgrad32_reduce(ws, dw, db, bias_from_big, grid, s);
 }
 
 // NHWC on both sides, Hs in {8, 16}; returns 1 if not applicable
 int launch_wgrad_mfma32_ws(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N, int Hs,
-                           float* ws, hipStream_t s) {
-  if (Hs == 16) return launch_wgrad_ws_t<16>(big, small, dw, db, bias_from_big, N, ws, s);
-  if (Hs == 8) return launch_wgrad_ws_t<8>(big, small, dw, db, bias_from_big, N, ws, s);
+                           float* ws, hipStream_t s, bool partial_only) {
+  if (Hs == 16) return launch_wgrad_ws_t<16>(big, small, dw, db, bias_from_big, N, ws, s, partial_only);
+  if (Hs == 8) return launch_wgrad_ws_t<8>(big, small, dw, db, bias_from_big, N, ws, s, partial_only);
   return 1;
 }
 

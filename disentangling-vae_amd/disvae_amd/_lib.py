@@ -37,6 +37,9 @@ SIGNATURES = {
     "dvae_convT4s2_wgrad": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "dvae_convT4s2_sigmoid_recon_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "dvae_conv_wgrad_ws_floats": [],
+    "dvae_conv4s2_wgrad_partial": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "dvae_convT4s2_wgrad_partial": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "dvae_conv_wgrad_reduce_grouped": [_p, _i, _p],
     "dvae_u8_to_f32": [_p, _p, _l, _p],
     "dvae_u8_fused_supported": [_i, _i, _i],
     "dvae_conv4s2_fwd_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -87,6 +90,23 @@ FCW_MAX = 8
 class LinearWgradDesc(ctypes.Structure):
     """dvae_linear_wgrad_desc (include/dvae_hip.h)."""
     _fields_ = [("x", _p), ("dy", _p), ("dw", _p), ("db", _p), ("M", _i), ("K", _i), ("N", _i)]
+
+
+WGR_MAX = 8
+
+
+class ConvWgradDesc(ctypes.Structure):
+    """dvae_conv_wgrad_desc (include/dvae_hip.h)."""
+    _fields_ = [("ws", _p), ("dw", _p), ("db", _p), ("N", _i), ("Cin", _i), ("H", _i), ("W", _i), ("Cout", _i),
+                ("transposed", _i)]
+
+
+def conv_wgrad_descs(problems):
+    """[(ws, dw, db, N, Cin, H, W, Cout, transposed), ...] -> (host array, its address); keep the array alive."""
+    arr = (ConvWgradDesc * len(problems))()
+    for d, vals in zip(arr, problems):
+        d.ws, d.dw, d.db, d.N, d.Cin, d.H, d.W, d.Cout, d.transposed = vals
+    return arr, ctypes.addressof(arr)
 
 
 def wgrad_descs(problems):

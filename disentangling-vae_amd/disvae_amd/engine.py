@@ -105,6 +105,7 @@ class ParamArena:
 
 
 _CONV_WGRAD_MAIN = os.environ.get("DVAE_CONV_WGRAD_MAIN", "0") == "1"
+_DEFER_REDUCE = os.environ.get("DVAE_DEFER_REDUCE", "1") != "0"     # A/B: 0 = every conv wgrad reduces on its own
 
 
 def _stream():
@@ -160,6 +161,9 @@ class VAEEngine:
         self._side = None      # side HIP stream: the FC weight-gradient GEMMs run beside the dgrad chain
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
         self._fc_descs = {}    # host descriptor arrays of the grouped launches, kept alive for recorded plans
+        self._defer_reduce = False   # conv weight gradients: partial sums now, ONE grouped reduction at the end of the backward pass
+        self._reduce_pending = []
+        self._layer_ws = {}    # one partial-sum workspace per conv layer (deferred reductions need them all alive)
 
     @property
     def device(self):
@@ -214,16 +218,45 @@ class VAEEngine:
             ent = self._fc_descs[key] = _lib.wgrad_descs(key)
         call("dvae_linear_wgrad_grouped", ent[1], len(problems), self._side.cuda_stream)
 
-    def _conv_wgrad(self, fn, *args, fork=True):
+    def _ws_of(self, key):
+        w = self._layer_ws.get(key)
+        if w is None or w.device != self.device:
+            _lib.note_alloc()
+            w = self._layer_ws[key] = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), dtype=torch.float32, device=self.device)
+        return w
+
+    def _conv_wgrad(self, fn, *args, fork=True, main=False):
         """Conv / convT weight gradient `fn(*args, ws, stream)`: off the dgrad critical path, so it
-        goes to the side stream (after a fork) and co-runs with the dgrad chain;
-        DVAE_CONV_WGRAD_MAIN=1 keeps it on the current stream."""
-        if _CONV_WGRAD_MAIN:
-            call(fn, *args, ptr(self._ws), _stream())
-            return
-        if fork:
+        goes to the side stream (after a fork) and co-runs with the dgrad chain (main=True: the current stream);
+        DVAE_CONV_WGRAD_MAIN=1 keeps it on the current stream.  While reductions are deferred (tuned 64x64 geometry)
+        only the accumulation kernel runs here, into the layer's own workspace; `_reduce_convs` finishes every layer of
+        the backward pass in ONE launch (8 latency-bound ~10 us reduce kernels less on the weight-gradient stream)."""
+        on_main = main or _CONV_WGRAD_MAIN
+        if fork and not on_main:
             self.fork_side()
-        call(fn, *args, ptr(self._ws_side), self._side.cuda_stream)
+        stream = _stream() if on_main else self._side.cuda_stream
+        if self._defer_reduce:
+            x, xl, dy, dyl, dw, db, N, Cin, H, W, Cout = args
+            ws = self._ws_of((fn, dw))
+            call(fn + "_partial", x, xl, dy, dyl, N, Cin, H, W, Cout, ptr(ws), stream)
+            self._reduce_pending.append((ptr(ws), dw, db, N, Cin, H, W, Cout, 1 if fn.startswith("dvae_convT") else 0))
+            return
+        call(fn, *args, ptr(self._ws if on_main else self._ws_side), stream)
+
+    def _reduce_convs(self):
+        """One launch: the fixed-order reductions of every deferred conv / convT weight gradient (current stream; the
+        side stream must have been joined)."""
+        pend, self._reduce_pending = self._reduce_pending, []
+        if not pend:
+            return
+        key = ("wgr",) + tuple(pend)
+        ent = self._fc_descs.get(key)
+        if ent is None:
+            if len(self._fc_descs) >= 64:
+                self._fc_descs.clear()
+                _lib.note_alloc()
+            ent = self._fc_descs[key] = _lib.conv_wgrad_descs(pend)
+        call("dvae_conv_wgrad_reduce_grouped", ent[1], len(pend), _stream())
 
     def _join_side(self):
         record_py(torch.cuda.current_stream().wait_stream, self._side)
@@ -330,6 +363,10 @@ class VAEEngine:
         D = self.latent_dim
         c = self.img_size[0]
         ws = ptr(self._ws)
+        # an encode_backward follows (defer_fc_wgrad): leave the conv reductions to its grouped launch as well
+        self._defer_reduce = bool(defer_fc_wgrad) and self.is64 and _DEFER_REDUCE
+        if not self._defer_reduce:
+            self._reduce_pending = []
         acts = [buf.d3] + buf.dec_act           # inputs of convT_64/convT1/convT2/convT3 (the first one NCHW = lin3's output)
         gacts = [buf.gd3] + buf.dec_gact
         names = self.dec_names + ["convT3"]
@@ -382,6 +419,7 @@ class VAEEngine:
             self._fc_pending = fc
         else:
             self._side_wgrad_grouped(fc)
+        self._defer_reduce = False
         if join:
             self._join_side()
 
@@ -391,6 +429,8 @@ class VAEEngine:
         B = x.shape[0] if n is None else n
         c, H, _ = self.img_size
         ws = ptr(self._ws)
+        self._reduce_pending = [p_ for p_ in self._reduce_pending if p_[3] == B]     # the decoder's, if it deferred them
+        self._defer_reduce = self.is64 and _DEFER_REDUCE
         call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
              ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
         call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
@@ -435,7 +475,7 @@ class VAEEngine:
                     call("dvae_conv4s2_wgrad_u8", ptr(x), ptr(dy), ptr(self.g("encoder.%s.weight" % name)),
                          ptr(self.g("encoder.%s.bias" % name)), B, cin, h_in, h_in, HID, ptr(self._ws), s)
                 else:
-                    call(wargs[0], *wargs[1:], ptr(self._ws), s)
+                    self._conv_wgrad(*wargs, fork=False, main=True)
             elif big:
                 self.fork_side()
                 side, deferred = deferred + [lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False)], []
@@ -451,3 +491,5 @@ class VAEEngine:
             for launch in deferred:
                 launch()
         self._join_side()
+        self._defer_reduce = False
+        self._reduce_convs()

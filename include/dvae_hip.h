@@ -83,6 +83,24 @@ int dvae_convT4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_la
                         float* db, int N, int Cin, int H, int W, int Cout, float* ws, void* stream);
 size_t dvae_conv_wgrad_ws_floats(void);
 
+/* Deferred reduction of the conv / convT weight gradients (tuned geometries only: 64x64 images, C in {1,3,32}):
+ * dvae_conv4s2_wgrad_partial / dvae_convT4s2_wgrad_partial run the accumulation kernel of dvae_conv*_wgrad and leave the
+ * per-workgroup partial sums in `ws` (dvae_conv_wgrad_ws_floats() floats, ONE workspace per layer, untouched until reduced);
+ * dvae_conv_wgrad_reduce_grouped finishes up to DVAE_WGR_MAX layers in ONE launch -- same fixed summation order, hence
+ * bit-identical to the one-call forms.  `descs` is a host array read during the call.                                */
+#define DVAE_WGR_MAX 8
+typedef struct {
+  const float* ws;      /* the workspace the partial call filled */
+  float* dw; float* db; /* outputs as in dvae_conv*_wgrad (db may be NULL) */
+  int N, Cin, H, W, Cout;   /* the layer's geometry, as passed to the partial call */
+  int transposed;       /* 0: dvae_conv4s2_wgrad_partial, 1: dvae_convT4s2_wgrad_partial */
+} dvae_conv_wgrad_desc;
+int dvae_conv4s2_wgrad_partial(const float* x, int x_layout, const float* dy, int dy_layout, int N, int Cin, int H,
+                               int W, int Cout, float* ws, void* stream);
+int dvae_convT4s2_wgrad_partial(const float* x, int x_layout, const float* dy, int dy_layout, int N, int Cin, int H,
+                                int W, int Cout, float* ws, void* stream);
+int dvae_conv_wgrad_reduce_grouped(const dvae_conv_wgrad_desc* descs, int n, void* stream);
+
 /* ---- uint8 input pipeline: utils/datasets.py:204-213 (dSprites: imgs * 255 -> ToTensor), :282-291 (CelebA:
  * imread -> ToTensor).  The batch stays uint8 [N,C,H,W] in HBM (NCHW = ToTensor's output order, 1 byte per pixel);
  * ToTensor's arithmetic, float(v) / 255 with IEEE division, is applied by the three consumers of the input image
