@@ -78,6 +78,12 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
   static_assert(G::IMGS == 1, "one image per unit");
   constexpr int HB = 2 * HS;
   constexpr int LNPF = (G::SH_SLOTS + 255) / 256;
+#ifdef DVAE_DEBUG_SWITCHES
+  const int abl = act >> 8;     // timing ablations (DVAE_UPWS_ABLATE, debug builds; results invalid): 1 no output stores,
+  act &= 0xff;                  // 2 no mask loads, 4 no tile loads, 8 no MFMAs, 16 no epilogue LDS writes, 32 no drain at all
+#else
+  constexpr int abl = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                                  // 16384 floats: w[tap][cs/4][cb][cs%4]
   float* in0 = smem + 16384;                         // 2 x G::SH_FLOATS
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
         A1[slot] = *reinterpret_cast<const f32x4*>(in + aoff[1][t][q]);
         Bv[slot] = *reinterpret_cast<const f32x4*>(wl + boff + ((kh * 4 + kw) * 8 + 2 * q) * 128);
       };
+      if (!(abl & 8)) {
       rd(0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 DS reads (next group)
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMAs (this group)
       }
+      }
       // bias / activation, D fragments -> output image (lanes 0-31 / 32-63 of a store: two pixels x 32 channels)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -172,8 +180,7 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
         const int dm = dpp / PPR, dl = dpp % PPR;    // (4h never carries into the row: 4h + (e&3) + 8*((e>>2)&1) < 16, < 8 for HS=8)
         const int d = (2 * dm * HB + 2 * dl) * 32;
         float v0 = epilogue_act(acc0[e] + bv, act), v1 = epilogue_act(acc1[e] + bv, act);
-        ob[ooff[0] + d] = v0;
-        ob[ooff[1] + d] = v1;
+        if (!(abl & 16)) { ob[ooff[0] + d] = v0; ob[ooff[1] + d] = v1; }
       }
       __syncthreads();
       buf ^= 1;
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
 #pragma unroll
           for (int x = 0; x < 4; ++x) v[x] = mk[j][x] > 0.f ? v[x] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(dst + c) = v;
+        if (!(abl & 1)) *reinterpret_cast<f32x4*>(dst + c) = v;
       }
     };
     for (int unit = unit0; unit < n_units; unit += stride, ++k) {
@@ -203,9 +210,9 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
       // wait for the input tile must not have this unit's 32 KB of output stores in front of it.  The tile (loaded one
       // iteration ago) is consumed FIRST, the next tile's loads are issued, and only then the stores / mask loads.
       if (unit + stride < n_units) store_small_n<LNPF>(pf, sd, in0 + ((k + 1) & 1) * G::SH_FLOATS);
-      if (unit + 2 * stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit + 2 * stride);
-      if (prev >= 0) drain(prev, (k - 1) & 1);
-      if (MASK) {                                   // this unit's mask, consumed one iteration later
+      if (unit + 2 * stride < n_units && !(abl & 4)) load_small_n<HS, LNPF>(pf, sd, small, unit + 2 * stride);
+      if (prev >= 0 && !(abl & 32)) drain(prev, (k - 1) & 1);
+      if (MASK && !(abl & 2)) {                     // this unit's mask, consumed one iteration later
         const float* src = mask + (long)unit * UPWS_OUT_FLOATS;
 #pragma unroll
         for (int j = 0; j < 8; ++j) mk[j] = *reinterpret_cast<const f32x4*>(src + (ht + 256 * j) * 4);
@@ -229,8 +236,10 @@ static int launch_up_ws_t(const ConvArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_up32ws<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  if (a.mask) hipLaunchKernelGGL((k_up32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.act, n_units);
-  else hipLaunchKernelGGL((k_up32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.act, n_units);
+  static const int abl = env_int("DVAE_UPWS_ABLATE", 0);      // debug builds only
+  const int af = a.act | (abl << 8);
+  if (a.mask) hipLaunchKernelGGL((k_up32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units);
+  else hipLaunchKernelGGL((k_up32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -105,7 +105,10 @@ class ParamArena:
 
 
 _CONV_WGRAD_MAIN = os.environ.get("DVAE_CONV_WGRAD_MAIN", "0") == "1"
-_DEFER_REDUCE = os.environ.get("DVAE_DEFER_REDUCE", "1") != "0"     # A/B: 0 = every conv wgrad reduces on its own
+# 1 = conv weight gradients leave their partial sums and ONE grouped launch reduces all layers at the end of the backward
+# pass.  Measured (profiles/r02_run6_ab.txt): 8 reduce launches fewer but +1.5 % step time at B=1024 -- the per-layer
+# reductions hide in the side stream, the grouped one (137 MB of partials, ~37 us) sits on the critical path -> default 0
+_DEFER_REDUCE = os.environ.get("DVAE_DEFER_REDUCE", "0") == "1"
 
 
 def _stream():
