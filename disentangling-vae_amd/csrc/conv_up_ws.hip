@@ -14,8 +14,10 @@
 //   waves 4-7 = memory: input tiles two units ahead (registers) and one unit ahead (LDS), the previous unit's output
 //       block from LDS to HBM with 16-byte coalesced stores -- a unit's output is ONE contiguous 32 KB block of the NHWC
 //       tensor -- masked by the producing layer's activation fetched with 16-byte loads one unit ahead.
-// One workgroup barrier per unit; input and output images are double-buffered in LDS (64 KB weights + 2 x 13.5 KB in
-// + 2 x 32 KB out = 155 KB: one workgroup per CU, as before).
+// One workgroup barrier per unit; input and output images are double-buffered in LDS.  The weights of a compute wave's
+// class live in 64 VGPRs per lane for the whole kernel (they are the same for every unit), so the 64 KB LDS weight image
+// is only a staging area of the prologue and the two 32 KB output images reuse it: 64 KB + 2 x 13.5 KB = 91 KB.  The
+// bias / ReLU / LDS-write epilogue of unit u is issued inside the MFMA stream of unit u+1 (two accumulator sets).
 // Per unit a CU moves 13.5 KB in + 32 KB out (+ 32 KB mask) for 8192 matrix-core cycles: at 100 % MFMA rate that is
 // 3.5 (5.9) TB/s over the chip -- the masked variant is HBM- and MFMA-bound at the same time.
 #include "common.h"
@@ -80,14 +82,14 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
   constexpr int LNPF = (G::SH_SLOTS + 255) / 256;
 #ifdef DVAE_DEBUG_SWITCHES
   const int abl = act >> 8;     // timing ablations (DVAE_UPWS_ABLATE, debug builds; results invalid): 1 no output stores,
-  act &= 0xff;                  // 2 no mask loads, 4 no tile loads, 8 no MFMAs, 16 no epilogue LDS writes, 32 no drain at all
+  act &= 0xff;                  // 2 no mask loads
 #else
   constexpr int abl = 0;
 #endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* wl = smem;                                  // 16384 floats: w[tap][cs/4][cb][cs%4]
+  float* wl = smem;                                  // 16384 floats: w[tap][cs/4][cb][cs%4] -- prologue only
+  float* out0 = smem;                                // 2 x UPWS_OUT_FLOATS: the output images REUSE the weight image's space
   float* in0 = smem + 16384;                         // 2 x G::SH_FLOATS
-  float* out0 = in0 + 2 * G::SH_FLOATS;              // 2 x UPWS_OUT_FLOATS
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_compute = wv < 4;
@@ -106,15 +108,31 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
     if (unit0 < n_units) store_small_n<LNPF>(pf, sd, in0);
     if (unit0 + stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit0 + stride);
   }
-  __syncthreads();
+  __syncthreads();                                   // weight image and the first input tile are in LDS
+
+  // compute-wave constants (the memory waves skip this)
+  const int cls = wv & 3;
+  const int py = cls >> 1, px = cls & 1;
+  const int i = lane & 31, h = lane >> 5;
+  // B operands of this wave's parity class -- 4 taps x 32 contracted channels x 32 output channels = 64 VGPRs per lane --
+  // stay in registers for the whole kernel: the weights are the same for every unit, and every LDS read taken out of the
+  // MFMA loop shortens it (timing ablations, profiles/r02_run7_upws_ablation.txt: operand reads cost 15 % of the loop)
+  f32x4 Bq[4][4];
+  if (is_compute) {
+    const int boff = i * 4 + h * 128;                // + ((kh*4+kw)*8 + 2q) * 128
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kh = 1 - py + 2 * (t >> 1), kw = 1 - px + 2 * (t & 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Bq[t][q] = *reinterpret_cast<const f32x4*>(wl + boff + ((kh * 4 + kw) * 8 + 2 * q) * 128);
+    }
+  }
+  __syncthreads();                                   // the weight image is dead from here on: the output images reuse its 64 KB
 
   if (is_compute) {
     // ---------------------------------------------------------------- compute waves: class cls, both M-tiles
-    const int cls = wv;
-    const int py = cls >> 1, px = cls & 1;
-    const int i = lane & 31, h = lane >> 5;
     const float bv = bias ? bias[i] : 0.f;
-    // LDS float offsets of the A operand (input tile) for (M-tile, tap, 8-channel group) and of the B operand (weights)
+    // LDS float offsets of the A operand (input tile) for (M-tile, tap, 8-channel group)
     int aoff[2][4][4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -129,7 +147,6 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
         for (int q = 0; q < 4; ++q) aoff[mt][t][q] = (row * G::SCOLS + col) * 32 + (((2 * q + h) ^ sw) << 2);
       }
     }
-    const int boff = i * 4 + h * 128;                // + ((kh*4+kw)*8 + 2q) * 128
     // D-fragment row e of M-tile mt -> float offset in the output image: ((2m+py) * HB + 2l+px) * 32 + i
     int ooff[2];
 #pragma unroll
@@ -138,58 +155,73 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
       const int m = pp / HS, l = pp % HS;
       ooff[mt] = ((2 * m + py) * HB + 2 * l + px) * 32 + i;
     }
-    __builtin_amdgcn_s_setprio(1);
-    int buf = 0;
-    for (int unit = unit0; unit < n_units; unit += stride) {
-      const float* in = in0 + buf * G::SH_FLOATS;
-      float* ob = out0 + buf * UPWS_OUT_FLOATS;
-      f32x16 acc0, acc1;
+    struct Acc { f32x16 a0, a1; };
+    // bias / activation of D-fragment rows [e0, e1) of a finished unit -> its output image (lanes 0-31 / 32-63 of a
+    // store: two pixels x 32 channels)
+    auto epilogue = [&](const Acc& P, float* ob, int e0, int e1) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-      f32x4 A0[2], A1[2], Bv[2];
+      for (int e = e0; e < e1; ++e) {
+        // pixel pp = mt*32 + 4h + (e&3) + 8*(e>>2); 4h + (e&3) + 8*((e>>2)&1) never carries into the next small row
+        const int dpp = (e & 3) + 8 * (e >> 2);
+        const int dm = dpp / HS, dl = dpp % HS;
+        const int d = (2 * dm * HB + 2 * dl) * 32;
+        ob[ooff[0] + d] = epilogue_act(P.a0[e] + bv, act);
+        ob[ooff[1] + d] = epilogue_act(P.a1[e] + bv, act);
+      }
+    };
+    // One unit: 128 MFMAs into C from the input image `in`; the PREVIOUS unit's results P are finished (bias, ReLU, LDS
+    // image `pob`) in the shadow of the first 8 MFMA groups -- the matrix core never waits for an epilogue.
+    auto unit_body = [&](Acc& C, const Acc& P, const float* in, float* pob, bool have_prev) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { C.a0[e] = 0.f; C.a1[e] = 0.f; }
+      f32x4 A0[2], A1[2];
       auto rd = [&](int g, int slot) {
         const int t = g >> 2, q = g & 3;
-        const int ty = t >> 1, tx = t & 1;
-        const int kh = 1 - py + 2 * ty, kw = 1 - px + 2 * tx;
         A0[slot] = *reinterpret_cast<const f32x4*>(in + aoff[0][t][q]);
         A1[slot] = *reinterpret_cast<const f32x4*>(in + aoff[1][t][q]);
-        Bv[slot] = *reinterpret_cast<const f32x4*>(wl + boff + ((kh * 4 + kw) * 8 + 2 * q) * 128);
       };
-      if (!(abl & 8)) {
       rd(0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int cur = g & 1;
+        const int t = g >> 2, q = g & 3;
         if (g + 1 < 16) rd(g + 1, cur ^ 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[cur][j], Bv[cur][j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[cur][j], Bv[cur][j], acc1, 0, 0, 0);
+          C.a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[cur][j], Bq[t][q][j], C.a0, 0, 0, 0);
+          C.a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[cur][j], Bq[t][q][j], C.a1, 0, 0, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 DS reads (next group)
+        if (have_prev && g < 8) epilogue(P, pob, 2 * g, 2 * g + 2);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads (next group)
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMAs (this group)
+        if (have_prev && g < 8) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // 8 VALU (bias + activation of 4 results)
+          __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);   // 4 DS writes
+        }
       }
-      }
-      // bias / activation, D fragments -> output image (lanes 0-31 / 32-63 of a store: two pixels x 32 channels)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        // pixel pp = mt*32 + (e&3) + 8*(e>>2) + 4h: HS=16: m += (e>>3), l += (e&3) + 8*((e>>2)&1);  HS=8: m += (e>>2), l += (e&3)
-        constexpr int PPR = HS;                      // small pixels per small row
-        const int dpp = (e & 3) + 8 * (e >> 2);
-        const int dm = dpp / PPR, dl = dpp % PPR;    // (4h never carries into the row: 4h + (e&3) + 8*((e>>2)&1) < 16, < 8 for HS=8)
-        const int d = (2 * dm * HB + 2 * dl) * 32;
-        float v0 = epilogue_act(acc0[e] + bv, act), v1 = epilogue_act(acc1[e] + bv, act);
-        if (!(abl & 16)) { ob[ooff[0] + d] = v0; ob[ooff[1] + d] = v1; }
-      }
+    };
+    __builtin_amdgcn_s_setprio(1);
+    Acc X, Y;
+    int unit = unit0, k = 0;
+    // iteration k computes unit k and writes the results of unit k-1 into output image (k-1)&1; X / Y alternate
+    unit_body(X, X, in0, nullptr, false);
+    __syncthreads();
+    unit += stride; k = 1;
+    for (;;) {
+      if (unit >= n_units) { epilogue(X, out0 + ((k - 1) & 1) * UPWS_OUT_FLOATS, 0, 16); break; }
+      unit_body(Y, X, in0 + (k & 1) * G::SH_FLOATS, out0 + ((k - 1) & 1) * UPWS_OUT_FLOATS, true);
       __syncthreads();
-      buf ^= 1;
+      unit += stride; ++k;
+      if (unit >= n_units) { epilogue(Y, out0 + ((k - 1) & 1) * UPWS_OUT_FLOATS, 0, 16); break; }
+      unit_body(X, Y, in0 + (k & 1) * G::SH_FLOATS, out0 + ((k - 1) & 1) * UPWS_OUT_FLOATS, true);
+      __syncthreads();
+      unit += stride; ++k;
     }
+    __syncthreads();                                 // the last unit's image is visible to the memory waves
   } else {
     // ---------------------------------------------------------------- memory waves
     f32x4 mk[8];
-    int k = 0;
-    int prev = -1;
     auto drain = [&](int u, int b) {
       // unit u's output block is contiguous: out + u * 8192 floats
       const float* ob = out0 + b * UPWS_OUT_FLOATS;
@@ -205,22 +237,28 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
         if (!(abl & 1)) *reinterpret_cast<f32x4*>(dst + c) = v;
       }
     };
-    for (int unit = unit0; unit < n_units; unit += stride, ++k) {
-      // Order matters: vector-memory operations retire in order (one vmcnt counter for loads AND stores on gfx950), so a
-      // wait for the input tile must not have this unit's 32 KB of output stores in front of it.  The tile (loaded one
-      // iteration ago) is consumed FIRST, the next tile's loads are issued, and only then the stores / mask loads.
-      if (unit + stride < n_units) store_small_n<LNPF>(pf, sd, in0 + ((k + 1) & 1) * G::SH_FLOATS);
-      if (unit + 2 * stride < n_units && !(abl & 4)) load_small_n<HS, LNPF>(pf, sd, small, unit + 2 * stride);
-      if (prev >= 0 && !(abl & 32)) drain(prev, (k - 1) & 1);
-      if (MASK && !(abl & 2)) {                     // this unit's mask, consumed one iteration later
-        const float* src = mask + (long)unit * UPWS_OUT_FLOATS;
+    // iteration k (k = 0 .. K, K = number of units of this workgroup): input image of unit k+1 <- registers, loads of unit
+    // k+2; output image of unit k-2 -> HBM (the compute waves write unit k-1's image during this iteration); mask of
+    // unit k-1 -> registers.  Vector-memory operations retire in order (one vmcnt counter for loads and stores on gfx950):
+    // the tile is consumed and re-requested BEFORE this iteration's 32 KB of output stores are issued.
+    int unit = unit0, k = 0, u1 = -1, u2 = -1;       // u1 / u2: units k-1 / k-2
+    for (;;) {
+      const bool have = unit < n_units;
+      if (have) {
+        if (unit + stride < n_units) store_small_n<LNPF>(pf, sd, in0 + ((k + 1) & 1) * G::SH_FLOATS);
+        if (unit + 2 * stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit + 2 * stride);
+      }
+      if (u2 >= 0) drain(u2, k & 1);
+      if (MASK && u1 >= 0 && !(abl & 2)) {
+        const float* src = mask + (long)u1 * UPWS_OUT_FLOATS;
 #pragma unroll
         for (int j = 0; j < 8; ++j) mk[j] = *reinterpret_cast<const f32x4*>(src + (ht + 256 * j) * 4);
       }
-      prev = unit;
       __syncthreads();
+      if (!have) break;
+      u2 = u1; u1 = unit; unit += stride; ++k;
     }
-    if (prev >= 0) drain(prev, (k - 1) & 1);
+    if (u1 >= 0) drain(u1, (k - 1) & 1);
   }
 }
 
@@ -229,7 +267,8 @@ static int launch_up_ws_t(const ConvArgs& a, hipStream_t s) {
   using G = Geo<HS>;
   const int n_units = (int)(((long)a.N * HS * HS) / 64);     // HS*HS is a multiple of 64: every unit is complete
   const int grid = n_units < 256 ? n_units : 256;
-  const size_t lds = (size_t)(16384 + 2 * G::SH_FLOATS + 2 * UPWS_OUT_FLOATS) * sizeof(float);
+  static_assert(2 * UPWS_OUT_FLOATS == 16384, "the two output images occupy exactly the weight image");
+  const size_t lds = (size_t)(16384 + 2 * G::SH_FLOATS) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k_up32ws<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
