@@ -162,6 +162,11 @@ class VAEEngine:
         self._ws = None
         self._ws_side = None
         self._side = None      # side HIP stream: the FC weight-gradient GEMMs run beside the dgrad chain
+        # small batches: everything on the caller's stream.  Below ~256 images the iteration is bound by the latency of
+        # dependent launches, a fork / join between hardware queues costs ~6 us each (5 forks + 1 join per iteration) and
+        # the weight-gradient kernels that the side stream would overlap are a few microseconds long.  Set per step by the
+        # loss plugins (BaseLoss._streams).
+        self.single_stream = False
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
         self._fc_descs = {}    # host descriptor arrays of the grouped launches, kept alive for recorded plans
         self._defer_reduce = False   # conv weight gradients: partial sums now, ONE grouped reduction at the end of the backward pass
@@ -196,17 +201,22 @@ class VAEEngine:
         """Order the side stream after everything enqueued so far on the current stream.  A fork
         costs the current stream ~6 us (event signal between hardware queues, profiles/r01_run19
         timeline), so the FC weight gradients fork once per chain, not once per layer."""
+        if self.single_stream:
+            return
         record_py(self._side.wait_stream, torch.cuda.current_stream())
 
     @property
     def side_stream(self):
-        return self._side
+        return torch.cuda.current_stream() if self.single_stream else self._side
+
+    def _side_raw(self):
+        return _stream() if self.single_stream else self._side.cuda_stream
 
     def _side_wgrad(self, x, dy, dw, db, M, K, N):
         """dw, db <- wgrad(x, dy) on the side stream (after a fork_side): overlaps with whatever the
         current stream does next."""
         call("dvae_linear_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(db), M, K, N, ptr(self._ws_side),
-             self._side.cuda_stream)
+             self._side_raw())
 
     def _side_wgrad_grouped(self, problems):
         """All FC weight gradients of `problems` = [(x, dy, dw, db, M, K, N)] (tensors) in ONE launch on the side stream
@@ -219,7 +229,7 @@ class VAEEngine:
                 self._fc_descs.clear()
                 _lib.note_alloc()
             ent = self._fc_descs[key] = _lib.wgrad_descs(key)
-        call("dvae_linear_wgrad_grouped", ent[1], len(problems), self._side.cuda_stream)
+        call("dvae_linear_wgrad_grouped", ent[1], len(problems), self._side_raw())
 
     def _ws_of(self, key):
         w = self._layer_ws.get(key)
@@ -237,7 +247,7 @@ class VAEEngine:
         on_main = main or _CONV_WGRAD_MAIN
         if fork and not on_main:
             self.fork_side()
-        stream = _stream() if on_main else self._side.cuda_stream
+        stream = _stream() if on_main else self._side_raw()
         if self._defer_reduce:
             x, xl, dy, dyl, dw, db, N, Cin, H, W, Cout = args
             ws = self._ws_of((fn, dw))
@@ -262,6 +272,8 @@ class VAEEngine:
         call("dvae_conv_wgrad_reduce_grouped", ent[1], len(pend), _stream())
 
     def _join_side(self):
+        if self.single_stream:
+            return
         record_py(torch.cuda.current_stream().wait_stream, self._side)
 
     # ------------------------------------------------------------------ input

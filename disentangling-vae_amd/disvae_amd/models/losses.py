@@ -139,6 +139,14 @@ class BaseLoss(abc.ABC):
         return t
 
     AUTO_PLAN_ELEMS = 256 * 3 * 64 * 64
+    # one HIP stream instead of two below this many input elements per step (engine.single_stream); DVAE_STREAMS=1|2 forces
+    SINGLE_STREAM_ELEMS = int(os.environ.get("DVAE_SINGLE_STREAM_ELEMS", 0))
+
+    def _streams(self, model, data):
+        mode = os.environ.get("DVAE_STREAMS", "auto")
+        single = mode == "1" or (mode == "auto" and data.numel() <= self.SINGLE_STREAM_ELEMS)
+        model.engine.single_stream = bool(single) and self._world()[0] == 1
+        return model.engine.single_stream
 
     def _replay_mode(self, is_train, data):
         if not (is_train and self._world()[0] == 1):
@@ -151,7 +159,8 @@ class BaseLoss(abc.ABC):
         """Everything a recorded launch freezes: buffers (allocation generation), arenas, the
         batch pointer, the stream, and the few Python-side switches passed as scalars."""
         return (id(model), data.shape, data.data_ptr(), injected, _stream(), model.arena.flat.data_ptr(),
-                model.arena.grad.data_ptr(), _lib.ALLOC_GEN[0], self.rec_dist, getattr(self, "is_mss", None))
+                model.arena.grad.data_ptr(), _lib.ALLOC_GEN[0], self.rec_dist, getattr(self, "is_mss", None),
+                model.engine.single_stream)
 
     @abc.abstractmethod
     def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):
@@ -353,6 +362,7 @@ class _SingleOptimizerLoss(BaseLoss):
         sc = self.scratch(data.device)
         sc.set_coef(INV_B=1.0 / (B * world), **self._coefs(is_train))
         data = data.contiguous()
+        self._streams(model, data)
         if self.KIND == _lib.LOSS_BTCVAE:
             self._check_latent_dim(D)
             sc.set_log_w(B * self._est_world()[0], self.n_data)
@@ -678,6 +688,7 @@ class FactorKLoss(BaseLoss):
         anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
         sc.set_coef(INV_B=1.0 / Bhg, ANNEAL=anneal, BETA=self.gamma)
         data = data.contiguous()
+        self._streams(model, data)
         if noise is not None:
             eps1, eps2, perms = noise
         else:
