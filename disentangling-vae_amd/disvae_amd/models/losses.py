@@ -140,7 +140,7 @@ class BaseLoss(abc.ABC):
 
     AUTO_PLAN_ELEMS = 256 * 3 * 64 * 64
     # one HIP stream instead of two below this many input elements per step (engine.single_stream); DVAE_STREAMS=1|2 forces
-    SINGLE_STREAM_ELEMS = int(os.environ.get("DVAE_SINGLE_STREAM_ELEMS", 0))
+    SINGLE_STREAM_ELEMS = int(os.environ.get("DVAE_SINGLE_STREAM_ELEMS", 64 * 3 * 64 * 64))   # measured: profiles/r02_run10_streams.txt
 
     def _streams(self, model, data):
         mode = os.environ.get("DVAE_STREAMS", "auto")
