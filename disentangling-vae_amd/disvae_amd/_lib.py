@@ -50,8 +50,6 @@ SIGNATURES = {
     "dvae_linear_dgrad": [_p, _p, _p, _i, _p, _i, _i, _i, _p, _p],
     "dvae_linear_wgrad": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
     "dvae_linear_wgrad_grouped": [_p, _i, _p],
-    "dvae_mlp3_fwd": [_p] * 10 + [_i] * 8 + [_p],
-    "dvae_mlp3_dgrad": [_p] * 10 + [_i] * 6 + [_p],
     "dvae_reparam_kl_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "dvae_recon_loss": [_p, _p, _l, _i, _p, _p, _p, _i, _p],

@@ -105,7 +105,6 @@ class ParamArena:
 
 
 _CONV_WGRAD_MAIN = os.environ.get("DVAE_CONV_WGRAD_MAIN", "0") == "1"
-_MLP3 = os.environ.get("DVAE_MLP3", "1") != "0"     # A/B: 0 = one launch per fully-connected layer (k_fc32) instead of the 3-layer chains
 # 1 = conv weight gradients leave their partial sums and ONE grouped launch reduces all layers at the end of the backward
 # pass.  Measured (profiles/r02_run6_ab.txt): 8 reduce launches fewer but +1.5 % step time at B=1024 -- the per-layer
 # reductions hide in the side stream, the grouped one (137 MB of partials, ~37 us) sits on the critical path -> default 0
@@ -321,13 +320,6 @@ class VAEEngine:
                 call("dvae_conv4s2_fwd", ptr(src), src_layout, ptr(self.p("encoder.%s.weight" % name)),
                      ptr(self.p("encoder.%s.bias" % name)), ptr(dst), dst_layout, B, cin, h, h, HID, ACT_RELU, s)
             src, src_layout, cin, h = act, NHWC, HID, h // 2
-        if _MLP3:      # lin1 -> lin2 -> mu_logvar_gen (encoders.py:81-86) in one launch
-            call("dvae_mlp3_fwd", ptr(buf.a_flat), ptr(self.p("encoder.lin1.weight")), ptr(self.p("encoder.lin1.bias")),
-                 ptr(self.p("encoder.lin2.weight")), ptr(self.p("encoder.lin2.bias")),
-                 ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(self.p("encoder.mu_logvar_gen.bias")),
-                 ptr(buf.h1), ptr(buf.h2), ptr(buf.ml), B, HID * 16, HIDDEN_DIM, HIDDEN_DIM, 2 * self.latent_dim,
-                 ACT_RELU, ACT_RELU, ACT_NONE, s)
-            return
         call("dvae_linear_fwd", ptr(buf.a_flat), ptr(self.p("encoder.lin1.weight")), ptr(self.p("encoder.lin1.bias")),
              ptr(buf.h1), B, HID * 16, HIDDEN_DIM, ACT_RELU, ws, s)
         call("dvae_linear_fwd", ptr(buf.h1), ptr(self.p("encoder.lin2.weight")), ptr(self.p("encoder.lin2.bias")),
@@ -348,18 +340,12 @@ class VAEEngine:
         ws = ptr(self._ws)
         B = z.shape[0] if n is None else n
         D = self.latent_dim
-        if _MLP3:      # lin1 -> lin2 -> lin3 (decoders.py:71-73) in one launch
-            call("dvae_mlp3_fwd", ptr(z), ptr(self.p("decoder.lin1.weight")), ptr(self.p("decoder.lin1.bias")),
-                 ptr(self.p("decoder.lin2.weight")), ptr(self.p("decoder.lin2.bias")),
-                 ptr(self.p("decoder.lin3.weight")), ptr(self.p("decoder.lin3.bias")),
-                 ptr(buf.d1), ptr(buf.d2), ptr(buf.d3), B, D, HIDDEN_DIM, HIDDEN_DIM, HID * 16, ACT_RELU, ACT_RELU, ACT_RELU, s)
-        else:
-            call("dvae_linear_fwd", ptr(z), ptr(self.p("decoder.lin1.weight")), ptr(self.p("decoder.lin1.bias")),
-                 ptr(buf.d1), B, D, HIDDEN_DIM, ACT_RELU, ws, s)
-            call("dvae_linear_fwd", ptr(buf.d1), ptr(self.p("decoder.lin2.weight")), ptr(self.p("decoder.lin2.bias")),
-                 ptr(buf.d2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, ws, s)
-            call("dvae_linear_fwd", ptr(buf.d2), ptr(self.p("decoder.lin3.weight")), ptr(self.p("decoder.lin3.bias")),
-                 ptr(buf.d3), B, HIDDEN_DIM, HID * 16, ACT_RELU, ws, s)
+        call("dvae_linear_fwd", ptr(z), ptr(self.p("decoder.lin1.weight")), ptr(self.p("decoder.lin1.bias")),
+             ptr(buf.d1), B, D, HIDDEN_DIM, ACT_RELU, ws, s)
+        call("dvae_linear_fwd", ptr(buf.d1), ptr(self.p("decoder.lin2.weight")), ptr(self.p("decoder.lin2.bias")),
+             ptr(buf.d2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, ws, s)
+        call("dvae_linear_fwd", ptr(buf.d2), ptr(self.p("decoder.lin3.weight")), ptr(self.p("decoder.lin3.bias")),
+             ptr(buf.d3), B, HIDDEN_DIM, HID * 16, ACT_RELU, ws, s)
         # lin3's output [B, 32*4*4] in (c,h,w) order IS the NCHW 4x4x32 input of the first convT
         # (decoders.py:74): read as such, no relayout pass
         src, src_layout, h = buf.d3, NCHW, 4
@@ -431,17 +417,12 @@ class VAEEngine:
                 queued, pending = pending, []
         for w_ in queued:
             self._conv_wgrad(*w_, fork=False)
-        if _MLP3:      # the three input-gradient GEMMs of lin3, lin2, lin1 (+ ReLU' of d2, d1) in one launch
-            call("dvae_mlp3_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(self.p("decoder.lin2.weight")),
-                 ptr(self.p("decoder.lin1.weight")), ptr(buf.d2), ptr(buf.d1), None, ptr(buf.gd2), ptr(buf.gd1), ptr(buf.dz),
-                 B, D, HIDDEN_DIM, HIDDEN_DIM, HID * 16, ACT_RELU, s)
-        else:
-            call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
-                 B, HIDDEN_DIM, HID * 16, ws, s)
-            call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
-                 B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
-            call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
-                 B, D, HIDDEN_DIM, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
+             B, HIDDEN_DIM, HID * 16, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
+             B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
+             B, D, HIDDEN_DIM, ws, s)
         # small conv layers + the three FC weight gradients: one fork, then they co-run with whatever follows
         self.fork_side()
         for wargs in deferred:
@@ -465,17 +446,12 @@ class VAEEngine:
         ws = ptr(self._ws)
         self._reduce_pending = [p_ for p_ in self._reduce_pending if p_[3] == B]     # the decoder's, if it deferred them
         self._defer_reduce = self.is64 and _DEFER_REDUCE
-        if _MLP3:      # mu_logvar_gen, lin2, lin1 input gradients (+ ReLU' of h2, h1, the conv stack's output) in one launch
-            call("dvae_mlp3_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(self.p("encoder.lin2.weight")),
-                 ptr(self.p("encoder.lin1.weight")), ptr(buf.h2), ptr(buf.h1), ptr(buf.a_flat), ptr(buf.gh2), ptr(buf.gh1),
-                 ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, HIDDEN_DIM, 2 * self.latent_dim, ACT_RELU, s)
-        else:
-            call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
-                 ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
-            call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
-                 B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
-            call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
-                 ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
+             ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
+             B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
+             ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, ws, s)
         # weight gradients wait for the next fork (they only have to be done by the end of the backward pass): the
         # encoder's three FC layers + the decoder's three when decode_backward deferred them = one grouped launch
         pend, self._fc_pending = [p_ for p_ in self._fc_pending if p_[4] == B], []

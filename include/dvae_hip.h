@@ -139,22 +139,6 @@ int dvae_linear_dgrad(const float* dy, const float* w, const float* x_act, int a
 int dvae_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N,
                       float* ws, void* stream);
 
-/* Three chained nn.Linear layers in ONE launch (encoders.py:81-86: lin1 -> lin2 -> mu_logvar_gen; decoders.py:71-73:
- * lin1 -> lin2 -> lin3): y1 = act1(x w1^T + b1) [M,N1], y2 = act2(y1 w2^T + b2) [M,N2], y3 = act3(y2 w3^T + b3) [M,N3];
- * w1[N1,K0], w2[N2,N1], w3[N3,N2] as in the state_dict; every y is written (the backward pass needs them).  A workgroup
- * takes 16 rows through all three layers (activations in LDS, weights streamed from L2 into the MFMA operand).
- * Limits: K0, N2, N3 <= 512, N1 <= 256.  y1 / y2 may be NULL.                                                     */
-int dvae_mlp3_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
-                  const float* b3, float* y1, float* y2, float* y3, int M, int K0, int N1, int N2, int N3, int act1,
-                  int act2, int act3, void* stream);
-/* Input-gradient chain of the same three layers (training.py:157): g2 = (dy w3) * act'(a2), g1 = (g2 w2) * act'(a1),
- * dx = (g1 w1) * act'(a0), where a2[M,N2], a1[M,N1], a0[M,K0] are the forward activations ENTERING layers 3, 2, 1 (NULL: no
- * mask) and mask_act the activation whose derivative they gate (relu / leaky 0.2).  g2, g1 are written too (weight
- * gradients).  Limits: K0, N1, N3 <= 512, N2 <= 256.                                                                */
-int dvae_mlp3_dgrad(const float* dy, const float* w3, const float* w2, const float* w1, const float* a2, const float* a1,
-                    const float* a0, float* g2, float* g1, float* dx, int M, int K0, int N1, int N2, int N3,
-                    int mask_act, void* stream);
-
 /* Grouped form of dvae_linear_wgrad: n <= DVAE_FCW_MAX independent problems (the weight gradients of the six
  * fully-connected layers of the VAE, encoders.py:63-67 / decoders.py:53-55 under training.py:157) in ONE launch of
  * ~400 short-lived workgroups instead of six chip-starving ones.  `descs` is a HOST array read during the call (not

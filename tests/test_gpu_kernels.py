@@ -499,49 +499,3 @@ def test_conv_wgrad_partial_plus_grouped_reduce_is_bit_identical(N):
     for q, (dw1, db1, dw2, db2) in enumerate(want):
         assert torch.equal(dw1, dw2), "dw of case %d" % q
         assert torch.equal(db1, db2), "db of case %d" % q
-
-
-@pytest.mark.parametrize("M", [1, 16, 37, 128, 1024])
-@pytest.mark.parametrize("dims", [(512, 256, 256, 20), (10, 256, 256, 512), (512, 256, 256, 32), (7, 33, 100, 36), (16, 256, 512, 512)])
-def test_mlp3_fwd_and_dgrad(M, dims):
-    """dvae_mlp3_fwd / dvae_mlp3_dgrad: three chained Linear(+ReLU) layers (encoders.py:81-86, decoders.py:71-73) and their
-    input-gradient chain in one launch each, vs fp64 torch; the encoder's (512,256,256,2D) and the decoder's (D,256,256,512)
-    shapes plus ragged ones."""
-    K0, N1, N2, N3 = dims
-    if M == 1024 and dims[0] == 7:
-        pytest.skip("ragged shape only at small M")
-    x = torch.relu(_rand(M, K0, seed=1))
-    ws = [_rand(N1, K0, seed=2, scale=1 / math.sqrt(K0)), _rand(N2, N1, seed=3, scale=1 / math.sqrt(N1)), _rand(N3, N2, seed=4, scale=1 / math.sqrt(N2))]
-    bs = [_rand(N1, seed=5, scale=0.1), _rand(N2, seed=6, scale=0.1), _rand(N3, seed=7, scale=0.1)]
-    acts = (_lib.ACT_RELU, _lib.ACT_RELU, _lib.ACT_NONE)
-    xd = dev(x)
-    wd, bd = [dev(w) for w in ws], [dev(b) for b in bs]
-    y1, y2, y3 = torch.full((M, N1), 7.0, device=DEV), torch.full((M, N2), 7.0, device=DEV), torch.full((M, N3), 7.0, device=DEV)
-    call("dvae_mlp3_fwd", ptr(xd), ptr(wd[0]), ptr(bd[0]), ptr(wd[1]), ptr(bd[1]), ptr(wd[2]), ptr(bd[2]), ptr(y1), ptr(y2), ptr(y3),
-         M, K0, N1, N2, N3, acts[0], acts[1], acts[2], stream())
-    xr = x.double().requires_grad_(True)
-    h1 = torch.relu(F.linear(xr, ws[0].double(), bs[0].double()))
-    h2 = torch.relu(F.linear(h1, ws[1].double(), bs[1].double()))
-    h3 = F.linear(h2, ws[2].double(), bs[2].double())
-    tag = "mlp3 M=%d %s " % (M, dims)
-    check(y1, h1, rtol=1e-5, atol_rel=2e-6, what=tag + "y1")
-    check(y2, h2, rtol=1e-5, atol_rel=2e-6, what=tag + "y2")
-    check(y3, h3, rtol=1e-5, atol_rel=2e-6, what=tag + "y3")
-    # the same three layers one by one (existing kernels): agreement to rounding
-    dy = _rand(M, N3, seed=8)
-    g2r, g1r = torch.autograd.grad(h3, (h2, h1), dy.double(), retain_graph=True)
-    (dxr,) = torch.autograd.grad(h3, xr, dy.double())
-    g2, g1, dx = torch.full((M, N2), 7.0, device=DEV), torch.full((M, N1), 7.0, device=DEV), torch.full((M, K0), 7.0, device=DEV)
-    # masks: a2 = y2 (enters layer 3), a1 = y1, a0 = x (ReLU output of the layer before)
-    call("dvae_mlp3_dgrad", ptr(dev(dy)), ptr(wd[2]), ptr(wd[1]), ptr(wd[0]), ptr(y2), ptr(y1), ptr(xd), ptr(g2), ptr(g1), ptr(dx),
-         M, K0, N1, N2, N3, _lib.ACT_RELU, stream())
-    # torch's g2r / g1r are gradients w.r.t. the POST-activation h2 / h1; the kernels return them gated by ReLU' (= gradients
-    # w.r.t. the pre-activations, what the weight gradients consume)
-    check(g2, g2r * (h2 > 0), rtol=1e-5, atol_rel=2e-6, what=tag + "g2")
-    check(g1, g1r * (h1 > 0), rtol=1e-5, atol_rel=2e-6, what=tag + "g1")
-    check(dx, dxr * (x.double() > 0), rtol=1e-5, atol_rel=2e-6, what=tag + "dx")
-    # no mask on the last stage (decoder lin1: its input z has no activation)
-    dx2 = torch.empty(M, K0, device=DEV)
-    call("dvae_mlp3_dgrad", ptr(dev(dy)), ptr(wd[2]), ptr(wd[1]), ptr(wd[0]), ptr(y2), ptr(y1), None, None, None, ptr(dx2),
-         M, K0, N1, N2, N3, _lib.ACT_RELU, stream())
-    check(dx2, dxr, rtol=1e-5, atol_rel=2e-6, what=tag + "dx (no input mask)")
