@@ -105,6 +105,10 @@ class ParamArena:
 
 
 _CONV_WGRAD_MAIN = os.environ.get("DVAE_CONV_WGRAD_MAIN", "0") == "1"
+# which encoder conv weight gradients the MAIN stream computes itself at the very end of the backward pass (after conv1's),
+# instead of leaving them in the side stream's queue: the side stream is the tail of the iteration (timeline:
+# profiles/r02_run9_timeline.md), the main stream is idle from the end of conv1's weight gradient to the join
+_TAIL_MAIN = [n_ for n_ in os.environ.get("DVAE_TAIL_MAIN", "conv3").split(",") if n_]
 # 1 = conv weight gradients leave their partial sums and ONE grouped launch reduces all layers at the end of the backward
 # pass.  Measured (profiles/r02_run6_ab.txt): 8 reduce launches fewer but +1.5 % step time at B=1024 -- the per-layer
 # reductions hide in the side stream, the grouped one (137 MB of partials, ~37 us) sits on the critical path -> default 0
@@ -463,6 +467,7 @@ class VAEEngine:
               + [(buf.h2, buf.dml, self.g("encoder.mu_logvar_gen.weight"), self.g("encoder.mu_logvar_gen.bias"),
                   B, HIDDEN_DIM, 2 * self.latent_dim)])
         deferred = [lambda fc=fc: self._side_wgrad_grouped(fc)]
+        tail_main = []                      # weight gradients the main stream computes after conv1's (load balance of the tail)
         last = len(self.enc_names) - 1
         for k in range(last, -1, -1):
             name = self.enc_names[k]
@@ -491,6 +496,10 @@ class VAEEngine:
                          ptr(self.g("encoder.%s.bias" % name)), B, cin, h_in, h_in, HID, ptr(self._ws), s)
                 else:
                     self._conv_wgrad(*wargs, fork=False, main=True)
+                for w_ in tail_main:
+                    self._conv_wgrad(*w_, fork=False, main=True)
+            elif name in _TAIL_MAIN and self.is64 and not self.single_stream:
+                tail_main.append(wargs)
             elif big:
                 self.fork_side()
                 side, deferred = deferred + [lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False)], []

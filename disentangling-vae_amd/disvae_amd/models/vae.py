@@ -144,7 +144,7 @@ class VAE(nn.Module):
             self._engine = VAEEngine(self.img_size, self.latent_dim, self._arena)
         return self._engine
 
-    FLAT_CHUNK = 8192
+    FLAT_CHUNK = int(__import__("os").environ.get("DVAE_FLAT_CHUNK", 8192))
 
     def _arena_chunks(self, grad=False):
         buf = self._arena.grad if grad else self._arena.flat
