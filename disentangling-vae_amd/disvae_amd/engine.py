@@ -108,7 +108,7 @@ _CONV_WGRAD_MAIN = os.environ.get("DVAE_CONV_WGRAD_MAIN", "0") == "1"
 # which encoder conv weight gradients the MAIN stream computes itself at the very end of the backward pass (after conv1's),
 # instead of leaving them in the side stream's queue: the side stream is the tail of the iteration (timeline:
 # profiles/r02_run9_timeline.md), the main stream is idle from the end of conv1's weight gradient to the join
-_TAIL_MAIN = [n_ for n_ in os.environ.get("DVAE_TAIL_MAIN", "conv3").split(",") if n_]
+_TAIL_MAIN = [n_ for n_ in os.environ.get("DVAE_TAIL_MAIN", "conv3,conv_64").split(",") if n_]
 # 1 = conv weight gradients leave their partial sums and ONE grouped launch reduces all layers at the end of the backward
 # pass.  Measured (profiles/r02_run6_ab.txt): 8 reduce launches fewer but +1.5 % step time at B=1024 -- the per-layer
 # reductions hide in the side stream, the grouped one (137 MB of partials, ~37 us) sits on the critical path -> default 0

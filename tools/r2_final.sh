@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 2, final visit: the SHIPPED (non-debug) library -- full parity suite, smoke, bench lines of all four BASELINE configs,
+# rocprofv3 kernel stats + timeline, PMC passes.  Everything goes to gpurun_out/ (copied to profiles/r02_final_*).
+set -u
+export TMPDIR=/tmp
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$REPO"; mkdir -p gpurun_out
+echo "== pytest -m gpu"
+DVAE_PARITY_STATS=gpurun_out/parity_stats.json timeout 2400 python -m pytest tests -m gpu -q --timeout=900 --no-header -x > gpurun_out/pytest.log 2>&1
+echo "pytest exit: $?" | tee -a gpurun_out/pytest.log
+grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/pytest.log | head -20
+grep -E "^E  " gpurun_out/pytest.log | cut -c1-300 | head -20
+echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -n 2 | cut -c1-300
+echo "== bench (default)"
+timeout 900 python bench.py 2>&1 | tail -n 1 > gpurun_out/bench_default.json; cut -c1-400 gpurun_out/bench_default.json; echo
+for c in factor_celeba btcvae_dsprites factor_dsprites; do
+  timeout 600 python bench.py --config $c --no-roofline 2>&1 | tail -n 1 > gpurun_out/bench_$c.json; python -c "import json; d=json.load(open('gpurun_out/bench_$c.json')); print('$c', d['value'], d['ms_per_step'], d['parity_check']['ok'], d.get('cpu_baseline',{}).get('value'))"
+done
+echo "== batch sweep"
+for b in 64 128 256 512 2048; do timeout 300 python bench.py --batch $b --steps 100 --warmup 20 --no-cpu-baseline --no-roofline --no-parity-check 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('btcvae 3ch B=$b', d['value'], d['ms_per_step'])"; done | tee gpurun_out/batch_sweep.txt
+echo "== rocprofv3 kernel stats + timeline"
+rm -rf gpurun_out/prof
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o prof -- python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-parity-check --no-roofline > "$REPO/gpurun_out/prof.log" 2>&1)
+python tools/prof_summary.py gpurun_out/prof/prof_results.db 13 > gpurun_out/prof_summary.md; head -20 gpurun_out/prof_summary.md
+python tools/timeline.py gpurun_out/prof/prof_results.db > gpurun_out/timeline.txt 2>&1; tail -n 2 gpurun_out/timeline.txt
+echo "== PMC passes"
+bash tools/pmc_collect.sh > gpurun_out/pmc.log 2>&1; grep -E "k_up32ws<16|k_wgrad32ws<16|k_down32ws<16" gpurun_out/pmc_summary.md | awk -F'|' '{print $2, $(NF-3), $(NF-2), $(NF-1)}'
