@@ -29,6 +29,7 @@ pytestmark = pytest.mark.gpu
 from gpu_util import *  # noqa
 from gpu_util import _lib, record_stat  # noqa
 from oracle import disvae_oracle as O
+from oracle.gate_match import engine_gates, discriminator_gates
 from disvae_amd.models.vae import init_specific_model
 from disvae_amd.models.losses import get_loss_f
 
@@ -47,27 +48,6 @@ def _rand(*shape, seed=0, scale=1.0):
 
 def check_grad(got, ref, what):
     check(got, ref, rtol=G_RTOL, atol_rel=G_ATOL, what=what)
-
-
-def engine_gates(model, B, splits=None, dec_rows=None):
-    """ReLU on/off pattern of the native forward that just ran (engine workspace), reference layout (NCHW).
-    splits: row ranges in the oracle's call order (factor: data1 then data2); dec_rows: rows the decoder ran on."""
-    eng = model.engine
-    buf = eng.buffers(B)
-    splits = splits or [slice(0, B)]
-    dec = dec_rows or slice(0, B)
-    g = {}
-    last = len(eng.enc_names) - 1
-    for k, (n, act) in enumerate(zip(eng.enc_names, buf.enc_act)):
-        t = buf.a_flat.view(B, 32, 4, 4) if k == last else act.permute(0, 3, 1, 2)
-        g["encoder." + n] = [(t[sl] > 0).cpu() for sl in splits]
-    g["encoder.lin1"] = [(buf.h1[sl] > 0).cpu() for sl in splits]
-    g["encoder.lin2"] = [(buf.h2[sl] > 0).cpu() for sl in splits]
-    for n, t in (("lin1", buf.d1), ("lin2", buf.d2), ("lin3", buf.d3)):
-        g["decoder." + n] = [(t[dec] > 0).cpu()]
-    for n, act in zip(eng.dec_names, buf.dec_act):
-        g["decoder." + n] = [(act.permute(0, 3, 1, 2)[dec] > 0).cpu()]
-    return g
 
 
 def check_gate_pattern(gates, log, what):
@@ -164,9 +144,7 @@ def test_factor_step_at_baseline_batch(name, img, B, n_data, lr_disc):
     # the encoder ran on both halves (data1 then data2 in the oracle's call order), the decoder on data1, the
     # discriminator on [z1; z_perm]
     gates = engine_gates(model, B, splits=[slice(0, Bh), slice(Bh, 2 * Bh)], dec_rows=slice(0, Bh))
-    hs = loss_f.discriminator._acts[2 * Bh]["h"]
-    for i in range(5):
-        gates["disc.lin%d" % (i + 1)] = [(hs[i][:Bh] > 0).cpu(), (hs[i][Bh:] > 0).cpu()]
+    gates.update(discriminator_gates(loss_f.discriminator, 2 * Bh, Bh))
     c64 = lambda p, rg: O.clone_params(p, dtype=torch.float64, requires_grad=rg)
     log = []
     with O.gates(None, record=log):
