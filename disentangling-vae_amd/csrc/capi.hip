@@ -25,13 +25,7 @@ static int check_layout(int l) { return l == DVAE_NCHW || l == DVAE_NHWC; }
 // big[N,Cb,2Hs,2Ws] -> small[N,Cs,Hs,Ws]
 static int run_down(const ConvArgs& a, hipStream_t s) {
   if (!use_generic_only()) {
-    int r = 1;
-    static const bool no_ws2 = env_off("DVAE_DOWN_WS2");      // debug builds: DVAE_DOWN_WS2=0 -> k_down32ws (A/B)
-    if (!no_ws2) {
-      r = launch_down_mfma32_ws2(a, s);
-      if (r <= 0) return r;
-    }
-    r = launch_down_mfma32(a, s);
+    int r = launch_down_mfma32(a, s);
     if (r <= 0) return r;
     r = launch_down_thin(a, s);
     if (r <= 0) return r;

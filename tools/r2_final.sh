@@ -14,7 +14,7 @@ echo "== smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -n 2 
 echo "== bench (default)"
 timeout 900 python bench.py 2>&1 | tail -n 1 > gpurun_out/bench_default.json; cut -c1-400 gpurun_out/bench_default.json; echo
 for c in factor_celeba btcvae_dsprites factor_dsprites; do
-  timeout 600 python bench.py --config $c --no-roofline 2>&1 | tail -n 1 > gpurun_out/bench_$c.json; python -c "import json; d=json.load(open('gpurun_out/bench_$c.json')); print('$c', d['value'], d['ms_per_step'], d['parity_check']['ok'], d.get('cpu_baseline',{}).get('value'))"
+  timeout 600 python bench.py --config $c --no-roofline --no-cpu-baseline 2>&1 | tail -n 1 > gpurun_out/bench_$c.json; python -c "import json; d=json.load(open('gpurun_out/bench_$c.json')); print('$c', d['value'], d['ms_per_step'], d['parity_check']['ok'])"
 done
 echo "== batch sweep"
 for b in 64 128 256 512 2048; do timeout 300 python bench.py --batch $b --steps 100 --warmup 20 --no-cpu-baseline --no-roofline --no-parity-check 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('btcvae 3ch B=$b', d['value'], d['ms_per_step'])"; done | tee gpurun_out/batch_sweep.txt
