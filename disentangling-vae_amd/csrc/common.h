@@ -111,8 +111,7 @@ int launch_wgrad_mfma32_ws(const float* big, const float* small, float* dw, floa
                            float* ws, hipStream_t s, bool partial_only = false);    // wave-specialised, transposed LDS tiles (conv_wgrad_ws.hip): Hs in {8,16}
 int launch_wgrad_reduce_grouped(const dvae_conv_wgrad_desc* d, int n, hipStream_t s);
 int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_big, int nblk, hipStream_t s);
-int launch_up_mfma32_ws(const ConvArgs& a, hipStream_t s);
-int launch_down_mfma32_ws2(const ConvArgs& a, hipStream_t s);   // weights in registers, output through LDS (conv_down_ws2.hip): Hs in {8,16}      // wave-specialised (conv_up_ws.hip): Hs in {8,16}, NHWC
+int launch_up_mfma32_ws(const ConvArgs& a, hipStream_t s);      // wave-specialised (conv_up_ws.hip): Hs in {8,16}, NHWC
 #ifdef DVAE_DEBUG_SWITCHES
 int launch_up_mfma32_r2(const ConvArgs& a, hipStream_t s);   // experimental (conv_up_r2.hip), DVAE_UP_R2=1
 #endif

@@ -5,6 +5,10 @@ set -u
 export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"; mkdir -p gpurun_out
+echo "== weight-gradient kernels first (fail fast: nothing below is worth measuring if these are wrong)"
+timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout=300 --no-header -x -k "wgrad or reduce" > gpurun_out/pytest_wgrad.log 2>&1
+rc=$?; tail -n 3 gpurun_out/pytest_wgrad.log
+if [ $rc -ne 0 ]; then grep -E "^E  " gpurun_out/pytest_wgrad.log | cut -c1-300 | head -20; echo "ABORT: weight-gradient parity failed"; exit 1; fi
 echo "== pytest -m gpu"
 DVAE_PARITY_STATS=gpurun_out/parity_stats.json timeout 2400 python -m pytest tests -m gpu -q --timeout=900 --no-header -x > gpurun_out/pytest.log 2>&1
 echo "pytest exit: $?" | tee -a gpurun_out/pytest.log
@@ -17,7 +21,7 @@ for c in factor_celeba btcvae_dsprites factor_dsprites; do
   timeout 600 python bench.py --config $c --no-roofline --no-cpu-baseline 2>&1 | tail -n 1 > gpurun_out/bench_$c.json; python -c "import json; d=json.load(open('gpurun_out/bench_$c.json')); print('$c', d['value'], d['ms_per_step'], d['parity_check']['ok'])"
 done
 echo "== batch sweep"
-for b in 64 128 256 512 2048; do timeout 300 python bench.py --batch $b --steps 100 --warmup 20 --no-cpu-baseline --no-roofline --no-parity-check 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('btcvae 3ch B=$b', d['value'], d['ms_per_step'])"; done | tee gpurun_out/batch_sweep.txt
+for b in 64 128 256 512; do timeout 300 python bench.py --batch $b --steps 100 --warmup 20 --no-cpu-baseline --no-roofline --no-parity-check 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('btcvae 3ch B=$b', d['value'], d['ms_per_step'])"; done | tee gpurun_out/batch_sweep.txt
 echo "== rocprofv3 kernel stats + timeline"
 rm -rf gpurun_out/prof
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o prof -- python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-parity-check --no-roofline > "$REPO/gpurun_out/prof.log" 2>&1)
