@@ -110,8 +110,8 @@ def kernel_rooflines(B, device):
     """HIP-event timing (events on torch's current stream = the stream the launches go to) of the three
     32 <-> 32 channel MFMA conv families at their largest geometry (32x32 <-> 16x16, 8.59 GFLOP per 1024 images:
     2 x 4.19 M MACs per image), launched through the C-ABI.  Per training step each family runs twice
-    at this geometry: k_up32<16> = convT2 fwd + conv2 dgrad (masked), k_down32ws<16> = conv2 fwd + convT2 dgrad
-    (masked), k_wgrad32<16> = conv2 wgrad + convT2 wgrad."""
+    at this geometry: k_up32ws<16> = convT2 fwd + conv2 dgrad (masked), k_down32ws<16> = conv2 fwd + convT2 dgrad
+    (masked), k_wgrad32ws<16> = conv2 wgrad + convT2 wgrad."""
     from disvae_amd import _lib
     from disvae_amd._lib import call, ptr
     f = lambda *s: torch.rand(*s, device=device)
@@ -124,19 +124,19 @@ def kernel_rooflines(B, device):
     s = torch.cuda.current_stream().cuda_stream
     NH, RELU = _lib.NHWC, _lib.ACT_RELU
     fams = {
-        "k_up32<16>": [("convT2 fwd", lambda: call("dvae_convT4s2_fwd", ptr(small), NH, ptr(w), ptr(b), ptr(obig), NH, B, 32, 16, 16, 32, RELU, s)),
+        "k_up32ws<16>": [("convT2 fwd", lambda: call("dvae_convT4s2_fwd", ptr(small), NH, ptr(w), ptr(b), ptr(obig), NH, B, 32, 16, 16, 32, RELU, s)),
                        ("conv2 dgrad (masked)", lambda: call("dvae_conv4s2_dgrad", ptr(small), NH, ptr(w), ptr(big), ptr(obig), NH, B, 32, 32, 32, 32, s))],
         "k_down32ws<16>": [("conv2 fwd", lambda: call("dvae_conv4s2_fwd", ptr(big), NH, ptr(w), ptr(b), ptr(osmall), NH, B, 32, 32, 32, 32, RELU, s)),
                            ("convT2 dgrad (masked)", lambda: call("dvae_convT4s2_dgrad", ptr(big), NH, ptr(w), ptr(small), ptr(osmall), NH, B, 32, 16, 16, 32, s))],
-        "k_wgrad32<16>": [("conv2 wgrad (+reduce)", lambda: call("dvae_conv4s2_wgrad", ptr(big), NH, ptr(small), NH, ptr(dw), ptr(db), B, 32, 32, 32, 32, ptr(ws), s))],
+        "k_wgrad32ws<16>": [("conv2 wgrad (+reduce)", lambda: call("dvae_conv4s2_wgrad", ptr(big), NH, ptr(small), NH, ptr(dw), ptr(db), B, 32, 32, 32, 32, ptr(ws), s))],
     }
     flops = 2.0 * 4194304 * B              # algorithmic FLOPs per launch: 2 x MACs/img x images per launch
     # algorithmic HBM bytes per launch: big tensor (B x 32x32x32 fp32) + small tensor (B x 16x16x32) moved once
     # (+ the mask read of the masked variants)
     big_b, small_b = 32 * 32 * 32 * 4.0, 16 * 16 * 32 * 4.0          # bytes per image
-    algo_bytes = {"k_up32<16>": (big_b + small_b) * B + big_b * B / 2,         # avg of the plain and the masked launch
+    algo_bytes = {"k_up32ws<16>": (big_b + small_b) * B + big_b * B / 2,         # avg of the plain and the masked launch
                   "k_down32ws<16>": (big_b + small_b) * B + small_b * B / 2,
-                  "k_wgrad32<16>": (big_b + small_b) * B}
+                  "k_wgrad32ws<16>": (big_b + small_b) * B}
     out = []
     for name, launches in fams.items():
         ms = [(_time_launch(fn), what) for what, fn in launches]
