@@ -11,33 +11,46 @@ namespace dvae {
 // stride between per-workgroup partial buffers: NOT a multiple of 64 KB, so that the reduce kernel's
 // loads of one output across all partials spread over HBM channels instead of hammering one
 #define WG_STRIDE (16384 + 320)
-#define WG_REDUCE_BLOCKS (256 + 2)         // workgroups of the 32-channel reduction (the last two: bias)
+#define WG_REDUCE_BLOCKS (256 + 4)         // workgroups of the 32-channel reduction (the last four: bias, 8 channels each)
 #define WT_MAX_BLOCKS 512
-#define WT_REDUCE_BLOCKS(C) (((16 * (C) + 31) / 32) * 64 + 2)   // NT x 1024 workspace positions, 16 per workgroup (+ 2: bias)
+// thin layers: the whole partial buffer (NT x 1024 weight slots + 32 + NT x 32 bias slots), 16 slots per workgroup
+#define WT_REDUCE_BLOCKS(C) ((((16 * (C) + 31) / 32) * (1024 + 32) + 32) / 16)
 
-// bias gradient: 2 workgroups x (16 channels x 16 partial-groups)
+// bias gradient: 4 workgroups x (8 channels x 32 partial-groups); every lane has its 8 partials (x 4 slots when the
+// bias comes from the big side) in flight at once
 __device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws, float* __restrict__ db,
                                                     int bias_from_big, int nblk, int blk) {
-  __shared__ float red[16][16];
-  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
-  const int c = blk * 16 + o;
-  const float* wsb = ws + 16384;
-  float pv[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int g = gq; g < nblk; g += 64) {
+  __shared__ float redb[32][8];
+  const int o = threadIdx.x & 7, gq = threadIdx.x >> 3;
+  const int c = blk * 8 + o;
+  const float* wsb = ws + 16384 + c;
+  float v[8];
+  if (bias_from_big) {
+    float a[8][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int gg = g + 16 * u;
-      const float* q = wsb + (long)(gg < nblk ? gg : 0) * WG_STRIDE;
-      float v = bias_from_big ? (q[32 + c] + q[64 + c]) + (q[96 + c] + q[128 + c]) : q[c];
-      pv[u] += gg < nblk ? v : 0.f;
+    for (int u = 0; u < 8; ++u) {                    // partial gq + 32 u, clamped (zeroed below)
+      const int g = gq + 32 * u;
+      const float* q = wsb + (long)(g < nblk ? g : nblk - 1) * WG_STRIDE;
+      a[u][0] = q[32]; a[u][1] = q[64]; a[u][2] = q[96]; a[u][3] = q[128];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int g = gq + 32 * u;
+      v[u] = wsb[(long)(g < nblk ? g : nblk - 1) * WG_STRIDE];
     }
   }
-  red[gq][o] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (gq + 32 * u >= nblk) v[u] = 0.f;
+  redb[gq][o] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   __syncthreads();
-  if (gq == 0) {
+  if (threadIdx.x < 8) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][o];
+    for (int k = 0; k < 32; ++k) t += redb[k][o];
     db[c] = t;
   }
 }
@@ -47,19 +60,23 @@ __device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws
 // to L2 / HBM instead of two rounds of 4-byte loads.  Fixed summation order: tree over u per lane, then groups 0..15.
 __device__ __forceinline__ void wgrad32_reduce_body(int blk_x, const float* __restrict__ ws, float* __restrict__ dw,
                                                     float* __restrict__ db, int bias_from_big, int nblk) {
-  if (blk_x >= 256) {                                // the last two workgroups reduce the bias gradient
+  if (blk_x >= 256) {                                // the last four workgroups reduce the bias gradient
     if (db) wgrad32_bias_reduce(ws, db, bias_from_big, nblk, blk_x - 256);
     return;
   }
   __shared__ __attribute__((aligned(16))) float red[16][64];
   const int p = threadIdx.x & 15, gq = threadIdx.x >> 4;
-  const float* src = ws + (long)gq * WG_STRIDE + (blk_x * 16 + p) * 4;
+  const float* src = ws + (blk_x * 16 + p) * 4;
   f32x4 v[16];
+  // unconditional loads from a clamped partial index, zeroed afterwards: a branch per load would serialise them
 #pragma unroll
   for (int u = 0; u < 16; ++u) {                     // partial gq + 16 u  (nblk <= WG_MAX_BLOCKS = 256)
-    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (gq + 16 * u < nblk) v[u] = *reinterpret_cast<const f32x4*>(src + (long)(16 * u) * WG_STRIDE);
+    const int g = gq + 16 * u;
+    v[u] = *reinterpret_cast<const f32x4*>(src + (long)(g < nblk ? g : nblk - 1) * WG_STRIDE);
   }
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if (gq + 16 * u >= nblk) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int w = 1; w < 16; w *= 2)
 #pragma unroll
@@ -78,68 +95,31 @@ __device__ __forceinline__ void wgrad32_reduce_body(int blk_x, const float* __re
 }
 
 
-// bias gradient of the thin layers: (16 channels x 16 partial-groups) per workgroup
-template <int C>
-__device__ __forceinline__ void wgrad_thin_bias_reduce(const float* __restrict__ ws, float* __restrict__ db,
-                                                       int bias_from_big, int nblk, int blk) {
-  constexpr int NT = (16 * C + 31) / 32;
-  constexpr int STRIDE = NT * 1024 + 32 + NT * 32;
-  __shared__ float redb[16][16];
-  const int o = threadIdx.x & 15, gq = threadIdx.x >> 4;
-  const int c = blk * 16 + o;
-  const int nout = bias_from_big ? C : 32;
-  // slot [0,32) = sum of the small side per cs; slots 32.. = per (cb,tap) column sums of the big side, of which
-  // taps (kh,kw) in {1,2}x{1,2} cover every big pixel exactly once
-  const int cc = c < nout ? c : 0;
-  const int t5 = cc * 16 + 5, t6 = cc * 16 + 6, t9 = cc * 16 + 9, t10 = cc * 16 + 10;
-  float pv[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int g = gq; g < nblk; g += 64) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int gg = g + 16 * u;
-      const float* q = ws + (long)(gg < nblk ? gg : 0) * STRIDE + NT * 1024;
-      float v;
-      if (bias_from_big)
-        v = (q[32 + (t5 >> 5) * 32 + (t5 & 31)] + q[32 + (t6 >> 5) * 32 + (t6 & 31)]) +
-            (q[32 + (t9 >> 5) * 32 + (t9 & 31)] + q[32 + (t10 >> 5) * 32 + (t10 & 31)]);
-      else
-        v = q[cc];
-      pv[u] += gg < nblk ? v : 0.f;
-    }
-  }
-  redb[gq][o] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
-  __syncthreads();
-  if (gq == 0 && c < nout) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += redb[k][o];
-    db[c] = t;
-  }
-}
-
-// Workgroup = 4 workspace positions of 16 bytes (16 of the NT x 1024 [nt][cs][j] slots) x 64 partial-groups: all 8 loads of a
-// lane in flight at once (nblk <= WT_MAX_BLOCKS = 512), one round trip.  Fixed summation order: tree over u per lane, groups
-// in eights, then the eight sums.  Slots j >= 16 C - 32 nt are the zero columns that pad the last N-tile: not written.
+// Workgroup = 4 positions of 16 bytes (16 slots of the partial buffer: NT x 1024 weight slots [nt][cs][j], then 32 sums of the
+// small side per cs, then NT x 32 column sums of the big side) x 64 partial-groups: all 8 loads of a lane in flight at once
+// (nblk <= WT_MAX_BLOCKS = 512), one round trip.  Fixed summation order: tree over u per lane, groups in eights, then the
+// eight sums.  Weight slots j >= 16 C - 32 nt are the zero columns that pad the last N-tile: not written.
 template <int C>
 __device__ __forceinline__ void wgrad_thin_reduce_body(int blk_x, const float* __restrict__ ws, float* __restrict__ dw,
                                                        float* __restrict__ db, int bias_from_big, int nblk) {
   constexpr int NT = (16 * C + 31) / 32;
   constexpr int STRIDE = NT * 1024 + 32 + NT * 32;
-  constexpr int NB = NT * 64;                        // workgroups reducing dw; two more reduce db
-  if (blk_x >= NB) {
-    if (db) wgrad_thin_bias_reduce<C>(ws, db, bias_from_big, nblk, blk_x - NB);
-    return;
-  }
+  constexpr int QB = NT * 1024;                      // first bias slot
   __shared__ __attribute__((aligned(16))) float red[64][16];
   __shared__ float red2[8][16];
+  __shared__ float fin[16];
   const int p = threadIdx.x & 3, gq = threadIdx.x >> 2;
-  const float* src = ws + (long)gq * STRIDE + (blk_x * 4 + p) * 4;
+  const float* src = ws + (blk_x * 4 + p) * 4;
   f32x4 v[8];
+  // unconditional loads from a clamped partial index, zeroed afterwards: a branch per load would serialise them
 #pragma unroll
   for (int u = 0; u < 8; ++u) {                      // partial gq + 64 u
-    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (gq + 64 * u < nblk) v[u] = *reinterpret_cast<const f32x4*>(src + (long)(64 * u) * STRIDE);
+    const int g = gq + 64 * u;
+    v[u] = *reinterpret_cast<const f32x4*>(src + (long)(g < nblk ? g : nblk - 1) * STRIDE);
   }
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (gq + 64 * u >= nblk) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int w = 1; w < 8; w *= 2)
 #pragma unroll
@@ -154,15 +134,34 @@ __device__ __forceinline__ void wgrad_thin_reduce_body(int blk_x, const float* _
     red2[part][o] = t;
   }
   __syncthreads();
+  float t = 0.f;
+  const int o = threadIdx.x & 15;
   if (threadIdx.x < 16) {
-    const int o = threadIdx.x;
-    float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red2[k][o];
-    const int q = blk_x * 16 + o;                    // workspace slot [nt][cs][j]
-    const int nt = q >> 10, cs = (q >> 5) & 31, nidx = nt * 32 + (q & 31);   // nidx = cb * 16 + tap
-    if (nidx < 16 * C) dw[cs * 16 * C + nidx] = t;   // dw[cs][cb][tap]
   }
+  const int q0 = blk_x * 16;                         // first slot of this workgroup (uniform)
+  if (q0 < QB) {
+    if (threadIdx.x < 16) {
+      const int q = q0 + o;                          // weight slot [nt][cs][j]
+      const int nt = q >> 10, cs = (q >> 5) & 31, nidx = nt * 32 + (q & 31);   // nidx = cb * 16 + tap
+      if (nidx < 16 * C) dw[cs * 16 * C + nidx] = t; // dw[cs][cb][tap]
+    }
+    return;
+  }
+  if (!db) return;
+  const int k = (q0 - QB) >> 4;                      // 16-slot chunk of the bias region
+  if (!bias_from_big) {
+    // chunks 0, 1: sum of the small side per cs
+    if (k < 2 && threadIdx.x < 16) db[k * 16 + o] = t;
+    return;
+  }
+  // chunk 2 + cb holds the 16 (kh,kw) column sums of big-side channel cb, of which taps (kh,kw) in {1,2}x{1,2} = 5, 6, 9, 10
+  // cover every big pixel exactly once
+  if (k < 2 || k - 2 >= C) return;
+  if (threadIdx.x < 16) fin[o] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) db[k - 2] = (fin[5] + fin[6]) + (fin[9] + fin[10]);
 }
 
 

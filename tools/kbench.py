@@ -60,8 +60,21 @@ for C in (3,):
     report("convT3 fwd (up_thin+sigmoid)", timeit(lambda: call("dvae_convT4s2_fwd", ptr(a1), NHWC, ptr(w), ptr(bc), ptr(x), NCHW, B, 32, 32, 32, C, 3, s)), 2 * macs, nx + na)
     report("conv1 wgrad (wgrad_thin+reduce)", timeit(lambda: call("dvae_conv4s2_wgrad", ptr(x), NCHW, ptr(a1), NHWC, ptr(dw), ptr(db), B, C, 64, 64, 32, ptr(ws), s)), 2 * macs, nx + na)
     g = torch.empty_like(x)
-    coef = torch.full((8,), 1.0 / B, device=dev)
-    parts = torch.empty(512, device=dev)
+    coef = torch.full((32,), 1.0 / B, device=dev)
+    parts = torch.empty(2048, device=dev)      # DVAE_REC_NPART
+    tgt, rec = torch.rand_like(x), torch.empty_like(x)
+    report("convT3 fwd + likelihood (up_thin fused)", timeit(lambda: call("dvae_convT4s2_sigmoid_recon_fwd", ptr(a1), NHWC, ptr(w), ptr(bc), ptr(tgt), ptr(rec), ptr(g), 0, ptr(coef), ptr(parts), B, 32, 32, 32, C, s)), 2 * macs, 3 * nx + na)
+    dbc = torch.empty(C, device=dev)
+    report("convT3 wgrad (wgrad_thin+reduce)", timeit(lambda: call("dvae_convT4s2_wgrad", ptr(a1), NHWC, ptr(g), NCHW, ptr(dw), ptr(dbc), B, 32, 32, 32, C, ptr(ws), s)), 2 * macs, nx + na)
+    # the accumulation kernels alone, and the fixed-order reductions alone (one layer per launch)
+    report("conv1 wgrad, partial sums only", timeit(lambda: call("dvae_conv4s2_wgrad_partial", ptr(x), NCHW, ptr(a1), NHWC, B, C, 64, 64, 32, ptr(ws), s)), 2 * macs, nx + na)
+    d1 = _lib.conv_wgrad_descs([(ptr(ws), ptr(dw), ptr(db), B, C, 64, 64, 32, 0)])
+    report("conv1 wgrad, reduction only", timeit(lambda: call("dvae_conv_wgrad_reduce_grouped", d1[1], 1, s)), 0, 0)
+    big2, small2 = torch.rand(B, 32, 32, 32, device=dev), torch.rand(B, 16, 16, 32, device=dev)
+    dw2, db2 = torch.empty(32, 32, 4, 4, device=dev), torch.empty(32, device=dev)
+    report("conv2 wgrad, partial sums only", timeit(lambda: call("dvae_conv4s2_wgrad_partial", ptr(big2), NHWC, ptr(small2), NHWC, B, 32, 32, 32, 32, ptr(ws), s)), 2.0 * B * 256 * 32 * 512, big2.numel() * 4 + small2.numel() * 4)
+    d2 = _lib.conv_wgrad_descs([(ptr(ws), ptr(dw2), ptr(db2), B, 32, 32, 32, 32, 0)])
+    report("conv2 wgrad, reduction only", timeit(lambda: call("dvae_conv_wgrad_reduce_grouped", d2[1], 1, s)), 0, 0)
     report("recon_loss (bernoulli)", timeit(lambda: call("dvae_recon_loss", ptr(x), ptr(x), x.numel(), 0, ptr(coef), ptr(parts), ptr(g), 1, s)), 0, 3 * nx)
 for (M, K, N) in ((B, 512, 256), (B, 256, 256), (B, 256, 20), (B, 10, 256), (B, 256, 512), (B, 1000, 1000)):
     x = torch.rand(M, K, device=dev); w = torch.rand(N, K, device=dev); b = torch.zeros(N, device=dev)

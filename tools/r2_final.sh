@@ -29,3 +29,14 @@ python tools/prof_summary.py gpurun_out/prof/prof_results.db 13 > gpurun_out/pro
 python tools/timeline.py gpurun_out/prof/prof_results.db > gpurun_out/timeline.txt 2>&1; tail -n 2 gpurun_out/timeline.txt
 echo "== PMC passes"
 bash tools/pmc_collect.sh > gpurun_out/pmc.log 2>&1; grep -E "k_up32ws<16|k_wgrad32ws<16|k_down32ws<16" gpurun_out/pmc_summary.md | awk -F'|' '{print $2, $(NF-3), $(NF-2), $(NF-1)}'
+echo "== extras (records for the next round): every kernel alone at B = 1024 and B = 128; the B = 128 step as a timeline; factor kernel stats"
+timeout 200 python tools/kbench.py 1024 > gpurun_out/kbench_final.txt 2>&1; grep -E "thin|reduction|partial|likelihood" gpurun_out/kbench_final.txt
+timeout 120 python tools/kbench.py 128 > gpurun_out/kbench_b128.txt 2>&1; tail -n 3 gpurun_out/kbench_b128.txt
+rm -rf gpurun_out/prof128
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof128" -o prof -- python "$REPO/bench.py" --batch 128 --steps 30 --warmup 5 --no-cpu-baseline --no-parity-check --no-roofline > "$REPO/gpurun_out/prof128.log" 2>&1)
+python tools/timeline.py gpurun_out/prof128/prof_results.db > gpurun_out/timeline_b128.txt 2>&1; tail -n 1 gpurun_out/timeline_b128.txt
+python tools/prof_summary.py gpurun_out/prof128/prof_results.db 35 > gpurun_out/prof128_summary.md 2>&1
+rm -rf gpurun_out/prof_factor
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_factor" -o prof -- python "$REPO/bench.py" --config factor_celeba --steps 10 --warmup 3 --no-cpu-baseline --no-parity-check --no-roofline > "$REPO/gpurun_out/prof_factor.log" 2>&1)
+python tools/prof_summary.py gpurun_out/prof_factor/prof_results.db 13 > gpurun_out/prof_factor_summary.md 2>&1; head -n 8 gpurun_out/prof_factor_summary.md
+rm -rf gpurun_out/prof128/*.db.tmp
