@@ -229,14 +229,23 @@ __global__ __launch_bounds__(512) void k_down32v2(const float* __restrict__ big,
 // one unit of MFMA work of a compute wave of k_down32ws: 16 pixels x 32 channels, K = 512
 template <int HS>
 __device__ __forceinline__ void down_ws_mfma(f32x4v (&acc)[2][4], const float* bt, const float* wl, int sy_l, int sx,
-                                             int i16, int kq) {
+                                             int i16, int kq, int abl = 0) {
   using G = Geo<HS>;
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[nh][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
   f32x4 A0[2], A1[2], B00[2], B01[2], B10[2], B11[2];
+#ifdef DVAE_DEBUG_SWITCHES
+  if (abl & 16) {                        // timing ablation: no LDS operand reads (constant operands)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { A0[c] = f32x4{1.f, 2.f, 3.f, 4.f}; A1[c] = A0[c]; B00[c] = A0[c]; B01[c] = A0[c]; B10[c] = A0[c]; B11[c] = A0[c]; }
+  }
+#endif
   auto rd = [&](int tap, int slot) {
+#ifdef DVAE_DEBUG_SWITCHES
+    if (abl & 16) return;
+#endif
     const int kh = tap >> 2, kw = tap & 3;
     const int r = 2 * sy_l + kh;
     const int par = kw & 1, cw = sx + (kw >> 1);
@@ -328,8 +337,8 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
 #pragma unroll
           for (int r = 0; r < 4; ++r) mv[nh][r] = mask[obase + r * 32 + nh * 16];
       }
-      if (!(abl & 8)) down_ws_mfma<HS>(acc, bt, wl, sy_l, sx, i16, kq);
-      __syncthreads();
+      if (!(abl & 8)) down_ws_mfma<HS>(acc, bt, wl, sy_l, sx, i16, kq, abl);
+      if (!(abl & 32)) __syncthreads();   // (32: timing ablation, no per-unit barrier)
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
         const f32x4v a = (acc[nh][0] + acc[nh][1]) + (acc[nh][2] + acc[nh][3]);
@@ -346,12 +355,12 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
     // loader: registers pfa hold tile u+1, pfb tile u+2 (in flight); alternate
     while (unit < n_units) {
       if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pfa, sd, bt1);
-      __syncthreads();
+      if (!(abl & 32)) __syncthreads();
       if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfa, sd, big, unit + 3 * stride, N);
       unit += stride;
       if (unit >= n_units) break;
       if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pfb, sd, bt0);
-      __syncthreads();
+      if (!(abl & 32)) __syncthreads();
       if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfb, sd, big, unit + 3 * stride, N);
       unit += stride;
     }

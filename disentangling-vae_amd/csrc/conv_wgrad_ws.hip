@@ -39,7 +39,15 @@ struct WGeo {
 
 template <int HS>
 __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big, const float* __restrict__ small,
-                                                   float* __restrict__ ws, int n_units) {
+                                                   float* __restrict__ ws, int n_units
+#ifdef DVAE_DEBUG_SWITCHES
+                                                   , int abl   // timing ablations (DVAE_WGWS_ABLATE; results invalid): 1 loaders do not
+                                                               // write LDS, 2 no tile loads, 8 no MFMAs, 16 no LDS operand reads, 32 no barrier
+#endif
+                                                   ) {
+#ifndef DVAE_DEBUG_SWITCHES
+  constexpr int abl = 0;
+#endif
   using G = Geo<HS>;
   using W = WGeo<HS>;
   static_assert(G::IMGS == 1, "one image per unit");
@@ -72,7 +80,12 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
       constexpr int NG = 64 / 8;                                      // groups of 8 pixels: (sy, gx)
       constexpr int GPR = HS / 8;                                     // groups per small row
       f32x4 A[2], P0a[2], P0b[2], P1a[2], P1b[2];
+      if (abl & 16) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { A[c] = f32x4{1.f, 2.f, 3.f, 4.f}; P0a[c] = A[c]; P0b[c] = A[c]; P1a[c] = A[c]; P1b[c] = A[c]; }
+      }
       auto rd = [&](int g, int slot) {
+        if (abl & 16) return;
         const int sy = g / GPR, gx = g % GPR;
         A[slot] = *reinterpret_cast<const f32x4*>(st + abase + sy * HS + 8 * gx);
         const float* bp = bt + bbase + (4 * sy) * W::CWP + 8 * gx;    // row 2 sy + kh, parity 0
@@ -83,6 +96,7 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
       };
       rd(0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+      if (!(abl & 8)) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const int c = g & 1;
@@ -104,7 +118,8 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
         __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);            // 5 DS reads (next group)
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);           // 16 MFMAs (this group)
       }
-      __syncthreads();
+      }
+      if (!(abl & 32)) __syncthreads();
       buf ^= 1;
     }
     // partial results of this workgroup, k_wgrad32's layout: ws[block][tap][cs][cb] + 160 bias floats
@@ -152,6 +167,7 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
     // loads in the same few hundred cycles after a barrier: one unit time of look-ahead does not cover the queueing delay)
     f32x4 pbA[W::BIG_NPF], psA[2], pbB[W::BIG_NPF], psB[2];
     auto load_unit = [&](int u, f32x4 (&pb)[W::BIG_NPF], f32x4 (&ps)[2]) {
+      if (abl & 2) return;
       const long P0 = (long)u * G::U;
       const int n0 = (int)(P0 / (HS * HS));
       const int sy0 = (int)(P0 % (HS * HS)) / HS;
@@ -169,6 +185,7 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
       for (int k = 0; k < 2; ++k) ps[k] = *reinterpret_cast<const f32x4*>(sbase_g + (lt + k * 256) * 4);
     };
     auto store_unit = [&](int b, const f32x4 (&pb)[W::BIG_NPF], const f32x4 (&ps)[2]) {
+      if (abl & 1) return;
       float* bt = smem + b * W::BUF_FLOATS;
       float* st = bt + W::BT_FLOATS;
 #pragma unroll
@@ -195,12 +212,12 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
     while (unit < n_units) {
       if (unit + stride < n_units) store_unit(1, pbA, psA);
       if (unit + 3 * stride < n_units) load_unit(unit + 3 * stride, pbA, psA);
-      __syncthreads();
+      if (!(abl & 32)) __syncthreads();
       unit += stride;
       if (unit >= n_units) break;
       if (unit + stride < n_units) store_unit(0, pbB, psB);
       if (unit + 3 * stride < n_units) load_unit(unit + 3 * stride, pbB, psB);
-      __syncthreads();
+      if (!(abl & 32)) __syncthreads();
       unit += stride;
     }
   }
@@ -215,7 +232,12 @@ static int launch_wgrad_ws_t(const float* big, const float* small, float* dw, fl
   const size_t lds = (size_t)2 * W::BUF_FLOATS * sizeof(float);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32ws<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+#ifdef DVAE_DEBUG_SWITCHES
+  static const int abl = env_int("DVAE_WGWS_ABLATE", 0);
+  hipLaunchKernelGGL(k_wgrad32ws<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, n_units, abl);
+#else
   hipLaunchKernelGGL(k_wgrad32ws<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, n_units);
+#endif
   DVAE_CHECK_LAUNCH();
   if (partial_only) return 0;
   return launch_wgrad32_reduce(ws, dw, db, bias_from_big, grid, s);
