@@ -282,8 +282,10 @@ __device__ __forceinline__ void down_ws_mfma(f32x4v (&acc)[2][4], const float* b
 // from HBM (units u+2 and u+3 in two register sets) and write tile u+1 into the idle LDS buffer while
 // the compute waves run: the whole chip issues its tile loads in the same few hundred cycles after a
 // barrier, so a single tile of look-ahead (~1 unit time) does not cover the queueing delay.
-template <int HS, bool MASK>
-__global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big, const float* __restrict__ w,
+// LT = number of loader threads (256 = one loader wave per SIMD; the debug build also instantiates 512 = two per SIMD: a wave
+// that shares its SIMD with an MFMA-streaming wave issues only ~1 instruction per 50 cycles, tools/ubench/mfma_mix.hip)
+template <int HS, bool MASK, int LT = 256>
+__global__ __launch_bounds__(256 + LT) void k_down32ws(const float* __restrict__ big, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ mask,
                                                   float* __restrict__ out, int N, int act_flags, int n_units) {
   using G = Geo<HS>;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
 #else
   constexpr int abl = 0;
 #endif
-  constexpr int LNPF = (G::BIG_SLOTS + 255) / 256;
+  constexpr int LNPF = (G::BIG_SLOTS + LT - 1) / LT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                          // 16384 floats
   float* bt0 = smem + 16384;
@@ -310,10 +312,10 @@ __global__ __launch_bounds__(512) void k_down32ws(const float* __restrict__ big,
   SlotDesc<LNPF> sd;
   f32x4 pfa[LNPF], pfb[LNPF];      // loader register sets: tiles of the units (u+1, u+3, ..) and (u+2, u+4, ..)
   const int ltid = tid - 256;
-  if (!is_compute) init_big_slots<HS, 256, LNPF>(sd, ltid);
+  if (!is_compute) init_big_slots<HS, LT, LNPF>(sd, ltid);
   int unit = blockIdx.x;
   if (!is_compute && unit < n_units) load_big<HS, LNPF>(pfa, sd, big, unit, N);
-  stage_weights<true>(w, wl, tid);
+  if (LT == 256 || tid < 512) stage_weights<true>(w, wl, tid);      // (512 threads stage the 64 KB weight image)
   if (!is_compute && unit < n_units) store_big<HS, LNPF>(pfa, sd, bt0);
   __syncthreads();
   if (!is_compute) {
@@ -649,6 +651,21 @@ static int launch_down_ws(const ConvArgs& a, hipStream_t s) {
   }
   static const int abl = env_int("DVAE_ABLATE", 0);   // timing ablation, debug builds only (results invalid)
   const int af = a.act | (abl << 8);
+#ifdef DVAE_DEBUG_SWITCHES
+  static const int lt = env_int("DVAE_DOWN_LT", 256);  // 512: two loader waves per SIMD (768-thread workgroups)
+  if (lt == 512) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)k_down32ws<HS, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)k_down32ws<HS, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr2 = true;
+    }
+    if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
+    else hipLaunchKernelGGL((k_down32ws<HS, false, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
   else hipLaunchKernelGGL((k_down32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
   DVAE_CHECK_LAUNCH();
