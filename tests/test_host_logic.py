@@ -214,3 +214,25 @@ def test_unknown_replay_mode_is_reported(monkeypatch):
     monkeypatch.setenv("DVAE_REPLAY", "sometimes")
     with pytest.raises(ValueError, match="DVAE_REPLAY"):
         BetaHLoss()
+
+
+def test_bench_reads_hbm_traffic_from_the_newest_pmc_summary(tmp_path, monkeypatch):
+    """roofline.traffic comes from the newest committed PMC summary: within a round the `_final_` summary is newer than
+    any `_runN_` one, a later round beats an earlier one; values = (fetch MB + write MB) averaged over the variants of
+    the kernel family (plain / masked)."""
+    import importlib
+    bench = importlib.import_module("bench")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    head = "| kernel | A | fetch MB (x2 corr) | write MB | mfma_busy/gui |\n|---|---|---|---|---|\n"
+    (prof / "r02_run6_pmc_summary.md").write_text(head + "| k_up32ws<16, true> | 1 | 100.0 | 50.0 | 0.5 |\n")
+    (prof / "r02_final_pmc_summary.md").write_text(head + "| k_up32ws<16, true> | 1 | 180.0 | 130.0 | 0.5 |\n"
+                                                          "| k_up32ws<16, false> | 1 | 50.0 | 130.0 | 0.6 |\n")
+    (prof / "r01_run31_pmc_summary.md").write_text(head + "| k_up32ws<16, true> | 1 | 1.0 | 1.0 | 0.5 |\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bytes_, src = bench.pmc_traffic("k_up32ws<16")
+    assert src == os.path.join("profiles", "r02_final_pmc_summary.md")
+    assert abs(bytes_ - (310.0 + 180.0) / 2 * 1e6) < 1.0
+    (prof / "r03_run1_pmc_summary.md").write_text(head + "| k_up32ws<16, true> | 1 | 170.0 | 130.0 | 0.5 |\n")
+    assert bench.pmc_traffic("k_up32ws<16")[1] == os.path.join("profiles", "r03_run1_pmc_summary.md")
+    assert bench.pmc_traffic("k_no_such_kernel") == (None, None)
