@@ -114,6 +114,7 @@ int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_b
 int launch_up_mfma32_ws(const ConvArgs& a, hipStream_t s);      // wave-specialised (conv_up_ws.hip): Hs in {8,16}, NHWC
 #ifdef DVAE_DEBUG_SWITCHES
 int launch_up_mfma32_r2(const ConvArgs& a, hipStream_t s);   // experimental (conv_up_r2.hip), DVAE_UP_R2=1
+int launch_down_mfma32_d(const ConvArgs& a, hipStream_t s);  // round-3 candidate (conv_down_d.hip), DVAE_DOWN_D=1: deferred epilogue
 #endif
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big,
                         int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0, bool partial_only = false);

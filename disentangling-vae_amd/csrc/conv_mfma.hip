@@ -749,6 +749,8 @@ int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
   static const bool v2 = env_on("DVAE_DOWN_V2");
   if (a.Hs == 16 && (v1 || v2)) return v1 ? launch_down_t<16>(a, s) : launch_down_v2<16>(a, s);
   if (a.Hs == 8 && (v1 || v2)) return v1 ? launch_down_t<8>(a, s) : launch_down_v2<8>(a, s);
+  static const bool dd = env_on("DVAE_DOWN_D");
+  if (dd && (a.Hs == 16 || a.Hs == 8) && a.out_layout == DVAE_NHWC && launch_down_mfma32_d(a, s) == 0) return 0;
 #endif
   switch (a.Hs) {
     case 16: return launch_down_ws<16>(a, s);
