@@ -15,8 +15,58 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// c4 / c5: k_down32ws<16>'s REAL operand addresses (swizzled A tile behind the 64 KB B image), one / two taps of look-ahead
+template <int DEPTH>
+__device__ __forceinline__ void compute_wave_down(const float* lds, int lane, int wv, int units, float* out, int tid) {
+  f32x4 acc[8];
+  for (int c = 0; c < 8; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int i16 = lane & 15, kq = lane >> 4;
+  const float* wl = lds;
+  const float* bt = lds + 16384;
+  f32x4 R[DEPTH + 1][6];
+  auto rd = [&](int tap, int slot) {
+    const int kh = tap >> 2, kw = tap & 3;
+    const int r = 2 * wv + kh;
+    const int par = kw & 1, cw = i16 + (kw >> 1);
+    const float* arow = bt + ((r * 2 + par) * 17 + cw) * 32;
+    const int sw = (cw >> 1) & 7;
+    const float* brow = wl + (tap * 8) * 128 + i16 * 4;
+    R[slot][0] = *(const f32x4*)(arow + ((kq ^ sw) << 2));
+    R[slot][1] = *(const f32x4*)(arow + (((4 + kq) ^ sw) << 2));
+    R[slot][2] = *(const f32x4*)(brow + kq * 128);
+    R[slot][3] = *(const f32x4*)(brow + kq * 128 + 64);
+    R[slot][4] = *(const f32x4*)(brow + (4 + kq) * 128);
+    R[slot][5] = *(const f32x4*)(brow + (4 + kq) * 128 + 64);
+  };
+  for (int u = 0; u < units; ++u) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) rd(d, d);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6 * DEPTH, 0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int cur = t % (DEPTH + 1);
+      if (t + DEPTH < 16) rd(t + DEPTH, (t + DEPTH) % (DEPTH + 1));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(R[cur][0][j], R[cur][2][j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(R[cur][0][j], R[cur][3][j], acc[4 + j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(R[cur][1][j], R[cur][4][j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(R[cur][1][j], R[cur][5][j], acc[4 + j], 0, 0, 0);
+      if (t + DEPTH < 16) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
+  }
+  float s = 0.f;
+  for (int c = 0; c < 8; ++c) for (int e = 0; e < 4; ++e) s += acc[c][e];
+  if (s == 12345.f) out[tid] = s;
+}
+
 template <int CM>
 __device__ __forceinline__ void compute_wave(const float* lds, int lane, int units, float* out, int tid) {
+  if (CM == 4) { compute_wave_down<1>(lds, lane, tid >> 6, units, out, tid); return; }
+  if (CM == 5) { compute_wave_down<2>(lds, lane, tid >> 6, units, out, tid); return; }
   if (CM == 3) {
     f32x4 acc[8];
     for (int c = 0; c < 8; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -246,15 +296,10 @@ int main() {
   printf("MFMA rate of the compute waves from the device clock, TFLOP/s chip-wide (in brackets: helper-wave time / compute-wave time)\n");
   printf("helpers: h0 none, h1 44 ds_write_b32, h2 same with bank conflicts, h7 11 ds_write_b128, h3 11 global loads 16 B, h4 150 VALU, h5 h1+h3+h4, h6 8 global stores 16 B (per unit)\n");
   printf("         h9 150 VALU in 6 independent chains, h8 150 SALU\n");
-  for (int cfg = 0; cfg < 3; ++cfg) {
-    g_prio = cfg == 1 ? 1 : 0;
-    g_threads = cfg == 2 ? 768 : 512;
-    printf("-- %s\n", cfg == 0 ? "512 threads; priorities compute 1, helper 0 (as in the conv kernels)"
-                      : cfg == 1 ? "512 threads; priorities compute 0, helper 3"
-                                 : "768 threads: TWO helper waves per SIMD, each doing the whole helper work (time of the first four)");
-    row<0>("c0 32x32x2 regs", out, in, gsrc, gdst);
-    row<1>("c1 32x32x2 2rd/8mfma", out, in, gsrc, gdst);
-    row<3>("c3 16x16x4 6rd/16mfma", out, in, gsrc, gdst);
-  }
+  g_prio = 0; g_threads = 512;
+  printf("-- 512 threads; priorities compute 1, helper 0; c4 / c5 = k_down32ws<16>'s real LDS addresses, 1 / 2 taps of look-ahead\n");
+  row<3>("c3 16x16x4 6rd/16mfma", out, in, gsrc, gdst);
+  row<4>("c4 down16 addresses", out, in, gsrc, gdst);
+  row<5>("c5 down16, 2 taps ahead", out, in, gsrc, gdst);
   return 0;
 }
