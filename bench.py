@@ -21,10 +21,16 @@ GLOBAL batch; `--scaling weak` keeps B images per GPU (global batch B x N).
 One JSON line on rank 0.  `value` = images/s of the whole job over EXACTLY --steps iterations bracketed by
 barrier + synchronize on both sides (max over ranks).  Also reported: HIP-event timing of the same iterations on the
 compute stream in 5 segments (`hip_event_ms_per_step`: segments + median), `roofline` = algorithmic FLOPs of the
-dominant kernel family / its HIP-event-timed duration vs the 157.3 TFLOP/s fp32 MFMA peak (+ the other two 32-channel
-conv families in `roofline_kernels`), `parity_check` = the first iteration of this very workload (same weights, batch,
-injected noise) against the oracle, `cpu_baseline` = the CPU oracle (port of the reference Trainer, torch CPU) timed on
-this box's host cores on a bounded sample.
+dominant kernel family / its HIP-event-timed duration vs the 157.3 TFLOP/s fp32 MFMA peak, `roofline_kernels` = the other
+two 32-channel conv families (bound "mfma") and the five thin (C = 1 / 3) conv launches of the step (bound "hbm":
+algorithmic bytes / HIP-event time vs 8 TB/s), `parity_check` = the first iteration of this very workload (same weights,
+batch, injected noise, the SAME optimizer construction as the timed loop) against the oracle, `drop_in` = the same
+workload driven exactly as INTEGRATION.md tells a reference user to (optim.Adam(model.parameters()), one loss.item() per
+iteration as Trainer does under is_progress_bar=True), `configs` = the other three single-GPU BASELINE workloads as short
+legs (value, ms_per_step, fraction of the fp32 peak, parity, CPU baseline), `cpu_baseline` = the reference's CPU path
+timed on this box's host cores on a bounded sample: kind "reference" = the unmodified /root/reference Trainer (only where
+that directory exists: the build container), kind "port" = the oracle's restatement of it (the GPU boxes).
+`python bench.py --cpu-reference` (no GPU needed) times both CPU legs side by side.
 """
 import argparse
 import glob
@@ -157,53 +163,160 @@ def kernel_rooflines(B, device):
     return out
 
 
+def thin_kernel_rooflines(B, C, device):
+    """The five launches of a training step that touch the C-channel image (conv1 / convT3 + likelihood are
+    bandwidth-bound): HIP-event time vs ALGORITHMIC bytes (every tensor the launch must read or write, once) against the
+    8 TB/s HBM peak.  Through the C-ABI, at the step's own sizes."""
+    from disvae_amd import _lib
+    from disvae_amd._lib import call, ptr
+    f = lambda *s: torch.rand(*s, device=device)
+    x, a1 = f(B, C, 64, 64), f(B, 32, 32, 32)
+    g, rec, ga1 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(a1)
+    w, wt = f(32, C, 4, 4) - 0.5, f(32, C, 4, 4) - 0.5
+    b32, bc = torch.zeros(32, device=device), torch.zeros(C, device=device)
+    dw, db, dbc = torch.empty_like(w), torch.empty_like(b32), torch.empty_like(bc)
+    coef = torch.full((8,), 1.0 / B, device=device)
+    parts = torch.empty(_lib.REC_NPART, device=device)
+    ws = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), device=device)
+    s = torch.cuda.current_stream().cuda_stream
+    NC, NH = _lib.NCHW, _lib.NHWC
+    nx, na = x.numel() * 4.0, a1.numel() * 4.0
+    launches = [
+        ("k_down_thin<%d,false>" % C, "conv1 fwd", nx + na,
+         lambda: call("dvae_conv4s2_fwd", ptr(x), NC, ptr(w), ptr(b32), ptr(ga1), NH, B, C, 64, 64, 32, _lib.ACT_RELU, s)),
+        ("k_up_thin<%d,true>" % C, "convT3 fwd + sigmoid + likelihood + dL/dlogit", na + 3 * nx,
+         lambda: call("dvae_convT4s2_sigmoid_recon_fwd", ptr(a1), NH, ptr(wt), ptr(bc), ptr(x), ptr(rec), ptr(g), 0, ptr(coef),
+                      ptr(parts), B, 32, 32, 32, C, s)),
+        ("k_down_thin<%d,true>" % C, "convT3 dgrad (masked)", nx + 2 * na,
+         lambda: call("dvae_convT4s2_dgrad", ptr(x), NC, ptr(wt), ptr(a1), ptr(ga1), NH, B, 32, 32, 32, C, s)),
+        ("k_wgrad_thin<%d>" % C, "convT3 wgrad (+reduce)", nx + na,
+         lambda: call("dvae_convT4s2_wgrad", ptr(a1), NH, ptr(x), NC, ptr(dw), ptr(dbc), B, 32, 32, 32, C, ptr(ws), s)),
+        ("k_wgrad_thin<%d>" % C, "conv1 wgrad (+reduce)", nx + na,
+         lambda: call("dvae_conv4s2_wgrad", ptr(x), NC, ptr(a1), NH, ptr(dw), ptr(db), B, C, 64, 64, 32, ptr(ws), s)),
+    ]
+    out = []
+    for kern, what, nbytes, fn in launches:
+        ms = _time_launch(fn)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        traffic, src = pmc_traffic(kern.split(",")[0].split(">")[0])
+        out.append({"bound": "hbm", "kernel": kern, "launch": what, "us_per_launch": round(ms * 1e3, 2),
+                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "images_per_launch": B, "algorithmic_bytes": nbytes,
+                    "traffic": round(traffic * B / 1024) if traffic is not None and C == 3 else None,
+                    "traffic_source": src if C == 3 else None})
+    return out
+
+
 # ---------------------------------------------------------------------------------- CPU legs
 def _oracle_hp(cfg):
     return dict(HP, n_data=cfg["n_data"], lr_disc=cfg["lr_disc"])
 
 
-def cpu_baseline(cfg, B, iters=6, warm=2):
-    """CPU oracle (port of the reference Trainer iteration, incl. the wasted full-batch forward of
-    training.py:153 for factor) on this box's host cores.  The thread count is calibrated (torch's
-    default of one thread per logical CPU oversubscribes large hosts badly): the fastest of
-    {8,16,32,64,all} on a B=128 probe is used."""
-    from oracle import disvae_oracle as O
+def _calibrate_threads(make_step, img):
+    """torch's default of one thread per logical CPU oversubscribes large hosts badly: the fastest of {8,16,32,64,all}
+    on a B = 128 probe is used."""
     ncpu = os.cpu_count() or 1
-    loss, img = cfg["loss"], cfg["img"]
-    hp = _oracle_hp(cfg)
-
-    def make():
-        torch.manual_seed(1234)
-        return O.OracleTrainer(loss, hp, img, 10, lr=cfg["lr"], lr_disc=cfg["lr_disc"], steps_anneal=HP["reg_anneal"])
-
     probe = torch.rand((128,) + tuple(img))
     best_t, best_n = None, 1
     for n in sorted(set([t for t in (8, 16, 32, 64) if t <= ncpu] + [ncpu])):
         torch.set_num_threads(n)
-        tr = make()
-        tr.train_iteration(probe)
+        step = make_step()
+        step(probe)
         dt = None
         for _ in range(2):               # best of two: a single probe on a shared host is noisy
             t0 = time.perf_counter()
-            tr.train_iteration(probe)
+            step(probe)
             d_ = time.perf_counter() - t0
             dt = d_ if dt is None or d_ < dt else dt
         if best_t is None or dt < best_t:
             best_t, best_n = dt, n
     torch.set_num_threads(best_n)
-    tr = make()
+    return best_n, ncpu
+
+
+def _time_cpu(make_step, img, B, iters, warm):
+    threads, ncpu = _calibrate_threads(make_step, img)
+    step = make_step()
     data = torch.rand((B,) + tuple(img))
     ts = []
-    for i in range(warm + iters):
+    for _ in range(warm + iters):
         t0 = time.perf_counter()
-        tr.train_iteration(data)
+        step(data)
         ts.append(time.perf_counter() - t0)
     ts = sorted(ts[warm:])
-    med = ts[len(ts) // 2]
-    return {"value": round(B / med, 1), "unit": "images/s", "cores": best_n, "kind": "port",
+    return ts[len(ts) // 2], threads, ncpu
+
+
+def cpu_baseline_port(cfg, B, iters=6, warm=2):
+    """CPU oracle (port of the reference Trainer iteration, incl. the wasted full-batch forward of
+    training.py:153 for factor) on this box's host cores."""
+    from oracle import disvae_oracle as O
+    loss, img = cfg["loss"], cfg["img"]
+    hp = _oracle_hp(cfg)
+
+    def make():
+        torch.manual_seed(1234)
+        tr = O.OracleTrainer(loss, hp, img, 10, lr=cfg["lr"], lr_disc=cfg["lr_disc"], steps_anneal=HP["reg_anneal"])
+        return tr.train_iteration
+
+    med, threads, ncpu = _time_cpu(make, img, B, iters, warm)
+    return {"value": round(B / med, 1), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": "oracle (torch-CPU restatement of reference Trainer._train_iteration), %s 64x64x%d B=%d, "
                       "median of %d iterations after %d warm-ups, %.0f ms/iter, %d threads (best of a sweep) on a "
-                      "%d-CPU host" % (loss, img[0], B, iters, warm, med * 1e3, best_n, ncpu)}
+                      "%d-CPU host" % (loss, img[0], B, iters, warm, med * 1e3, threads, ncpu)}
+
+
+REFERENCE_DIR = os.environ.get("DVAE_REFERENCE", "/root/reference")
+
+
+def have_reference():
+    return os.path.isdir(os.path.join(REFERENCE_DIR, "disvae"))
+
+
+def cpu_baseline_reference(cfg, B, iters=6, warm=2):
+    """The UNMODIFIED reference (read-only checkout, imported with the two shims of SURVEY.md 8c: a stub `imageio`
+    module and numpy.product) timed on this box's host cores: init_specific_model + optim.Adam + get_loss_f +
+    Trainer._train_iteration (training.py:137-164) on the same synthetic batch.  Only where the checkout exists."""
+    import logging
+    import types
+    import numpy as np
+    sys.modules.setdefault("imageio", types.ModuleType("imageio"))
+    if not hasattr(np, "product"):
+        np.product = np.prod
+    if REFERENCE_DIR not in sys.path:
+        sys.path.insert(0, REFERENCE_DIR)
+    from disvae.models.vae import init_specific_model as ref_model
+    from disvae.models.losses import get_loss_f as ref_loss_f
+    from disvae.training import Trainer as RefTrainer
+    loss, img = cfg["loss"], cfg["img"]
+    dev = torch.device("cpu")
+
+    os.makedirs("/tmp/dvae_bench_ref", exist_ok=True)      # the reference's LossesLogger opens a file there
+
+    def make():
+        torch.manual_seed(1234)
+        model = ref_model("Burgess", img, 10)
+        opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
+        loss_f = ref_loss_f(loss, n_data=cfg["n_data"], device=dev, lr_disc=cfg["lr_disc"], **HP)
+        tr = RefTrainer(model, opt, loss_f, device=dev, logger=logging.getLogger("bench.ref"),
+                        save_dir="/tmp/dvae_bench_ref", is_progress_bar=False)
+        model.train()
+        storer = defaultdict(list)
+        return lambda data: tr._train_iteration(data, storer)
+
+    med, threads, ncpu = _time_cpu(make, img, B, iters, warm)
+    return {"value": round(B / med, 1), "unit": "images/s", "cores": threads, "kind": "reference",
+            "sample": "the reference's own Trainer._train_iteration (%s, unmodified, torch CPU), %s 64x64x%d B=%d, "
+                      "median of %d iterations after %d warm-ups, %.0f ms/iter, %d threads (best of a sweep) on a "
+                      "%d-CPU host" % (REFERENCE_DIR, loss, img[0], B, iters, warm, med * 1e3, threads, ncpu)}
+
+
+def cpu_baseline(cfg, B, iters=6, warm=2):
+    """kind "reference" wherever the reference checkout exists (the build container), kind "port" elsewhere (the GPU
+    boxes receive the repository only)."""
+    if have_reference():
+        return cpu_baseline_reference(cfg, B, iters, warm)
+    return cpu_baseline_port(cfg, B, iters, warm)
 
 
 def parity_check(cfg, B, device):
@@ -220,11 +333,11 @@ def parity_check(cfg, B, device):
     loss, img = cfg["loss"], cfg["img"]
     hp = _oracle_hp(cfg)
     torch.manual_seed(1234)
-    model = init_specific_model("Burgess", img, 10)
-    opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
+    model = init_specific_model("Burgess", img, 10).to(device)
+    opt = make_optimizer(model, cfg["lr"])          # exactly what the timed loop steps with
     loss_f = get_loss_f(loss, n_data=cfg["n_data"], device=device, lr_disc=cfg["lr_disc"], **HP)
     loss_f.replay = None
-    model.to(device).train()
+    model.train()
     torch.manual_seed(1234)
     p0 = O.init_vae_params(img, 10)
     gen = torch.Generator().manual_seed(4321)
@@ -275,6 +388,66 @@ def parity_check(cfg, B, device):
             "worst_such_preactivation_over_layer_scale": gate_worst, "batch": B, "seconds": round(time.perf_counter() - t0, 1)}
 
 
+def make_optimizer(model, lr):
+    """torch.optim.Adam as in main.py:208 on the parameter arena viewed as equal chunks (element-wise identical to Adam
+    over the 28 state_dict views: tests/test_gpu_step.py::test_flat_fused_adam_equals_adam_over_the_state_dict_views),
+    fused=True = torch's single-kernel multi-tensor variant."""
+    return torch.optim.Adam(model.flat_parameters(), lr=lr, fused=True)
+
+
+def time_leg(cfg, B, device, steps, warmup, drop_in=False, replay=None):
+    """One single-GPU leg: fresh seed-1234 model, resident synthetic batch, `warmup` untimed + `steps` timed iterations
+    between two synchronisations.  drop_in: driven the way INTEGRATION.md tells a reference user to -- optim.Adam over
+    model.parameters() (main.py:208 verbatim) and Trainer._train_iteration, i.e. one loss.item() host sync per iteration
+    (training.py:164; what is_progress_bar=True needs).  Returns (ms per step, final loss)."""
+    import logging
+    from disvae_amd.models.vae import init_specific_model
+    from disvae_amd.models.losses import get_loss_f
+    from disvae_amd.training import Trainer
+    torch.manual_seed(1234)
+    model = init_specific_model("Burgess", cfg["img"], 10).to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"]) if drop_in else make_optimizer(model, cfg["lr"])
+    loss_f = get_loss_f(cfg["loss"], n_data=cfg["n_data"], device=device, lr_disc=cfg["lr_disc"], **HP)
+    trainer = Trainer(model, opt, loss_f, device=device, logger=logging.getLogger("bench"), save_dir="/tmp/dvae_bench_leg",
+                      is_progress_bar=False, replay=replay)
+    model.train()
+    gen = torch.Generator(device=device).manual_seed(1234)
+    data = torch.rand((B,) + tuple(cfg["img"]), device=device, generator=gen)
+    torch.cuda.manual_seed(1234)
+    storer = defaultdict(list)
+    step = trainer._train_iteration if drop_in else trainer._train_iteration_async
+    for _ in range(warmup):
+        step(data, storer)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(data, storer)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt / steps * 1e3, float(loss if drop_in else loss.item())
+
+
+def extra_config(name, device, steps, warmup, with_cpu, with_parity):
+    """A BASELINE workload other than the headline one as a short single-GPU leg (outside the headline timed region)."""
+    cfg = dict(CONFIGS[name])
+    B, C = cfg["batch"], cfg["img"][0]
+    ms, final_loss = time_leg(cfg, B, device, steps, warmup)
+    flops_img = flops_per_image_factor(C) if cfg["loss"] == "factor" else flops_per_image_train(C)
+    tf = flops_img * B / (ms * 1e-3) / 1e12
+    out = {"name": name, "baseline_config": cfg["baseline_config"], "loss": cfg["loss"], "img": list(cfg["img"]), "batch": B,
+           "value": round(B / (ms * 1e-3), 1), "unit": "images/s", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup,
+           "step_tflops": round(tf, 2), "step_frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+           "final_loss": round(final_loss, 4)}
+    if with_parity:
+        pc = parity_check(cfg, B, device)
+        out["parity_check"] = {k: pc[k] for k in ("ok", "loss_rel_err", "worst_grad_err_over_max_abs_grad_vs_gate_matched_fp64",
+                                                  "units_gated_differently_than_fp64", "seconds")}
+    if with_cpu:
+        # bounded sample: at most 256 images per CPU iteration (the oracle's factor iteration at tensor 2048 is ~25 s)
+        out["cpu_baseline"] = cpu_baseline(cfg, min(B, 256), iters=3, warm=1)
+    return out
+
+
 # ---------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -302,7 +475,24 @@ def main():
                          "dvae_comm_* (RCCL enqueued by libdvae_hip.so); DVAE_COMM sets the default")
     ap.add_argument("--replay", default=None, choices=["auto", "eager", "plan", "graph"],
                     help="how the launches of an iteration are issued (disvae_amd/graph.py)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the short legs of the other three BASELINE "
+                    "workloads (they run by default with N = 1 and the default workload)")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the drop-in leg (Adam(model.parameters()) + a host "
+                    "sync per iteration)")
+    ap.add_argument("--cpu-reference", action="store_true", help="no GPU needed: time the unmodified reference Trainer "
+                    "(where /root/reference exists) and the oracle's port of it on this host, print both, exit")
     args = ap.parse_args()
+
+    if args.cpu_reference:
+        name = args.config or "btcvae_celeba"
+        cfg = dict(CONFIGS[name])
+        B = args.batch or min(cfg["batch"], 256)
+        out = {"config": name, "batch": B, "port": cpu_baseline_port(cfg, B, iters=4, warm=1)}
+        if have_reference():
+            out["reference"] = cpu_baseline_reference(cfg, B, iters=4, warm=1)
+            out["port_over_reference"] = round(out["port"]["value"] / out["reference"]["value"], 3)
+        print(json.dumps(out), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -347,9 +537,7 @@ def main():
 
     torch.manual_seed(1234)
     model = init_specific_model("Burgess", img, 10).to(device)
-    # torch.optim.Adam as in main.py:208, fused=True = torch's single-kernel multi-tensor variant, on the
-    # parameter arena viewed as equal chunks (element-wise identical to Adam over the 28 state_dict views)
-    optimizer = torch.optim.Adam(model.flat_parameters(), lr=lr, fused=True)
+    optimizer = make_optimizer(model, lr)
     loss_f = get_loss_f(loss_name, n_data=cfg["n_data"], device=device, lr_disc=cfg["lr_disc"], **HP)
     import logging
     trainer = Trainer(model, optimizer, loss_f, device=device, logger=logging.getLogger("bench"),
@@ -448,11 +636,24 @@ def main():
     if parity is not None:
         out["parity_check"] = parity
     if not args.no_roofline:
-        fams = kernel_rooflines(B if loss_name != "factor" else B // 2, device)
+        nimg = B if loss_name != "factor" else B // 2
+        fams = kernel_rooflines(nimg, device)
         out["roofline"] = fams[0]           # the family with the largest share of the step
-        out["roofline_kernels"] = fams[1:]
+        out["roofline_kernels"] = fams[1:] + thin_kernel_rooflines(nimg, C, device)
+    if world == 1 and not args.no_drop_in:
+        d_steps = min(args.steps, 50)
+        d_ms, _ = time_leg(cfg, B, device, d_steps, min(args.warmup, 10), drop_in=True)
+        out["drop_in"] = {"ms_per_step": round(d_ms, 4), "value": round(B / (d_ms * 1e-3), 1), "steps": d_steps,
+                          "optimizer": "torch.optim.Adam(model.parameters(), lr) (main.py:208 verbatim, not fused, 28 tensors)",
+                          "host_sync": "loss.item() every iteration (Trainer._train_iteration, training.py:164)",
+                          "over_timed_configuration": round(d_ms / ms, 3)}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, B)
+    if world == 1 and not args.force_ddp and not args.no_extra_configs and name == "btcvae_celeba" and not (
+            args.batch or args.channels or args.loss):
+        out["configs"] = [extra_config(n, device, steps=min(args.steps, 30), warmup=min(args.warmup, 10),
+                                       with_cpu=not args.no_cpu_baseline, with_parity=not args.no_parity_check)
+                          for n in ("factor_celeba", "btcvae_dsprites", "factor_dsprites")]
     flush_c_stdio()
     print(json.dumps(out), flush=True)
     if parity is not None and not parity["ok"]:

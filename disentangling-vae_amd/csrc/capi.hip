@@ -35,11 +35,6 @@ static int run_down(const ConvArgs& a, hipStream_t s) {
 static int run_up(const ConvArgs& a, hipStream_t s) {
   if (!use_generic_only()) {
     int r = 1;
-#ifdef DVAE_DEBUG_SWITCHES
-    static const bool r2 = env_on("DVAE_UP_R2");      // experimental kernel, debug builds only
-    if (r2) r = launch_up_mfma32_r2(a, s);
-    if (r <= 0) return r;
-#endif
     static const bool no_ws = env_off("DVAE_UP_WS");        // debug builds: DVAE_UP_WS=0 -> k_up32 for every geometry (A/B)
     if (!no_ws) {
       r = launch_up_mfma32_ws(a, s);
@@ -52,23 +47,17 @@ static int run_up(const ConvArgs& a, hipStream_t s) {
   }
   return launch_up_generic(a, s);
 }
-// partial_only: accumulate into ws and leave the reduction to dvae_conv_wgrad_reduce_grouped (tuned geometries only: 1 otherwise)
 static int run_wgrad(const float* big, int big_layout, const float* small, int small_layout, float* dw, float* db,
-                     int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws, float* ws, hipStream_t s,
-                     bool partial_only = false) {
+                     int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws, float* ws, hipStream_t s) {
   // the small side of the 4x4 end of the conv stack may be NCHW (= the FC stack's (c,h,w) order)
   if (!use_generic_only() && ws != nullptr && Hs == Ws && Cs == 32 && Cb == 32 && big_layout == DVAE_NHWC && Hs == 4 &&
       small_layout == DVAE_NCHW)
-    return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s, 1, partial_only);
+    return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s, 1);
   if (!use_generic_only() && ws != nullptr && Hs == Ws && Cs == 32 && small_layout == DVAE_NHWC) {
     if (Cb == 32 && big_layout == DVAE_NHWC && (Hs == 4 || Hs == 8 || Hs == 16))
-      return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s, 0, partial_only);
+      return launch_wgrad_mfma32(big, small, dw, db, bias_from_big, N, Hs, ws, s, 0);
     if ((Cb == 1 || Cb == 3) && Hs == 32 && big_layout == DVAE_NCHW)
-      return launch_wgrad_thin(big, small, dw, db, bias_from_big, N, Cb, Hs, ws, s, partial_only);
-  }
-  if (partial_only) {
-    set_error("dvae_conv*_wgrad_partial: geometry not covered by the tuned kernels (use dvae_conv*_wgrad)");
-    return 1;
+      return launch_wgrad_thin(big, small, dw, db, bias_from_big, N, Cb, Hs, ws, s);
   }
   return launch_wgrad_generic(big, big_layout, small, small_layout, dw, db, bias_from_big, N, Cb, Cs, Hs, Ws, s);
 }
@@ -182,24 +171,6 @@ int dvae_convT4s2_sigmoid_recon_fwd_u8(const float* x, const float* w, const flo
   DVAE_CHECK_ARG(dist == DVAE_REC_BERNOULLI || dist == DVAE_REC_GAUSSIAN || dist == DVAE_REC_LAPLACE);
   ConvArgs a{nullptr, 0, x, DVAE_NHWC, w, b, nullptr, recon, DVAE_NCHW, N, Cout, Cin, H, W, DVAE_ACT_SIGMOID};
   return launch_up_thin_recon_u8(a, target, g, dist, coef, partials, (hipStream_t)stream);
-}
-
-int dvae_conv4s2_wgrad_partial(const float* x, int x_layout, const float* dy, int dy_layout, int N, int Cin, int H, int W,
-                               int Cout, float* ws, void* stream) {
-  DVAE_CHECK_ARG(x && dy && ws && N > 0 && (H % 2 == 0) && (W % 2 == 0));
-  return run_wgrad(x, x_layout, dy, dy_layout, nullptr, nullptr, 0, N, Cin, Cout, H / 2, W / 2, ws, (hipStream_t)stream, true);
-}
-
-int dvae_convT4s2_wgrad_partial(const float* x, int x_layout, const float* dy, int dy_layout, int N, int Cin, int H, int W,
-                                int Cout, float* ws, void* stream) {
-  DVAE_CHECK_ARG(x && dy && ws && N > 0);
-  return run_wgrad(dy, dy_layout, x, x_layout, nullptr, nullptr, 1, N, Cout, Cin, H, W, ws, (hipStream_t)stream, true);
-}
-
-int dvae_conv_wgrad_reduce_grouped(const dvae_conv_wgrad_desc* descs, int n, void* stream) {
-  DVAE_CHECK_ARG(descs && n >= 1 && n <= DVAE_WGR_MAX);
-  for (int q = 0; q < n; ++q) DVAE_CHECK_ARG(descs[q].ws && descs[q].dw && descs[q].N > 0 && descs[q].H == descs[q].W);
-  return launch_wgrad_reduce_grouped(descs, n, (hipStream_t)stream);
 }
 
 size_t dvae_conv_wgrad_ws_floats(void) {
@@ -318,13 +289,71 @@ int dvae_loss_pack(const float* rec_partials, const float* kl_dim, int D, const 
   return launch_loss_pack(rec_partials, kl_dim, D, rowstats, Bl, disc_sums, packed, (hipStream_t)stream);
 }
 
-int dvae_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_rows, int D, const float* rowstats,
+int dvae_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_blocks, int D, const float* rowstats,
                        int Bl, const float* disc_sums, int Bg, const float* coef, float* packed, float* scal,
                        void* stream) {
-  DVAE_CHECK_ARG(rec_partials && packed && coef && D >= 0 && D <= 16 && Bl >= 0 && Bg > 0 && kl_rows >= 0);
+  DVAE_CHECK_ARG(rec_partials && packed && coef && D >= 0 && D <= 16 && Bl >= 0 && Bg > 0);
+  DVAE_CHECK_ARG(kl_blocks >= 0 && kl_blocks <= DVAE_KL_MAX_BLOCKS);
   DVAE_CHECK_ARG(kind >= DVAE_LOSS_BETAH && kind <= DVAE_LOSS_FACTOR);
-  return launch_loss_epilogue(kind, rec_partials, kl_dim, kl_rows, D, rowstats, Bl, disc_sums, Bg, coef, packed, scal,
+  return launch_loss_epilogue(kind, rec_partials, kl_dim, kl_blocks, D, rowstats, Bl, disc_sums, Bg, coef, packed, scal,
                               (hipStream_t)stream);
+}
+
+int dvae_reparam_kl_blocks(int B) { return B > 0 ? reparam_kl_blocks(B) : 0; }
+
+int dvae_kl_finish(float* kl_dim, int kl_blocks, const float* coef, int D, void* stream) {
+  DVAE_CHECK_ARG(kl_dim && coef && kl_blocks > 0 && kl_blocks <= DVAE_KL_MAX_BLOCKS && D > 0 && D <= DVAE_MAX_D);
+  return launch_kl_finish(kl_dim, kl_blocks, coef, D, (hipStream_t)stream);
+}
+
+// ---- per-step weight staging, the tuned 32-channel kernels on pre-staged weights, the FC chain ----------------------
+int dvae_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc, float* coef,
+                       const float* coef_vals, void* stream) {
+  DVAE_CHECK_ARG(n_conv >= 0 && n_conv <= DVAE_STAGE_MAX_CONV && n_fc >= 0 && n_fc <= DVAE_STAGE_MAX_FC);
+  DVAE_CHECK_ARG((n_conv == 0 || conv) && (n_fc == 0 || fc));
+  for (int q = 0; q < n_conv; ++q) DVAE_CHECK_ARG(conv[q].w);
+  for (int q = 0; q < n_fc; ++q) DVAE_CHECK_ARG(fc[q].w && fc[q].N > 0 && fc[q].K > 0);
+  return launch_stage_weights(conv, n_conv, fc, n_fc, coef, coef_vals, (hipStream_t)stream);
+}
+
+int dvae_conv32_down(const float* big, const float* img_down, const float* bias, const float* mask, float* out,
+                     int out_layout, int N, int Hs, int act, void* stream) {
+  DVAE_CHECK_ARG(big && img_down && out && N > 0 && (Hs == 4 || Hs == 8 || Hs == 16) && check_layout(out_layout));
+  DVAE_CHECK_ARG(out_layout == DVAE_NHWC || Hs == 4);
+  DVAE_CHECK_ARG(act == DVAE_ACT_NONE || act == DVAE_ACT_RELU);
+  ConvArgs a{big, DVAE_NHWC, nullptr, 0, img_down, bias, mask, out, out_layout, N, 32, 32, Hs, Hs, act, 1};
+  const int r = launch_down_mfma32(a, (hipStream_t)stream);
+  if (r > 0) { set_error("dvae_conv32_down: geometry not covered"); return -1; }
+  return r;
+}
+
+int dvae_conv32_up(const float* small, int small_layout, const float* img_up, const float* bias, const float* mask,
+                   float* out, int N, int Hs, int act, void* stream) {
+  DVAE_CHECK_ARG(small && img_up && out && N > 0 && (Hs == 4 || Hs == 8 || Hs == 16) && check_layout(small_layout));
+  DVAE_CHECK_ARG(small_layout == DVAE_NHWC || Hs == 4);
+  DVAE_CHECK_ARG(act == DVAE_ACT_NONE || act == DVAE_ACT_RELU);
+  ConvArgs a{nullptr, 0, small, small_layout, img_up, bias, mask, out, DVAE_NHWC, N, 32, 32, Hs, Hs, act, 1};
+  int r = launch_up_mfma32_ws(a, (hipStream_t)stream);
+  if (r > 0) r = launch_up_mfma32(a, (hipStream_t)stream);
+  if (r > 0) { set_error("dvae_conv32_up: geometry not covered"); return -1; }
+  return r;
+}
+
+int dvae_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, void* stream) {
+  DVAE_CHECK_ARG(a && a->a_flat && a->w_e1 && a->w_e2 && a->w_ml && a->b_e1 && a->b_e2 && a->b_ml);
+  DVAE_CHECK_ARG(a->h1 && a->h2 && a->ml && a->mu && a->logvar && a->z);
+  DVAE_CHECK_ARG(a->D >= 1 && a->D <= DVAE_MAX_D && a->n_enc > 0 && a->n_enc <= 8 * DVAE_KL_MAX_BLOCKS);
+  DVAE_CHECK_ARG(a->n_kl >= 0 && a->n_kl <= a->n_enc && a->n_dec >= 0 && a->n_dec <= a->n_enc);
+  if (a->n_dec > 0) DVAE_CHECK_ARG(a->w_d1 && a->w_d2 && a->w_d3 && a->b_d1 && a->b_d2 && a->b_d3 && a->d1 && a->d2 && a->d3);
+  return launch_fc_chain_fwd(a, (hipStream_t)stream);
+}
+
+int dvae_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, void* stream) {
+  DVAE_CHECK_ARG(a && a->gd3 && a->w_d3 && a->w_d2 && a->w_d1 && a->w_ml && a->w_e2 && a->w_e1);
+  DVAE_CHECK_ARG(a->d2 && a->d1 && a->h2 && a->h1 && a->a_flat && a->mu && a->logvar && a->scal && a->coef);
+  DVAE_CHECK_ARG(a->gd2 && a->gd1 && a->dml && a->gh2 && a->gh1 && a->ga_flat);
+  DVAE_CHECK_ARG(a->D >= 1 && a->D <= DVAE_MAX_D && a->n > 0);
+  return launch_fc_chain_bwd(a, (hipStream_t)stream);
 }
 
 int dvae_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal, void* stream) {

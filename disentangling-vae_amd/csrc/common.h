@@ -98,6 +98,7 @@ struct ConvArgs {
   float* out; int out_layout;
   int N, Cb, Cs, Hs, Ws;  // Hs,Ws: SMALL spatial dims (big is 2Hs x 2Ws)
   int act;
+  int w_staged;           // 1: `w` is the pre-staged LDS weight image of dvae_stage_weights (tuned 32-channel kernels only)
 };
 int launch_down_generic(const ConvArgs& a, hipStream_t s);
 int launch_up_generic(const ConvArgs& a, hipStream_t s);
@@ -108,16 +109,11 @@ int launch_wgrad_generic(const float* big, int big_layout, const float* small, i
 int launch_down_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_up_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_wgrad_mfma32_ws(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N, int Hs,
-                           float* ws, hipStream_t s, bool partial_only = false);    // wave-specialised, transposed LDS tiles (conv_wgrad_ws.hip): Hs in {8,16}
-int launch_wgrad_reduce_grouped(const dvae_conv_wgrad_desc* d, int n, hipStream_t s);
+                           float* ws, hipStream_t s);    // wave-specialised, transposed LDS tiles (conv_wgrad_ws.hip): Hs in {8,16}
 int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_big, int nblk, hipStream_t s);
 int launch_up_mfma32_ws(const ConvArgs& a, hipStream_t s);      // wave-specialised (conv_up_ws.hip): Hs in {8,16}, NHWC
-#ifdef DVAE_DEBUG_SWITCHES
-int launch_up_mfma32_r2(const ConvArgs& a, hipStream_t s);   // experimental (conv_up_r2.hip), DVAE_UP_R2=1
-int launch_down_mfma32_d(const ConvArgs& a, hipStream_t s);  // round-3 candidate (conv_down_d.hip), DVAE_DOWN_D=1: deferred epilogue
-#endif
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big,
-                        int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0, bool partial_only = false);
+                        int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0);
 // thin paths (Cb in {1,3}, Cs == 32, big NCHW 64x64 / small NHWC 32x32)
 int launch_down_thin(const ConvArgs& a, hipStream_t s);
 int launch_up_thin(const ConvArgs& a, hipStream_t s);
@@ -125,7 +121,7 @@ int launch_up_thin(const ConvArgs& a, hipStream_t s);
 int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int dist, const float* coef,
                          float* partials, hipStream_t s);
 int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big,
-                      int N, int Cb, int Hs, float* ws, hipStream_t s, bool partial_only = false);
+                      int N, int Cb, int Hs, float* ws, hipStream_t s);
 // uint8 input image x[N,C,64,64] (NCHW), converted on the fly with ToTensor's float(v)/255; return 1 if C is not 1 or 3
 int launch_down_thin_u8(const uint8_t* x, const float* w, const float* bias, float* out, int N, int C, int act, hipStream_t s);
 int launch_up_thin_recon_u8(const ConvArgs& a, const uint8_t* target, float* g, int dist, const float* coef,
@@ -150,6 +146,12 @@ size_t latent_entropy_ws_floats(long N, int D, int S);
 int launch_latent_entropy(const float* z_ds, const float* mean, const float* logvar, long N, int D, int S, float* ws,
                           float* H, hipStream_t s);
 int launch_linear_wgrad_grouped(const dvae_linear_wgrad_desc* d, int n, hipStream_t s);
+int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s);
+int launch_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, hipStream_t s);
+int reparam_kl_blocks(int B);
+int launch_kl_finish(float* kl_dim, int kl_blocks, const float* coef, int D, hipStream_t s);
+int launch_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc, float* coef,
+                         const float* coef_vals, hipStream_t s);
 
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                           const float* coef, int B, int D, hipStream_t s);
@@ -170,7 +172,7 @@ int launch_disc_losses(const float* lg, int Bh, const float* coef, float* sums, 
 int launch_loss_pack(const float* rec_partials, const float* kl_dim, int D, const float* rowstats, int Bl,
                      const float* disc_sums, float* packed, hipStream_t s);
 int launch_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal, hipStream_t s);
-int launch_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_rows, int D, const float* rowstats,
+int launch_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_blocks, int D, const float* rowstats,
                          int Bl, const float* disc_sums, int Bg, const float* coef, float* packed, float* scal,
                          hipStream_t s);
 int launch_set_coef(float* coef, const float* v, hipStream_t s);

@@ -30,7 +30,7 @@ template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, const float* __restrict__ w,
                                                 const float* __restrict__ bias, const float* __restrict__ mask,
                                                 float* __restrict__ out, int N, int act, int n_units,
-                                                int out_nchw) {
+                                                int out_nchw, int w_staged) {
   using G = Geo<HS>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;                    // 16384 floats
@@ -48,7 +48,8 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
   f32x4 pf[G::BIG_NPF];
   int unit = blockIdx.x;
   if (unit < n_units) load_big<HS>(pf, sd, big, unit, N);
-  stage_weights<true>(w, wl, tid);
+  if (w_staged) copy_weight_image(w, wl, tid);
+  else stage_weights<true>(w, wl, tid);
   const float bv = bias ? bias[i] : 0.f;
   const long npix = (long)N * HS * HS;
 
@@ -122,104 +123,6 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
   }
 }
 
-#ifdef DVAE_DEBUG_SWITCHES
-// ---- down, version 2 (HS = 16, 8): no K-split ---------------------------------------------
-// 8 waves = 4 M-tiles of 16 pixels x 2 halves of the 32 output channels on v_mfma_f32_16x16x4_f32
-// (two independent accumulator chains: the instruction's 40-cycle dependent latency exceeds its
-// 32-cycle issue interval).  Every wave runs the full K = 512, so there is no cross-wave
-// reduction and no reduction buffer; the LDS that frees up double-buffers the activation tile:
-// one barrier per unit, and a wave that finishes its MFMAs writes the NEXT tile while the other
-// waves are still computing.
-template <int HS, bool MASK>
-__global__ __launch_bounds__(512) void k_down32v2(const float* __restrict__ big, const float* __restrict__ w,
-                                                  const float* __restrict__ bias, const float* __restrict__ mask,
-                                                  float* __restrict__ out, int N, int act, int n_units) {
-  using G = Geo<HS>;
-  static_assert(G::IMGS == 1, "v2 assumes one image per unit");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* wl = smem;                          // 16384 floats
-  float* bt0 = smem + 16384;                 // G::BIG_FLOATS
-  float* bt1 = bt0 + G::BIG_FLOATS;          // G::BIG_FLOATS
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int mt = wv >> 1, nh = wv & 1;
-  const int i16 = lane & 15, kq = lane >> 4;
-  const int p = mt * 16 + i16;
-  const int sy_l = (p / HS) % G::R, sx = p % HS;
-  const int co = nh * 16 + i16;
-
-  SlotDesc<G::BIG_NPF> sd;
-  init_big_slots<HS>(sd, tid);
-  f32x4 pf[G::BIG_NPF];
-  int unit = blockIdx.x;
-  const int stride = gridDim.x;
-  if (unit < n_units) load_big<HS>(pf, sd, big, unit, N);
-  stage_weights<true>(w, wl, tid);
-  const float bv = bias ? bias[co] : 0.f;
-  if (unit < n_units) store_big<HS>(pf, sd, bt0);
-  __syncthreads();
-  if (unit + stride < n_units) load_big<HS>(pf, sd, big, unit + stride, N);
-  int buf = 0;
-
-  for (; unit < n_units; unit += stride) {
-    const float* bt = buf ? bt1 : bt0;
-    // this wave's 4 output rows (pixels) x 16 channels: D row = 4*kq + reg, col = i16
-    const long obase = ((long)unit * G::U + mt * 16 + 4 * kq) * 32 + co;
-    float mv[4];
-    if (MASK) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mv[r] = mask[obase + r * 32];
-    }
-    // 4 independent accumulator chains (index = ci % 4): consecutive MFMAs never depend on each
-    // other (16x16x4: 40-cycle dependent latency vs 32-cycle issue, plus the issue-slot cliff for
-    // back-to-back dependent MFMAs with other instructions in between)
-    f32x4v acc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    // operands of tap t+1 are read from LDS before the 8 MFMAs of tap t are issued (register
-    // ping-pong); sched_group_barrier pins that order so the LDS latency hides under the MFMAs
-    f32x4 A0[2], B0[2], A1[2], B1[2];
-    auto rd = [&](int tap, int slot) {
-      const int kh = tap >> 2, kw = tap & 3;
-      const int r = 2 * sy_l + kh;
-      const int par = kw & 1, cw = sx + (kw >> 1);
-      const float* arow = bt + ((r * 2 + par) * G::CW + cw) * 32;
-      const int sw = swz_big<HS>(r, cw);
-      const float* brow = wl + (tap * 8) * 128 + co * 4;
-      A0[slot] = *reinterpret_cast<const f32x4*>(arow + ((kq ^ sw) << 2));
-      B0[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128);
-      A1[slot] = *reinterpret_cast<const f32x4*>(arow + (((4 + kq) ^ sw) << 2));
-      B1[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128);
-    };
-    rd(0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // prologue: the reads of tap 0
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int cur = t & 1;
-      if (t + 1 < 16) rd(t + 1, cur ^ 1);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B0[cur][j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B1[cur][j], acc[j], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads (next tap)
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMAs (this tap)
-    }
-    const f32x4v acc0 = acc[0] + acc[1], acc1 = acc[2] + acc[3];
-    // hand over to the next unit: its tile (prefetched during the MFMAs) goes to the other buffer
-    if (unit + stride < n_units) store_big<HS>(pf, sd, buf ? bt0 : bt1);
-    __syncthreads();
-    if (unit + 2 * stride < n_units) load_big<HS>(pf, sd, big, unit + 2 * stride, N);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = epilogue_act(acc0[r] + acc1[r] + bv, act);
-      if (MASK) v = mv[r] > 0.f ? v : 0.f;
-      out[obase + r * 32] = v;
-    }
-    buf ^= 1;
-  }
-}
-
-#endif  // DVAE_DEBUG_SWITCHES
-
 // ---- down, version 3 (HS = 16, 8): wave-specialised ---------------------------------------
 // Waves 0-3 (one per SIMD) do nothing but MFMAs: each owns 16 pixels x all 32 output channels of the
 // unit (256 v_mfma_f32_16x16x4_f32, 8 independent accumulator chains, operands prefetched one tap
@@ -287,7 +190,8 @@ __device__ __forceinline__ void down_ws_mfma(f32x4v (&acc)[2][4], const float* b
 template <int HS, bool MASK, int LT = 256>
 __global__ __launch_bounds__(256 + LT) void k_down32ws(const float* __restrict__ big, const float* __restrict__ w,
                                                   const float* __restrict__ bias, const float* __restrict__ mask,
-                                                  float* __restrict__ out, int N, int act_flags, int n_units) {
+                                                  float* __restrict__ out, int N, int act_flags, int n_units,
+                                                  int w_staged) {
   using G = Geo<HS>;
   static_assert(G::IMGS == 1, "one image per unit");
   const int act = act_flags & 0xff;
@@ -315,7 +219,9 @@ __global__ __launch_bounds__(256 + LT) void k_down32ws(const float* __restrict__
   if (!is_compute) init_big_slots<HS, LT, LNPF>(sd, ltid);
   int unit = blockIdx.x;
   if (!is_compute && unit < n_units) load_big<HS, LNPF>(pfa, sd, big, unit, N);
-  if (LT == 256 || tid < 512) stage_weights<true>(w, wl, tid);      // (512 threads stage the 64 KB weight image)
+  // the 64 KB weight image: copied as it is when pre-staged (dvae_stage_weights), else re-laid here by 512 threads
+  if (w_staged) copy_weight_image(w, wl, tid);
+  else if (LT == 256 || tid < 512) stage_weights<true>(w, wl, tid);
   if (!is_compute && unit < n_units) store_big<HS, LNPF>(pfa, sd, bt0);
   __syncthreads();
   if (!is_compute) {
@@ -413,7 +319,7 @@ template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, const float* __restrict__ w,
                                               const float* __restrict__ bias, const float* __restrict__ mask,
                                               float* __restrict__ out, int N, int act, int n_units,
-                                              int small_nchw) {
+                                              int small_nchw, int w_staged) {
   using G = Geo<HS>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;              // 16384 floats
@@ -430,7 +336,8 @@ __global__ __launch_bounds__(512) void k_up32(const float* __restrict__ small, c
   f32x4 pf[G::SH_NPF];
   int unit = blockIdx.x;
   if (unit < n_units) load_small_halo<HS>(pf, sd, small, unit, N, small_nchw);
-  stage_weights<false>(w, wl, tid);
+  if (w_staged) copy_weight_image(w, wl, tid);
+  else stage_weights<false>(w, wl, tid);
   const float bv = bias ? bias[i] : 0.f;
   float vals[16];
   int prev_unit = -1;
@@ -616,27 +523,6 @@ int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_b
 // ---- launchers -----------------------------------------------------------------------------
 static int units_for(int N, int HS) { return (int)(((long)N * HS * HS + 63) / 64); }
 
-#ifdef DVAE_DEBUG_SWITCHES
-template <int HS>
-static int launch_down_v2(const ConvArgs& a, hipStream_t s) {
-  using G = Geo<HS>;
-  const int n_units = units_for(a.N, HS);     // HS*HS is a multiple of 64: every unit is complete
-  const int grid = n_units < 256 ? n_units : 256;
-  const size_t lds = (16384 + 2 * G::BIG_FLOATS) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_down32v2<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)k_down32v2<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
-  if (a.mask) hipLaunchKernelGGL((k_down32v2<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
-  else hipLaunchKernelGGL((k_down32v2<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
-  DVAE_CHECK_LAUNCH();
-  return 0;
-}
-
-#endif
-
 template <int HS>
 static int launch_down_ws(const ConvArgs& a, hipStream_t s) {
   using G = Geo<HS>;
@@ -660,14 +546,14 @@ static int launch_down_ws(const ConvArgs& a, hipStream_t s) {
       (void)hipFuncSetAttribute((const void*)k_down32ws<HS, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr2 = true;
     }
-    if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
-    else hipLaunchKernelGGL((k_down32ws<HS, false, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
+    if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
+    else hipLaunchKernelGGL((k_down32ws<HS, false, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
     DVAE_CHECK_LAUNCH();
     return 0;
   }
 #endif
-  if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
-  else hipLaunchKernelGGL((k_down32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units);
+  if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
+  else hipLaunchKernelGGL((k_down32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -685,8 +571,8 @@ static int launch_down_t(const ConvArgs& a, hipStream_t s) {
     attr = true;
   }
   const int out_nchw = a.out_layout == DVAE_NCHW;
-  if (a.mask) hipLaunchKernelGGL((k_down32<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, out_nchw);
-  else hipLaunchKernelGGL((k_down32<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, out_nchw);
+  if (a.mask) hipLaunchKernelGGL((k_down32<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, out_nchw, a.w_staged);
+  else hipLaunchKernelGGL((k_down32<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, out_nchw, a.w_staged);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -704,15 +590,15 @@ static int launch_up_t(const ConvArgs& a, hipStream_t s) {
     attr = true;
   }
   const int small_nchw = a.small_layout == DVAE_NCHW;
-  if (a.mask) hipLaunchKernelGGL((k_up32<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, small_nchw);
-  else hipLaunchKernelGGL((k_up32<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, small_nchw);
+  if (a.mask) hipLaunchKernelGGL((k_up32<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, small_nchw, a.w_staged);
+  else hipLaunchKernelGGL((k_up32<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, small_nchw, a.w_staged);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
 
 template <int HS>
 static int launch_wgrad_t(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
-                          float* ws, hipStream_t s, int small_nchw, bool partial_only) {
+                          float* ws, hipStream_t s, int small_nchw) {
   using G = Geo<HS>;
   const int n_units = units_for(N, HS);
   // (capping the persistent grid to leave CUs to the dgrad stream was measured: 128 -> +10 % step time)
@@ -726,7 +612,6 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units, small_nchw);
   DVAE_CHECK_LAUNCH();
-  if (partial_only) return 0;                       // dvae_conv_wgrad_reduce_grouped finishes it
   hipLaunchKernelGGL(k_wgrad32_reduce, dim3(WG_REDUCE_BLOCKS), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   DVAE_CHECK_LAUNCH();
   return 0;
@@ -742,16 +627,7 @@ int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
   const int out_l = (a.Hs == 4 && a.out_layout == DVAE_NCHW) ? DVAE_NHWC : a.out_layout;
   if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.big_layout, out_l, DVAE_NHWC)) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
-  // HS = 16, 8: wave-specialised (4 MFMA waves + 4 loader waves); HS = 4: K-split 32x32x2 kernel.  Debug builds:
-  // DVAE_DOWN_V1=1 = the K-split kernel for every HS, DVAE_DOWN_V2=1 = 8 symmetric waves
-#ifdef DVAE_DEBUG_SWITCHES
-  static const bool v1 = env_on("DVAE_DOWN_V1");
-  static const bool v2 = env_on("DVAE_DOWN_V2");
-  if (a.Hs == 16 && (v1 || v2)) return v1 ? launch_down_t<16>(a, s) : launch_down_v2<16>(a, s);
-  if (a.Hs == 8 && (v1 || v2)) return v1 ? launch_down_t<8>(a, s) : launch_down_v2<8>(a, s);
-  static const bool dd = env_on("DVAE_DOWN_D");
-  if (dd && (a.Hs == 16 || a.Hs == 8) && a.out_layout == DVAE_NHWC && launch_down_mfma32_d(a, s) == 0) return 0;
-#endif
+  // HS = 16, 8: wave-specialised (4 MFMA waves + 4 loader waves); HS = 4: K-split 32x32x2 kernel
   switch (a.Hs) {
     case 16: return launch_down_ws<16>(a, s);
     case 8: return launch_down_ws<8>(a, s);
@@ -772,14 +648,14 @@ int launch_up_mfma32(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
-                        int Hs, float* ws, hipStream_t s, int small_nchw, bool partial_only) {
+                        int Hs, float* ws, hipStream_t s, int small_nchw) {
   static const bool no_ws = env_off("DVAE_WGRAD_WS");     // debug builds: DVAE_WGRAD_WS=0 -> k_wgrad32 for every geometry (A/B)
   if (!no_ws && !small_nchw && (Hs == 16 || Hs == 8))
-    return launch_wgrad_mfma32_ws(big, small, dw, db, bias_from_big, N, Hs, ws, s, partial_only);
+    return launch_wgrad_mfma32_ws(big, small, dw, db, bias_from_big, N, Hs, ws, s);
   switch (Hs) {
-    case 16: return launch_wgrad_t<16>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw, partial_only);
-    case 8: return launch_wgrad_t<8>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw, partial_only);
-    case 4: return launch_wgrad_t<4>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw, partial_only);
+    case 16: return launch_wgrad_t<16>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
+    case 8: return launch_wgrad_t<8>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
+    case 4: return launch_wgrad_t<4>(big, small, dw, db, bias_from_big, N, ws, s, small_nchw);
     default: return 1;
   }
 }

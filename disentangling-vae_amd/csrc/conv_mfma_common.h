@@ -172,6 +172,23 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ w, float
   }
 }
 
+// Straight copy of a PRE-STAGED 64 KB weight image (dvae_stage_weights: the image already is in the LDS order above) by the
+// first 8 waves of the workgroup: 8 LDS-DMA transfers of 1 KB per wave (global_load_lds_dwordx4: no staging registers, no
+// ds_write pass); the data is in LDS once every wave has passed this function AND the following workgroup barrier.
+__device__ __forceinline__ void copy_weight_image(const float* __restrict__ img, float* wl, int tid) {
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wv < 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int base = (k * 8 + wv) * 256;             // 256 floats = 64 lanes x 16 bytes; the LDS side is lane-linear
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + base + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(wl + base), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // LDS-DMA completes in vmcnt order; the barrier that follows publishes it
+}
+
 __device__ __forceinline__ float epilogue_act(float v, int act) {
   if (act == DVAE_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;

@@ -474,7 +474,7 @@ int launch_wgrad_thin_u8(const uint8_t* x, const float* small, float* dw, float*
 }
 
 int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N, int Cb,
-                      int Hs, float* ws, hipStream_t s, bool partial_only) {
+                      int Hs, float* ws, hipStream_t s) {
   if (!(Cb == 1 || Cb == 3) || Hs != 32) return 1;
   const int n_units = N * 8;
   int grid = n_units < WT_MAX_BLOCKS ? n_units : WT_MAX_BLOCKS;
@@ -485,12 +485,10 @@ int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db
   if (Cb == 1) {
     hipLaunchKernelGGL(k_wgrad_thin<1>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    if (partial_only) return 0;
     hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(WT_REDUCE_BLOCKS(1)), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   } else {
     hipLaunchKernelGGL(k_wgrad_thin<3>, dim3(grid), dim3(256), 0, s, big, small, ws, N, n_units);
     DVAE_CHECK_LAUNCH();
-    if (partial_only) return 0;
     hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(WT_REDUCE_BLOCKS(3)), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
   }
   DVAE_CHECK_LAUNCH();

@@ -75,7 +75,7 @@ __device__ __forceinline__ void store_small_n(const f32x4 (&pf)[NPF], const Slot
 template <int HS, bool MASK>
 __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small, const float* __restrict__ w,
                                                 const float* __restrict__ bias, const float* __restrict__ mask,
-                                                float* __restrict__ out, int act, int n_units) {
+                                                float* __restrict__ out, int act, int n_units, int w_staged) {
   using G = Geo<HS>;
   static_assert(G::IMGS == 1, "one image per unit");
   constexpr int HB = 2 * HS;
@@ -103,14 +103,7 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
     init_small_slots_n<HS, 256, LNPF>(sd, ht);
     if (unit0 < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit0);
   }
-  stage_weights<false>(w, wl, tid);
-  if (!is_compute) {
-    if (unit0 < n_units) store_small_n<LNPF>(pf, sd, in0);
-    if (unit0 + stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit0 + stride);
-  }
-  __syncthreads();                                   // weight image and the first input tile are in LDS
-
-  // compute-wave constants (the memory waves skip this)
+  // compute-wave constants (the memory waves skip their use)
   const int cls = wv & 3;
   const int py = cls >> 1, px = cls & 1;
   const int i = lane & 31, h = lane >> 5;
@@ -118,8 +111,28 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
   // stay in registers for the whole kernel: the weights are the same for every unit, and every LDS read taken out of the
   // MFMA loop shortens it (timing ablations, profiles/r02_run7_upws_ablation.txt: operand reads cost 15 % of the loop)
   f32x4 Bq[4][4];
-  if (is_compute) {
-    const int boff = i * 4 + h * 128;                // + ((kh*4+kw)*8 + 2q) * 128
+  const int boff = i * 4 + h * 128;                  // + ((kh*4+kw)*8 + 2q) * 128
+  // pre-staged weights (dvae_stage_weights): `w` already is the image, the compute waves take their B fragments straight
+  // from it (16 coalesced 16-byte loads per lane, L2-resident, issued before the first barrier) and the LDS staging pass
+  // disappears from the prologue
+  if (w_staged) {
+    if (is_compute) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int kh = 1 - py + 2 * (t >> 1), kw = 1 - px + 2 * (t & 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Bq[t][q] = *reinterpret_cast<const f32x4*>(w + boff + ((kh * 4 + kw) * 8 + 2 * q) * 128);
+      }
+    }
+  } else {
+    stage_weights<false>(w, wl, tid);
+  }
+  if (!is_compute) {
+    if (unit0 < n_units) store_small_n<LNPF>(pf, sd, in0);
+    if (unit0 + stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit0 + stride);
+  }
+  __syncthreads();                                   // weight image and the first input tile are in LDS
+  if (is_compute && !w_staged) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int kh = 1 - py + 2 * (t >> 1), kw = 1 - px + 2 * (t & 1);
@@ -277,8 +290,8 @@ static int launch_up_ws_t(const ConvArgs& a, hipStream_t s) {
   }
   static const int abl = env_int("DVAE_UPWS_ABLATE", 0);      // debug builds only
   const int af = a.act | (abl << 8);
-  if (a.mask) hipLaunchKernelGGL((k_up32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units);
-  else hipLaunchKernelGGL((k_up32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units);
+  if (a.mask) hipLaunchKernelGGL((k_up32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units, a.w_staged);
+  else hipLaunchKernelGGL((k_up32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units, a.w_staged);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

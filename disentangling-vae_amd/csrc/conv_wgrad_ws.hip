@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
 
 template <int HS>
 static int launch_wgrad_ws_t(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N,
-                             float* ws, hipStream_t s, bool partial_only) {
+                             float* ws, hipStream_t s) {
   using W = WGeo<HS>;
   const int n_units = (int)(((long)N * HS * HS) / 64);
   const int grid = n_units < WGW_MAX_BLOCKS ? n_units : WGW_MAX_BLOCKS;
@@ -239,15 +239,14 @@ static int launch_wgrad_ws_t(const float* big, const float* small, float* dw, fl
   hipLaunchKernelGGL(k_wgrad32ws<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, n_units);
 #endif
   DVAE_CHECK_LAUNCH();
-  if (partial_only) return 0;
   return launch_wgrad32_reduce(ws, dw, db, bias_from_big, grid, s);
 }
 
 // NHWC on both sides, Hs in {8, 16}; returns 1 if not applicable
 int launch_wgrad_mfma32_ws(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N, int Hs,
-                           float* ws, hipStream_t s, bool partial_only) {
-  if (Hs == 16) return launch_wgrad_ws_t<16>(big, small, dw, db, bias_from_big, N, ws, s, partial_only);
-  if (Hs == 8) return launch_wgrad_ws_t<8>(big, small, dw, db, bias_from_big, N, ws, s, partial_only);
+                           float* ws, hipStream_t s) {
+  if (Hs == 16) return launch_wgrad_ws_t<16>(big, small, dw, db, bias_from_big, N, ws, s);
+  if (Hs == 8) return launch_wgrad_ws_t<8>(big, small, dw, db, bias_from_big, N, ws, s);
   return 1;
 }
 

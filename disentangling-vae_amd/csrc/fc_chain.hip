@@ -1,0 +1,500 @@
+// The fully-connected core of the Burgess VAE as ONE launch per direction:
+//   forward : lin1 -> lin2 -> mu_logvar_gen -> reparameterise (+ per-dim KL partials) -> lin1 -> lin2 -> lin3
+//             (encoders.py:81-87, vae.py:52-71, losses.py:452-480, decoders.py:71-73)
+//   backward: the mirror chain of input gradients with the ReLU masks of the saved activations and the reparameterisation /
+//             KL backward in the middle (training.py:157 through the same lines).
+// Why: as separate launches these are 7 + 7 kernels of 4-11 us each at ANY batch size (profiles/r02_final_kbench*.txt: the
+// arithmetic is < 1 us, the rest is launch + dependent-load latency); they are the longest part of the latency chain that
+// bounds the step at the 128 images per GPU of the 8-GPU headline configuration (profiles/r02_final_timeline_b128.md).
+//
+// Formulation.  Batch rows are independent, so a workgroup (4 waves, one per SIMD) owns FCC_R = 8 rows and walks the whole
+// chain with the activations in LDS; nothing but the weights is read from memory between the first and the last layer, and
+// the weight streams do not depend on the data, so they are prefetched across layer boundaries (8 chunks in flight per
+// wave).  A layer is  y[8][O] = x[8][C] W  on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks per instruction =
+// 4 batch rows x 64 output columns per wave, one contraction step; two row groups share the B operand.  The same 64
+// FLOP/clk/SIMD as the large MFMA shapes but with M = 4, so 8 rows waste nothing (a 16x16x4 tile would idle half of the
+// matrix core, a 32x32x2 tile three quarters).  B operand: the lane's output column, four contraction steps per 16-byte
+// load from the k-chunked images of dvae_stage_weights ([C/4][O][4]: a wave's load = 1 KB contiguous).  A operand: one
+// broadcast ds_read_b128 per row group and 4 steps.  Per 4 steps a wave issues 1 global load, 2 LDS reads and 8 MFMAs
+// (64 matrix-core cycles per KB of weights): the launch is bound by the CU's L2 -> register bandwidth (1.6 MB of weights
+// per workgroup per direction), ~10-15 us at any batch size up to 2048 rows (256 workgroups).
+// Exact fp32 (k-ordered fmaf chains per accumulator; two accumulators per output, even / odd steps, summed at the end).
+#include "common.h"
+
+namespace dvae {
+
+#define FCC_R 8
+#define FCC_XS 516        // LDS row stride of an activation tile (floats): rows r, r+1 are 4 banks apart -> the four distinct
+                          // 16-byte addresses of a broadcast ds_read_b128 never share a bank
+#define FCC_HID 256
+#define FCC_FLAT 512
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  // A: lane l -> (block l/4, row l%4); B: lane l -> (block l/4, column l%4); D[v] on lane l = (block l/4, row v, column l%4)
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+// accumulators of one 64-column group: [row group 0-3 / 4-7][even / odd contraction step]
+struct Acc8 { f32x4 a[2][2]; };
+__device__ __forceinline__ void acc_zero(Acc8& c) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) c.a[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// the lane's column, rows 0..7
+__device__ __forceinline__ void acc_rows(const Acc8& c, float (&v)[8]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const f32x4 s = c.a[g][0] + c.a[g][1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[4 * g + r] = s[r];
+  }
+}
+
+template <int DEPTH, int NG>
+struct Ring { f32x4 v[DEPTH][NG]; };
+
+// first DEPTH chunks of a weight stream: wp = image + (lane's column) * 4, chunk c of group g at wp + g*gstride + c*cstride
+template <int DEPTH, int NG, int NCH>
+__device__ __forceinline__ void ring_fill(Ring<DEPTH, NG>& ring, const float* __restrict__ wp, int gstride, int cstride) {
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const int c = d < NCH ? d : NCH - 1;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) ring.v[d][g] = *reinterpret_cast<const f32x4*>(wp + g * gstride + c * cstride);
+  }
+}
+
+__device__ __forceinline__ void mac_chunk(const f32x4 a0, const f32x4 a1, const f32x4 w, Acc8& acc) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    acc.a[0][j & 1] = mfma4(a0[j], w[j], acc.a[0][j & 1]);
+    acc.a[1][j & 1] = mfma4(a1[j], w[j], acc.a[1][j & 1]);
+  }
+}
+
+// NCH chunks (4 contraction steps each) of NG column groups.  `ring` holds chunks 0..DEPTH-1 on entry; while the last DEPTH
+// chunks are consumed the first chunks of the NEXT layer's stream are requested into `nring` (NGN = 0: none), so a layer
+// boundary costs no exposed weight latency.  xr = activation tile + (lane & 3) * FCC_XS (row group 1 is 4 rows further).
+template <int DEPTH, int NCH, int NG, int NCHN, int NGN>
+__device__ __forceinline__ void gemm_run(Ring<DEPTH, NG>& ring, const float* __restrict__ wp, int gstride, int cstride,
+                                         const float* xr, Acc8 (&acc)[NG], Ring<DEPTH, (NGN > 0 ? NGN : 1)>& nring,
+                                         const float* __restrict__ wn, int gstride_n, int cstride_n) {
+  static_assert(NCH % DEPTH == 0, "chunk count must be a multiple of the ring depth");
+  // A operands one chunk ahead (register ping-pong): the LDS latency hides under the 8 MFMAs of the current chunk.  The
+  // read for chunk NCH lands in the tile row's padding (FCC_XS >= C + 4) and is never used.
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(xr);
+  f32x4 a1 = *reinterpret_cast<const f32x4*>(xr + 4 * FCC_XS);
+  for (int c0 = 0; c0 < NCH - DEPTH; c0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int c = c0 + d;
+      f32x4 w[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        w[g] = ring.v[d][g];
+        ring.v[d][g] = *reinterpret_cast<const f32x4*>(wp + g * gstride + (c + DEPTH) * cstride);
+      }
+      const f32x4 n0 = *reinterpret_cast<const f32x4*>(xr + 4 * (c + 1));
+      const f32x4 n1 = *reinterpret_cast<const f32x4*>(xr + 4 * FCC_XS + 4 * (c + 1));
+#pragma unroll
+      for (int g = 0; g < NG; ++g) mac_chunk(a0, a1, w[g], acc[g]);
+      a0 = n0; a1 = n1;
+      // pin the software pipeline: the re-request of the slot just consumed stays HERE (DEPTH chunks ahead of its use) and
+      // the next chunk's operand reads precede this chunk's MFMAs; left alone the scheduler gathers all DEPTH loads at the
+      // end of the loop body, where their latency is fully exposed
+      __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);       // NG VMEM reads
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // 2 DS reads (next chunk)
+      __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);   // 8 MFMAs per column group (this chunk)
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const int c = NCH - DEPTH + d;
+    if (NGN > 0) {
+      const int cn = d < NCHN ? d : NCHN - 1;
+#pragma unroll
+      for (int g = 0; g < NGN; ++g) nring.v[d][g] = *reinterpret_cast<const f32x4*>(wn + g * gstride_n + cn * cstride_n);
+    }
+    const f32x4 n0 = *reinterpret_cast<const f32x4*>(xr + 4 * (c + 1));
+    const f32x4 n1 = *reinterpret_cast<const f32x4*>(xr + 4 * FCC_XS + 4 * (c + 1));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) mac_chunk(a0, a1, ring.v[d][g], acc[g]);
+    a0 = n0; a1 = n1;
+    __builtin_amdgcn_sched_group_barrier(0x020, NGN, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);
+  }
+}
+
+// layer with a SMALL contraction (C <= 32, run-time: the latent side): chunks 0..c4-1 of one column group, all requested at
+// once (c4 <= 8)
+__device__ __forceinline__ void gemm_small_c(const float* __restrict__ wp, int cstride, int c4, const float* xr, Acc8& acc) {
+  f32x4 w[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) w[c] = *reinterpret_cast<const f32x4*>(wp + (c < c4 ? c : 0) * cstride);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c < c4) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(xr + 4 * FCC_XS + 4 * c);
+      mac_chunk(a0, a1, w[c], acc);
+    }
+  }
+}
+
+// 8 x C rows of a row-major [n][C] tensor -> LDS tile (zero rows beyond n)
+template <int C>
+__device__ __forceinline__ void load_rows(const float* __restrict__ x, int row0, int n, float* tile, int tid) {
+  constexpr int Q = C / 4;                      // 16-byte chunks per row
+  constexpr int NP = FCC_R * Q / 256;
+  f32x4 v[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int idx = tid + 256 * p;
+    const int r = idx / Q, q = idx % Q;
+    v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row0 + r < n) v[p] = *reinterpret_cast<const f32x4*>(x + (long)(row0 + r) * C + q * 4);
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int idx = tid + 256 * p;
+    *reinterpret_cast<f32x4*>(tile + (idx / Q) * FCC_XS + (idx % Q) * 4) = v[p];
+  }
+}
+
+struct FwdArgs { dvae_fc_chain_fwd_args a; };
+struct BwdArgs { dvae_fc_chain_bwd_args a; };
+
+// ---------------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(256) void k_fc_chain_fwd(const FwdArgs P) {
+  const dvae_fc_chain_fwd_args& a = P.a;
+  __shared__ __attribute__((aligned(16))) float tA[FCC_R * FCC_XS];
+  __shared__ __attribute__((aligned(16))) float tB[FCC_R * FCC_XS];
+  __shared__ float red[4][FCC_R][64];
+  __shared__ float mlt[FCC_R][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * FCC_R;
+  const int D = a.D, D2 = 2 * a.D;
+  const int col = wv * 64 + lane;                   // this lane's output column in a 256-wide layer
+  const int xo = (lane & 3) * FCC_XS;
+  constexpr int CS = FCC_HID * 4;                   // chunk stride of a 256-wide image
+
+  Ring<8, 1> r1, r2;
+  Ring<8, 1> dummy;
+  Ring<16, 1> dummy16;
+  ring_fill<8, 1, 128>(r1, a.w_e1 + col * 4, 0, CS);
+  load_rows<FCC_FLAT>(a.a_flat, row0, a.n_enc, tA, tid);
+  const float be1 = a.b_e1[col], be2 = a.b_e2[col];
+  __syncthreads();
+
+  float v[8];
+  // ---- encoder lin1: 512 -> 256, ReLU
+  {
+    Acc8 acc[1];
+    acc_zero(acc[0]);
+    gemm_run<8, 128, 1, 64, 1>(r1, a.w_e1 + col * 4, 0, CS, tA + xo, acc, r2, a.w_e2 + col * 4, 0, CS);
+    acc_rows(acc[0], v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r] = fmaxf(v[r] + be1, 0.f);
+      tB[r * FCC_XS + col] = v[r];
+      if (row0 + r < a.n_enc) a.h1[(long)(row0 + r) * FCC_HID + col] = v[r];
+    }
+  }
+  __syncthreads();
+  // ---- encoder lin2: 256 -> 256, ReLU; meanwhile request this wave's slice of mu_logvar_gen (contraction split over the waves)
+  Ring<16, 1> rml;
+  {
+    Acc8 acc[1];
+    acc_zero(acc[0]);
+    gemm_run<8, 64, 1, 0, 0>(r2, a.w_e2 + col * 4, 0, CS, tB + xo, acc, dummy, nullptr, 0, 0);
+    const int cml = lane < D2 ? lane : D2 - 1;
+    ring_fill<16, 1, 16>(rml, a.w_ml + ((long)wv * 16 * D2 + cml) * 4, 0, D2 * 4);
+    acc_rows(acc[0], v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r] = fmaxf(v[r] + be2, 0.f);
+      tA[r * FCC_XS + col] = v[r];
+      if (row0 + r < a.n_enc) a.h2[(long)(row0 + r) * FCC_HID + col] = v[r];
+    }
+  }
+  __syncthreads();
+  // ---- mu_logvar_gen: 256 -> 2D (no activation): wave w contracts k in [64w, 64w+64), partial sums through LDS
+  {
+    Acc8 acc[1];
+    acc_zero(acc[0]);
+    const int cml = lane < D2 ? lane : D2 - 1;
+    gemm_run<16, 16, 1, 0, 0>(rml, a.w_ml + ((long)wv * 16 * D2 + cml) * 4, 0, D2 * 4, tA + xo + wv * 64, acc, dummy16, nullptr, 0, 0);
+    acc_rows(acc[0], v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) red[wv][r][lane] = v[r];
+  }
+  // the decoder's first two weight streams do not depend on anything computed here: request them now
+  Ring<8, 1> rd2;
+  const bool dec = row0 < a.n_dec;                  // workgroup-uniform
+  if (dec) ring_fill<8, 1, 64>(rd2, a.w_d2 + col * 4, 0, CS);
+  __syncthreads();
+  for (int t = tid; t < FCC_R * D2; t += 256) {
+    const int r = t / D2, j = t % D2;
+    const float m = ((red[0][r][j] + red[1][r][j]) + (red[2][r][j] + red[3][r][j])) + a.b_ml[j];
+    mlt[r][j] = m;
+    if (row0 + r < a.n_enc) a.ml[(long)(row0 + r) * D2 + j] = m;
+  }
+  __syncthreads();
+  // ---- reparameterise (vae.py:66-68) + per-dim KL terms (losses.py:470); z -> tB (zero padded to a multiple of 4 columns)
+  {
+    float* klt = &red[0][0][0];                     // [8][16]
+    const int dp = (D + 3) & ~3;
+    for (int t = tid; t < FCC_R * 16; t += 256) {
+      const int r = t >> 4, d = t & 15;
+      float kl = 0.f;
+      if (d < dp) {
+        float zz = 0.f;
+        if (d < D) {
+          const float m = mlt[r][2 * d], lv = mlt[r][2 * d + 1];
+          zz = m;
+          const long o = (long)(row0 + r) * D + d;
+          if (row0 + r < a.n_enc) {
+            if (a.eps) zz = m + expf(0.5f * lv) * a.eps[o];
+            a.mu[o] = m; a.logvar[o] = lv; a.z[o] = zz;
+            if (row0 + r < a.n_kl) kl = 0.5f * (-1.f - lv + m * m + expf(lv));
+          }
+        }
+        tB[r * FCC_XS + d] = zz;
+      }
+      klt[r * 16 + d] = kl;
+    }
+    __syncthreads();
+    if (a.kl_part && tid < 16) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < FCC_R; ++r) s += klt[r * 16 + tid];
+      a.kl_part[(long)blockIdx.x * 16 + tid] = s;
+    }
+  }
+  if (!dec) return;
+  const float bd1 = a.b_d1[col], bd2 = a.b_d2[col];
+  // ---- decoder lin1: D -> 256, ReLU
+  {
+    Acc8 acc;
+    acc_zero(acc);
+    gemm_small_c(a.w_d1 + col * 4, CS, (D + 3) >> 2, tB + xo, acc);
+    acc_rows(acc, v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r] = fmaxf(v[r] + bd1, 0.f);
+      tA[r * FCC_XS + col] = v[r];
+      if (row0 + r < a.n_dec) a.d1[(long)(row0 + r) * FCC_HID + col] = v[r];
+    }
+  }
+  __syncthreads();
+  // ---- decoder lin2: 256 -> 256, ReLU
+  Ring<8, 2> rd3;
+  {
+    Acc8 acc[1];
+    acc_zero(acc[0]);
+    gemm_run<8, 64, 1, 64, 2>(rd2, a.w_d2 + col * 4, 0, CS, tA + xo, acc, rd3, a.w_d3 + col * 4, FCC_HID * 4, FCC_FLAT * 4);
+    acc_rows(acc[0], v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r] = fmaxf(v[r] + bd2, 0.f);
+      tB[r * FCC_XS + col] = v[r];
+      if (row0 + r < a.n_dec) a.d2[(long)(row0 + r) * FCC_HID + col] = v[r];
+    }
+  }
+  __syncthreads();
+  // ---- decoder lin3: 256 -> 512, ReLU (columns col and 256 + col)
+  {
+    Acc8 acc[2];
+    acc_zero(acc[0]); acc_zero(acc[1]);
+    const float b0 = a.b_d3[col], b1 = a.b_d3[FCC_HID + col];
+    gemm_run<8, 64, 2, 0, 0>(rd3, a.w_d3 + col * 4, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      acc_rows(acc[g], v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (row0 + r < a.n_dec) a.d3[(long)(row0 + r) * FCC_FLAT + g * FCC_HID + col] = fmaxf(v[r] + (g ? b1 : b0), 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+__global__ __launch_bounds__(256) void k_fc_chain_bwd(const BwdArgs P) {
+  const dvae_fc_chain_bwd_args& a = P.a;
+  __shared__ __attribute__((aligned(16))) float tA[FCC_R * FCC_XS];
+  __shared__ __attribute__((aligned(16))) float tB[FCC_R * FCC_XS];
+  __shared__ float red[4][FCC_R][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * FCC_R;
+  const int n = a.n;
+  const int D = a.D, D2 = 2 * a.D;
+  const int col = wv * 64 + lane;
+  const int xo = (lane & 3) * FCC_XS;
+  constexpr int CS = FCC_HID * 4;
+
+  Ring<8, 1> r3, r2, re2;
+  Ring<8, 1> dummy;
+  Ring<16, 1> dummy16;
+  ring_fill<8, 1, 128>(r3, a.w_d3 + col * 4, 0, CS);
+  load_rows<FCC_FLAT>(a.gd3, row0, n, tA, tid);
+  float mk[8], v[8];
+  // ReLU mask of a 256-wide layer = its saved post-activation output (zero rows beyond n: their gradients are not stored)
+  auto load_mask = [&](const float* __restrict__ act) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mk[r] = row0 + r < n ? act[(long)(row0 + r) * FCC_HID + col] : 0.f;
+  };
+  load_mask(a.d2);
+  __syncthreads();
+  // ---- decoder lin3 input gradient: 512 -> 256, mask d2
+  {
+    Acc8 acc[1];
+    acc_zero(acc[0]);
+    gemm_run<8, 128, 1, 64, 1>(r3, a.w_d3 + col * 4, 0, CS, tA + xo, acc, r2, a.w_d2 + col * 4, 0, CS);
+    acc_rows(acc[0], v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r] = mk[r] > 0.f ? v[r] : 0.f;
+      tB[r * FCC_XS + col] = v[r];
+      if (row0 + r < n) a.gd2[(long)(row0 + r) * FCC_HID + col] = v[r];
+    }
+  }
+  load_mask(a.d1);
+  __syncthreads();
+  // ---- decoder lin2 input gradient: 256 -> 256, mask d1; request this wave's slice of lin1's (256 -> D, split over the waves)
+  Ring<16, 1> r1;
+  {
+    Acc8 acc[1];
+    acc_zero(acc[0]);
+    gemm_run<8, 64, 1, 0, 0>(r2, a.w_d2 + col * 4, 0, CS, tB + xo, acc, dummy, nullptr, 0, 0);
+    const int c1 = lane < D ? lane : D - 1;
+    ring_fill<16, 1, 16>(r1, a.w_d1 + ((long)wv * 16 * D + c1) * 4, 0, D * 4);
+    acc_rows(acc[0], v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r] = mk[r] > 0.f ? v[r] : 0.f;
+      tA[r * FCC_XS + col] = v[r];
+      if (row0 + r < n) a.gd1[(long)(row0 + r) * FCC_HID + col] = v[r];
+    }
+  }
+  __syncthreads();
+  // ---- decoder lin1 input gradient: 256 -> D (dL/dz through the decoder)
+  {
+    Acc8 acc[1];
+    acc_zero(acc[0]);
+    const int c1 = lane < D ? lane : D - 1;
+    gemm_run<16, 16, 1, 0, 0>(r1, a.w_d1 + ((long)wv * 16 * D + c1) * 4, 0, D * 4, tA + xo + wv * 64, acc, dummy16, nullptr, 0, 0);
+    acc_rows(acc[0], v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) red[wv][r][lane] = v[r];
+  }
+  ring_fill<8, 1, 64>(re2, a.w_e2 + col * 4, 0, CS);      // encoder lin2's stream: independent of the latent glue below
+  load_mask(a.h2);
+  __syncthreads();
+  // ---- reparameterisation + KL backward (k_reparam_kl_bwd's arithmetic) -> dml[8][2D] (interleaved) -> tB, zero padded
+  {
+    const float klw = a.scal[DVAE_S_KLW] * a.coef[DVAE_C_INV_B];
+    const int dp2 = (D2 + 3) & ~3;
+    for (int t = tid; t < FCC_R * 32; t += 256) {
+      const int r = t >> 5, d = t & 31;
+      if (d < D) {
+        float dm = 0.f, dl = 0.f;
+        if (row0 + r < n) {
+          const long o = (long)(row0 + r) * D + d;
+          float g = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
+          if (a.dz) a.dz[o] = g;
+          if (a.dz2) g += a.dz2[o];
+          if (a.dz3) g += a.dz3[o];
+          const float m = a.mu[o], lv = a.logvar[o];
+          dm = g + klw * m;
+          dl = klw * 0.5f * (expf(lv) - 1.f);
+          if (a.eps) dl += g * a.eps[o] * 0.5f * expf(0.5f * lv);
+          if (a.dmu_x) dm += a.dmu_x[o];
+          if (a.dlv_x) dl += a.dlv_x[o];
+          a.dml[(long)(row0 + r) * D2 + 2 * d] = dm;
+          a.dml[(long)(row0 + r) * D2 + 2 * d + 1] = dl;
+        }
+        tB[r * FCC_XS + 2 * d] = dm;
+        tB[r * FCC_XS + 2 * d + 1] = dl;
+      }
+    }
+    if (tid < FCC_R * 4) {                           // padding columns D2 .. dp2-1 (at most 2: D2 is even)
+      const int r = tid >> 2, c = D2 + (tid & 3);
+      if (c < dp2) tB[r * FCC_XS + c] = 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- mu_logvar_gen input gradient: 2D -> 256, mask h2
+  {
+    Acc8 acc;
+    acc_zero(acc);
+    gemm_small_c(a.w_ml + col * 4, CS, (D2 + 3) >> 2, tB + xo, acc);
+    acc_rows(acc, v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r] = mk[r] > 0.f ? v[r] : 0.f;
+      tA[r * FCC_XS + col] = v[r];
+      if (row0 + r < n) a.gh2[(long)(row0 + r) * FCC_HID + col] = v[r];
+    }
+  }
+  load_mask(a.h1);
+  __syncthreads();
+  // ---- encoder lin2 input gradient: 256 -> 256, mask h1
+  Ring<8, 2> re1;
+  {
+    Acc8 acc[1];
+    acc_zero(acc[0]);
+    gemm_run<8, 64, 1, 64, 2>(re2, a.w_e2 + col * 4, 0, CS, tA + xo, acc, re1, a.w_e1 + col * 4, FCC_HID * 4, FCC_FLAT * 4);
+    acc_rows(acc[0], v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r] = mk[r] > 0.f ? v[r] : 0.f;
+      tB[r * FCC_XS + col] = v[r];
+      if (row0 + r < n) a.gh1[(long)(row0 + r) * FCC_HID + col] = v[r];
+    }
+  }
+  // masks of the 512-wide output: the conv stack's flattened activation (encoders.py:80), columns col and 256 + col
+  float mk2[2][8];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mk2[g][r] = row0 + r < n ? a.a_flat[(long)(row0 + r) * FCC_FLAT + g * FCC_HID + col] : 0.f;
+  __syncthreads();
+  // ---- encoder lin1 input gradient: 256 -> 512, mask a_flat
+  {
+    Acc8 acc[2];
+    acc_zero(acc[0]); acc_zero(acc[1]);
+    gemm_run<8, 64, 2, 0, 0>(re1, a.w_e1 + col * 4, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      acc_rows(acc[g], v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (row0 + r < n) a.ga_flat[(long)(row0 + r) * FCC_FLAT + g * FCC_HID + col] = mk2[g][r] > 0.f ? v[r] : 0.f;
+    }
+  }
+}
+
+int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s) {
+  FwdArgs P;
+  P.a = *a;
+  const int nblk = (a->n_enc + FCC_R - 1) / FCC_R;
+  hipLaunchKernelGGL(k_fc_chain_fwd, dim3(nblk), dim3(256), 0, s, P);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, hipStream_t s) {
+  BwdArgs P;
+  P.a = *a;
+  const int nblk = (a->n + FCC_R - 1) / FCC_R;
+  hipLaunchKernelGGL(k_fc_chain_bwd, dim3(nblk), dim3(256), 0, s, P);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace dvae

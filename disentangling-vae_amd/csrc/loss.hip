@@ -46,14 +46,31 @@ __global__ __launch_bounds__(256) void k_reparam_kl_fwd(const float* __restrict_
   if (tid < 16) kl_part[blockIdx.x * 16 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
-__global__ void k_reparam_kl_finish(const float* __restrict__ kl_part, int nblk, float* __restrict__ kl_dim,
-                                    const float* __restrict__ coef, int D) {
-  const int d = threadIdx.x;
-  if (d < 16) {
-    float v = 0.f;
-    for (int g = 0; g < nblk; ++g) v += kl_part[g * 16 + d];
-    kl_dim[d] = d < D ? v * coef[DVAE_C_INV_B] : 0.f;
+// fixed-order sum of `nblk` per-workgroup KL partial blocks ([nblk][16] floats) by a 256-thread workgroup: thread t adds
+// the blocks g = t/16, t/16 + 16, ... of dimension t%16, then 16 threads add the 16 strided sums.  Returns the total in
+// threads 0..15 (dimension = thread index); `klred` = 256 floats of LDS.  The order depends on nblk only, so every
+// consumer of the same partials (the finishing kernel, the one-launch loss epilogue) produces the same bits.
+__device__ __forceinline__ float kl_blocks_sum(const float* __restrict__ part, int nblk, float* klred) {
+  const int tid = threadIdx.x;
+  const int d = tid & 15, g0 = tid >> 4;
+  float v = 0.f;
+  for (int g = g0; g < nblk; g += 16) v += part[g * 16 + d];
+  klred[g0 * 16 + d] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (tid < 16) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += klred[q * 16 + tid];
   }
+  return t;
+}
+
+__global__ __launch_bounds__(256) void k_reparam_kl_finish(const float* __restrict__ kl_part, int nblk, float* __restrict__ kl_dim,
+                                                           const float* __restrict__ coef, int D) {
+  __shared__ float klred[256];
+  const float t = kl_blocks_sum(kl_part, nblk, klred);
+  const int d = threadIdx.x;
+  if (d < 16) kl_dim[d] = d < D ? t * coef[DVAE_C_INV_B] : 0.f;
 }
 
 __global__ void k_reparam_kl_bwd(const float* __restrict__ dz, const float* __restrict__ dz2,
@@ -383,7 +400,10 @@ __device__ __forceinline__ void loss_pack_body(const float* __restrict__ rec_par
                                                const float* __restrict__ disc_sums, float* packed,
                                                int kl_blocks, float kl_scale) {
   __shared__ float red[5][4];
+  __shared__ float klred[256];
   const int tid = threadIdx.x;
+  // un-finished per-workgroup KL partials (dvae_reparam_kl_fwd without coef, dvae_fc_chain_fwd): same order as k_reparam_kl_finish
+  const float klsum = (kl_dim && kl_blocks > 0) ? kl_blocks_sum(kl_dim + 16, kl_blocks, klred) : 0.f;
   float r = 0.f;
   for (int k = tid; k < DVAE_REC_NPART; k += 256) r += rec_partials[k];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -404,17 +424,10 @@ __device__ __forceinline__ void loss_pack_body(const float* __restrict__ rec_par
     const float t = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
     packed[tid == 0 ? 0 : 16 + tid] = t;          // [0] rec, [17..20] rowstat sums
   }
-  if (tid >= 32 && tid < 32 + 16) {
-    const int d = tid - 32;
+  if (tid < 16) {
+    const int d = tid;
     float v = 0.f;
-    if (kl_dim && d < D) {
-      if (kl_blocks > 0) {               // un-finished per-workgroup partials of k_reparam_kl_fwd (same order as k_reparam_kl_finish)
-        for (int g = 0; g < kl_blocks; ++g) v += kl_dim[16 + g * 16 + d];
-        v *= kl_scale;
-      } else {
-        v = kl_dim[d];
-      }
-    }
+    if (kl_dim && d < D) v = kl_blocks > 0 ? klsum * kl_scale : kl_dim[d];
     packed[1 + d] = v;
   }
   if (tid >= 64 && tid < 64 + 3) packed[21 + (tid - 64)] = disc_sums ? disc_sums[tid - 64] : 0.f;
@@ -540,13 +553,12 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                           const float* coef, int B, int D, hipStream_t s) {
   // kl_dim[16..16+RK_BLOCKS*16) is used as scratch for the per-workgroup partial sums
-  int blocks = (B + 255) / 256;
-  if (blocks > RK_BLOCKS) blocks = RK_BLOCKS;
+  const int blocks = reparam_kl_blocks(B);
   float* part = kl_dim ? kl_dim + 16 : nullptr;
   hipLaunchKernelGGL(k_reparam_kl_fwd, dim3(blocks), dim3(256), 0, s, ml, eps, mu, logvar, z, part, B, D);
   DVAE_CHECK_LAUNCH();
   if (kl_dim && coef) {      // coef == NULL: the raw partials stay in kl_dim[16..]; dvae_loss_epilogue finishes them
-    hipLaunchKernelGGL(k_reparam_kl_finish, dim3(1), dim3(64), 0, s, part, blocks, kl_dim, coef, D);
+    hipLaunchKernelGGL(k_reparam_kl_finish, dim3(1), dim3(256), 0, s, part, blocks, kl_dim, coef, D);
     DVAE_CHECK_LAUNCH();
   }
   return 0;
@@ -623,14 +635,20 @@ int launch_loss_pack(const float* rec_partials, const float* kl_dim, int D, cons
   return 0;
 }
 
-int launch_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_rows, int D, const float* rowstats,
+int reparam_kl_blocks(int B) {            // the grid of launch_reparam_kl_fwd = the number of partial blocks it leaves
+  int blocks = (B + 255) / 256;
+  return blocks > RK_BLOCKS ? RK_BLOCKS : blocks;
+}
+
+int launch_kl_finish(float* kl_dim, int kl_blocks, const float* coef, int D, hipStream_t s) {
+  hipLaunchKernelGGL(k_reparam_kl_finish, dim3(1), dim3(256), 0, s, kl_dim + 16, kl_blocks, kl_dim, coef, D);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_blocks, int D, const float* rowstats,
                          int Bl, const float* disc_sums, int Bg, const float* coef, float* packed, float* scal,
                          hipStream_t s) {
-  int kl_blocks = 0;
-  if (kl_rows > 0) {                     // same grid as launch_reparam_kl_fwd
-    kl_blocks = (kl_rows + 255) / 256;
-    if (kl_blocks > RK_BLOCKS) kl_blocks = RK_BLOCKS;
-  }
   hipLaunchKernelGGL(k_loss_epilogue, dim3(1), dim3(256), 0, s, kind, rec_partials, kl_dim, kl_blocks, D, rowstats, Bl,
                      disc_sums, Bg, coef, packed, scal);
   DVAE_CHECK_LAUNCH();

@@ -37,9 +37,13 @@ SIGNATURES = {
     "dvae_convT4s2_wgrad": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "dvae_convT4s2_sigmoid_recon_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "dvae_conv_wgrad_ws_floats": [],
-    "dvae_conv4s2_wgrad_partial": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p],
-    "dvae_convT4s2_wgrad_partial": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p],
-    "dvae_conv_wgrad_reduce_grouped": [_p, _i, _p],
+    "dvae_stage_weights": [_p, _i, _p, _i, _p, _p, _p],
+    "dvae_conv32_down": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "dvae_conv32_up": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "dvae_fc_chain_fwd": [_p, _p],
+    "dvae_fc_chain_bwd": [_p, _p],
+    "dvae_reparam_kl_blocks": [_i],
+    "dvae_kl_finish": [_p, _i, _p, _i, _p],
     "dvae_u8_to_f32": [_p, _p, _l, _p],
     "dvae_u8_fused_supported": [_i, _i, _i],
     "dvae_conv4s2_fwd_u8": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -85,28 +89,47 @@ _RESTYPE = {"dvae_last_error": ctypes.c_char_p, "dvae_conv_wgrad_ws_floats": cty
 
 
 FCW_MAX = 8
+KL_MAX_BLOCKS = 1024                 # DVAE_KL_MAX_BLOCKS
+KL_FLOATS = 16 + KL_MAX_BLOCKS * 16   # DVAE_KL_FLOATS
+FC_CHAIN_ROWS = 8                    # batch rows per workgroup of dvae_fc_chain_*: ceil(n / 8) KL partial blocks
+
+
+class ConvImageDesc(ctypes.Structure):
+    """dvae_conv_image_desc (include/dvae_hip.h)."""
+    _fields_ = [("w", _p), ("img_down", _p), ("img_up", _p)]
+
+
+class FcImageDesc(ctypes.Structure):
+    """dvae_fc_image_desc (include/dvae_hip.h)."""
+    _fields_ = [("w", _p), ("img_fwd", _p), ("img_bwd", _p), ("N", _i), ("K", _i)]
+
+
+class FcChainFwdArgs(ctypes.Structure):
+    """dvae_fc_chain_fwd_args (include/dvae_hip.h)."""
+    _fields_ = [(n_, _p) for n_ in ("a_flat", "w_e1", "w_e2", "w_ml", "w_d1", "w_d2", "w_d3", "b_e1", "b_e2", "b_ml",
+                                    "b_d1", "b_d2", "b_d3", "eps", "h1", "h2", "ml", "mu", "logvar", "z", "kl_part",
+                                    "d1", "d2", "d3")] + [(n_, _i) for n_ in ("n_enc", "n_kl", "n_dec", "D")]
+
+
+class FcChainBwdArgs(ctypes.Structure):
+    """dvae_fc_chain_bwd_args (include/dvae_hip.h)."""
+    _fields_ = [(n_, _p) for n_ in ("gd3", "w_d3", "w_d2", "w_d1", "w_ml", "w_e2", "w_e1", "d2", "d1", "h2", "h1",
+                                    "a_flat", "mu", "logvar", "eps", "dz2", "dz3", "dmu_x", "dlv_x", "scal", "coef",
+                                    "gd2", "gd1", "dz", "dml", "gh2", "gh1", "ga_flat")] + [("n", _i), ("D", _i)]
+
+
+def struct_of(cls, **kw):
+    """ctypes struct with the given fields (device pointers as ints / None, sizes as ints) -> (struct, its address).
+    Keep the struct alive while a recorded launch plan may replay the call."""
+    st = cls()
+    for k, v in kw.items():
+        setattr(st, k, v)
+    return st, ctypes.addressof(st)
 
 
 class LinearWgradDesc(ctypes.Structure):
     """dvae_linear_wgrad_desc (include/dvae_hip.h)."""
     _fields_ = [("x", _p), ("dy", _p), ("dw", _p), ("db", _p), ("M", _i), ("K", _i), ("N", _i)]
-
-
-WGR_MAX = 8
-
-
-class ConvWgradDesc(ctypes.Structure):
-    """dvae_conv_wgrad_desc (include/dvae_hip.h)."""
-    _fields_ = [("ws", _p), ("dw", _p), ("db", _p), ("N", _i), ("Cin", _i), ("H", _i), ("W", _i), ("Cout", _i),
-                ("transposed", _i)]
-
-
-def conv_wgrad_descs(problems):
-    """[(ws, dw, db, N, Cin, H, W, Cout, transposed), ...] -> (host array, its address); keep the array alive."""
-    arr = (ConvWgradDesc * len(problems))()
-    for d, vals in zip(arr, problems):
-        d.ws, d.dw, d.db, d.N, d.Cin, d.H, d.W, d.Cout, d.transposed = vals
-    return arr, ctypes.addressof(arr)
 
 
 def wgrad_descs(problems):

@@ -13,7 +13,7 @@ Reference being replaced: EncoderBurgess.forward (encoders.py:69-89), VAE.repara
 (vae.py:52-71), DecoderBurgess.forward (decoders.py:67-84) and their autograd backward
 (training.py:157).
 """
-import os
+import ctypes
 from collections import OrderedDict
 
 import torch
@@ -104,15 +104,11 @@ class ParamArena:
         return self
 
 
-_CONV_WGRAD_MAIN = os.environ.get("DVAE_CONV_WGRAD_MAIN", "0") == "1"
 # which encoder conv weight gradients the MAIN stream computes itself at the very end of the backward pass (after conv1's),
 # instead of leaving them in the side stream's queue: the side stream is the tail of the iteration (timeline:
 # profiles/r02_run9_timeline.md), the main stream is idle from the end of conv1's weight gradient to the join
-_TAIL_MAIN = [n_ for n_ in os.environ.get("DVAE_TAIL_MAIN", "conv3,conv_64").split(",") if n_]
-# 1 = conv weight gradients leave their partial sums and ONE grouped launch reduces all layers at the end of the backward
-# pass.  Measured (profiles/r02_run6_ab.txt): 8 reduce launches fewer but +1.5 % step time at B=1024 -- the per-layer
-# reductions hide in the side stream, the grouped one (137 MB of partials, ~37 us) sits on the critical path -> default 0
-_DEFER_REDUCE = os.environ.get("DVAE_DEFER_REDUCE", "0") == "1"
+# (measured -1.5 %: profiles/r02_run12_tail_ab.txt)
+_TAIL_MAIN = ("conv3", "conv_64")
 
 
 def _stream():
@@ -148,6 +144,43 @@ class _Buffers:
         self.dz = f(B, D)
 
 
+class _Images:
+    """Pre-staged weight images of one parameter placement (dvae_stage_weights): the two 64 KB LDS images of every
+    32 <-> 32 channel conv / convT layer and the k-chunked forward / input-gradient operand streams of the six FC layers, in
+    ONE device buffer, plus the host descriptor tables of the staging launch."""
+
+    FC = ["encoder.lin1", "encoder.lin2", "encoder.mu_logvar_gen", "decoder.lin1", "decoder.lin2", "decoder.lin3"]
+
+    def __init__(self, eng):
+        _lib.note_alloc()
+        arena = eng.arena
+        self.flat_ptr = arena.flat.data_ptr()
+        conv = ["encoder." + n for n in eng.enc_names[1:]] + ["decoder." + n for n in eng.dec_names]
+        sizes, off = {}, 0
+        for name in conv:
+            for kind in ("down", "up"):
+                sizes[(name, kind)] = off
+                off += 16384
+        for name in self.FC:
+            N, K = arena.shapes[name + ".weight"]
+            sizes[(name, "fwd")] = off
+            off += (K + 3) // 4 * N * 4
+            sizes[(name, "bwd")] = off
+            off += (N + 3) // 4 * K * 4
+        self.buf = torch.empty(off, dtype=torch.float32, device=arena.flat.device)
+        base = self.buf.data_ptr()
+        self.ptrs = {k: base + 4 * o for k, o in sizes.items()}
+        self.conv_descs = (_lib.ConvImageDesc * len(conv))()
+        for d, name in zip(self.conv_descs, conv):
+            d.w, d.img_down, d.img_up = ptr(arena.view(name + ".weight")), self.ptrs[(name, "down")], self.ptrs[(name, "up")]
+        self.fc_descs = (_lib.FcImageDesc * len(self.FC))()
+        for d, name in zip(self.fc_descs, self.FC):
+            N, K = arena.shapes[name + ".weight"]
+            d.w, d.img_fwd, d.img_bwd, d.N, d.K = (ptr(arena.view(name + ".weight")), self.ptrs[(name, "fwd")],
+                                                   self.ptrs[(name, "bwd")], N, K)
+        self.coef_vals = (ctypes.c_float * 8)()
+
+
 class VAEEngine:
     """Forward / backward of the Burgess VAE on one MI355X through libdvae_hip.so."""
 
@@ -165,17 +198,15 @@ class VAEEngine:
         self._bufs = {}
         self._ws = None
         self._ws_side = None
-        self._side = None      # side HIP stream: the FC weight-gradient GEMMs run beside the dgrad chain
+        self._side = None      # side HIP stream: the weight-gradient kernels run beside the dgrad chain
         # small batches: everything on the caller's stream.  Below ~256 images the iteration is bound by the latency of
         # dependent launches, a fork / join between hardware queues costs ~6 us each (5 forks + 1 join per iteration) and
         # the weight-gradient kernels that the side stream would overlap are a few microseconds long.  Set per step by the
         # loss plugins (BaseLoss._streams).
         self.single_stream = False
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
-        self._fc_descs = {}    # host descriptor arrays of the grouped launches, kept alive for recorded plans
-        self._defer_reduce = False   # conv weight gradients: partial sums now, ONE grouped reduction at the end of the backward pass
-        self._reduce_pending = []
-        self._layer_ws = {}    # one partial-sum workspace per conv layer (deferred reductions need them all alive)
+        self._fc_descs = {}    # host descriptor arrays / argument structs of launches, kept alive for recorded plans
+        self._images = None
 
     @property
     def device(self):
@@ -200,7 +231,42 @@ class VAEEngine:
             self._side = torch.cuda.Stream(device=self.device)
         return b
 
-    # ---- fork / join of the side stream (weight-gradient GEMMs of the FC layers) ----------------
+    # ---- per-step weight staging -------------------------------------------------------------------
+    @property
+    def images(self):
+        im = self._images
+        if im is None or im.flat_ptr != self.arena.flat.data_ptr():
+            im = self._images = _Images(self)
+        return im
+
+    def stage(self, coef=None, coef_host=None):
+        """ONE launch at the head of a forward pass: the LDS weight images of the 32-channel conv layers and the operand
+        streams of the FC chain are rebuilt from the current parameters (they change in optimizer.step(), training.py:158, or
+        under the caller's hands: load_state_dict, reset_parameters); `coef` (device) <- `coef_host` (8 floats) rides along
+        (= dvae_set_coef).  Everything downstream in the pass -- forward and backward -- reads the images."""
+        im = self.images
+        cv = None
+        if coef is not None:
+            for i, v in enumerate(coef_host):
+                im.coef_vals[i] = v
+            cv = ctypes.addressof(im.coef_vals)
+        call("dvae_stage_weights", ctypes.addressof(im.conv_descs), len(im.conv_descs), ctypes.addressof(im.fc_descs),
+             len(im.fc_descs), ptr(coef), cv, _stream())
+
+    def _img(self, layer, kind):
+        return self._images.ptrs[(layer, kind)]
+
+    def _args(self, key, cls, **fields):
+        """Host argument struct of a C-ABI call (cached: recorded launch plans hold its address)."""
+        ent = self._fc_descs.get(key)
+        if ent is None:
+            if len(self._fc_descs) >= 64:        # recorded plans hold the addresses of these structs: invalidate them
+                self._fc_descs.clear()
+                _lib.note_alloc()
+            ent = self._fc_descs[key] = _lib.struct_of(cls, **fields)
+        return ent[1]
+
+    # ---- fork / join of the side stream (weight-gradient kernels) ----------------------------------
     def fork_side(self):
         """Order the side stream after everything enqueued so far on the current stream.  A fork
         costs the current stream ~6 us (event signal between hardware queues, profiles/r01_run19
@@ -216,12 +282,6 @@ class VAEEngine:
     def _side_raw(self):
         return _stream() if self.single_stream else self._side.cuda_stream
 
-    def _side_wgrad(self, x, dy, dw, db, M, K, N):
-        """dw, db <- wgrad(x, dy) on the side stream (after a fork_side): overlaps with whatever the
-        current stream does next."""
-        call("dvae_linear_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(db), M, K, N, ptr(self._ws_side),
-             self._side_raw())
-
     def _side_wgrad_grouped(self, problems):
         """All FC weight gradients of `problems` = [(x, dy, dw, db, M, K, N)] (tensors) in ONE launch on the side stream
         (dvae_linear_wgrad_grouped): ~400 short-lived workgroups instead of six launches that each leave most of
@@ -235,45 +295,12 @@ class VAEEngine:
             ent = self._fc_descs[key] = _lib.wgrad_descs(key)
         call("dvae_linear_wgrad_grouped", ent[1], len(problems), self._side_raw())
 
-    def _ws_of(self, key):
-        w = self._layer_ws.get(key)
-        if w is None or w.device != self.device:
-            _lib.note_alloc()
-            w = self._layer_ws[key] = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), dtype=torch.float32, device=self.device)
-        return w
-
     def _conv_wgrad(self, fn, *args, fork=True, main=False):
         """Conv / convT weight gradient `fn(*args, ws, stream)`: off the dgrad critical path, so it
-        goes to the side stream (after a fork) and co-runs with the dgrad chain (main=True: the current stream);
-        DVAE_CONV_WGRAD_MAIN=1 keeps it on the current stream.  While reductions are deferred (tuned 64x64 geometry)
-        only the accumulation kernel runs here, into the layer's own workspace; `_reduce_convs` finishes every layer of
-        the backward pass in ONE launch (8 latency-bound ~10 us reduce kernels less on the weight-gradient stream)."""
-        on_main = main or _CONV_WGRAD_MAIN
-        if fork and not on_main:
+        goes to the side stream (after a fork) and co-runs with the dgrad chain (main=True: the current stream)."""
+        if fork and not main:
             self.fork_side()
-        stream = _stream() if on_main else self._side_raw()
-        if self._defer_reduce:
-            x, xl, dy, dyl, dw, db, N, Cin, H, W, Cout = args
-            ws = self._ws_of((fn, dw))
-            call(fn + "_partial", x, xl, dy, dyl, N, Cin, H, W, Cout, ptr(ws), stream)
-            self._reduce_pending.append((ptr(ws), dw, db, N, Cin, H, W, Cout, 1 if fn.startswith("dvae_convT") else 0))
-            return
-        call(fn, *args, ptr(self._ws if on_main else self._ws_side), stream)
-
-    def _reduce_convs(self):
-        """One launch: the fixed-order reductions of every deferred conv / convT weight gradient (current stream; the
-        side stream must have been joined)."""
-        pend, self._reduce_pending = self._reduce_pending, []
-        if not pend:
-            return
-        key = ("wgr",) + tuple(pend)
-        ent = self._fc_descs.get(key)
-        if ent is None:
-            if len(self._fc_descs) >= 64:
-                self._fc_descs.clear()
-                _lib.note_alloc()
-            ent = self._fc_descs[key] = _lib.conv_wgrad_descs(pend)
-        call("dvae_conv_wgrad_reduce_grouped", ent[1], len(pend), _stream())
+        call(fn, *args, ptr(self._ws if main else self._ws_side), _stream() if main else self._side_raw())
 
     def _join_side(self):
         if self.single_stream:
@@ -305,25 +332,38 @@ class VAEEngine:
         return buf.x_f32
 
     # ------------------------------------------------------------------ forward
-    def encode(self, x, buf, n=None):
-        """x[B,C,H,W] (NCHW; fp32, or uint8 for the fused geometry: see input()) -> buf.ml[B,2D] (interleaved mu/logvar)."""
+    def encode_convs(self, x, buf, n=None):
+        """x[B,C,H,W] (NCHW; fp32, or uint8 for the fused geometry: see input()) -> buf.a_flat[B,512]: the conv stack of
+        encoders.py:73-80.  The 32-channel layers read their pre-staged weight images (stage() must precede)."""
         s = _stream()
-        ws = ptr(self._ws)
         B = x.shape[0] if n is None else n
         c, H, _ = self.img_size
-        src, src_layout, cin, h = x, NCHW, c, H
+        src, h = x, H
         last = len(self.enc_names) - 1
         for k, (name, act) in enumerate(zip(self.enc_names, buf.enc_act)):
             # the last conv writes its 4x4x32 output NCHW = the (c,h,w) flatten order lin1 consumes
             # (encoders.py:80), straight into a_flat: no relayout pass; no conv kernel reads that tensor
             dst, dst_layout = (buf.a_flat, NCHW) if k == last else (act, NHWC)
-            if k == 0 and x.dtype == torch.uint8:
-                call("dvae_conv4s2_fwd_u8", ptr(src), ptr(self.p("encoder.%s.weight" % name)),
-                     ptr(self.p("encoder.%s.bias" % name)), ptr(dst), B, cin, h, h, HID, ACT_RELU, s)
+            lname = "encoder.%s" % name
+            if k > 0:
+                call("dvae_conv32_down", ptr(src), self._img(lname, "down"), ptr(self.p(lname + ".bias")), None, ptr(dst),
+                     dst_layout, B, h // 2, ACT_RELU, s)
+            elif x.dtype == torch.uint8:
+                call("dvae_conv4s2_fwd_u8", ptr(src), ptr(self.p(lname + ".weight")), ptr(self.p(lname + ".bias")),
+                     ptr(dst), B, c, h, h, HID, ACT_RELU, s)
             else:
-                call("dvae_conv4s2_fwd", ptr(src), src_layout, ptr(self.p("encoder.%s.weight" % name)),
-                     ptr(self.p("encoder.%s.bias" % name)), ptr(dst), dst_layout, B, cin, h, h, HID, ACT_RELU, s)
-            src, src_layout, cin, h = act, NHWC, HID, h // 2
+                call("dvae_conv4s2_fwd", ptr(src), NCHW, ptr(self.p(lname + ".weight")), ptr(self.p(lname + ".bias")),
+                     ptr(dst), dst_layout, B, c, h, h, HID, ACT_RELU, s)
+            src, h = act, h // 2
+
+    def encode(self, x, buf, n=None):
+        """x -> buf.ml[B,2D] (interleaved mu/logvar), layer by layer (the autograd-compatible entry points; the native
+        training step runs the FC layers as one launch: fc_chain_fwd)."""
+        s = _stream()
+        ws = ptr(self._ws)
+        B = x.shape[0] if n is None else n
+        self.stage()
+        self.encode_convs(x, buf, n)
         call("dvae_linear_fwd", ptr(buf.a_flat), ptr(self.p("encoder.lin1.weight")), ptr(self.p("encoder.lin1.bias")),
              ptr(buf.h1), B, HID * 16, HIDDEN_DIM, ACT_RELU, ws, s)
         call("dvae_linear_fwd", ptr(buf.h1), ptr(self.p("encoder.lin2.weight")), ptr(self.p("encoder.lin2.bias")),
@@ -336,26 +376,61 @@ class VAEEngine:
         call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(kl_dim),
              ptr(coef), B, self.latent_dim, _stream())
 
-    def decode(self, z, buf, n=None, fuse_loss=None):
-        """z[B,D] -> buf.recon[B,C,H,W] (NCHW, post-sigmoid).  fuse_loss = (target, dist_code, coef,
-        partials): the last layer also evaluates the reconstruction likelihood against `target`
-        (partial sums -> partials) and writes dLoss/dlogit into buf.g_logit in the same pass."""
+    @staticmethod
+    def kl_blocks(n_enc):
+        """Number of KL partial blocks fc_chain_fwd leaves at kl_dim + 16 (dvae_loss_epilogue / dvae_kl_finish argument)."""
+        return (n_enc + _lib.FC_CHAIN_ROWS - 1) // _lib.FC_CHAIN_ROWS
+
+    def fc_chain_fwd(self, buf, eps, kl_dim, n_enc, n_kl=None, n_dec=None):
+        """buf.a_flat -> h1, h2, ml, mu, logvar, z (rows < n_enc; KL partial blocks from rows < n_kl at kl_dim + 16) and
+        d1, d2, d3 (rows < n_dec) in ONE launch (dvae_fc_chain_fwd): encoders.py:81-87, vae.py:52-71, losses.py:470,
+        decoders.py:71-73.  eps [n_enc, D] or None (z = mu)."""
+        n_kl = n_enc if n_kl is None else n_kl
+        n_dec = n_enc if n_dec is None else n_dec
+        if n_enc > _lib.FC_CHAIN_ROWS * _lib.KL_MAX_BLOCKS:
+            raise _lib.DvaeHipError("fc_chain_fwd: at most %d rows per launch" % (_lib.FC_CHAIN_ROWS * _lib.KL_MAX_BLOCKS))
+        P, I = self.p, self._img
+        addr = self._args(("fcf", id(buf), ptr(eps), ptr(kl_dim), n_enc, n_kl, n_dec, self._images.buf.data_ptr()),
+                          _lib.FcChainFwdArgs, a_flat=ptr(buf.a_flat),
+                          w_e1=I("encoder.lin1", "fwd"), w_e2=I("encoder.lin2", "fwd"), w_ml=I("encoder.mu_logvar_gen", "fwd"),
+                          w_d1=I("decoder.lin1", "fwd"), w_d2=I("decoder.lin2", "fwd"), w_d3=I("decoder.lin3", "fwd"),
+                          b_e1=ptr(P("encoder.lin1.bias")), b_e2=ptr(P("encoder.lin2.bias")),
+                          b_ml=ptr(P("encoder.mu_logvar_gen.bias")), b_d1=ptr(P("decoder.lin1.bias")),
+                          b_d2=ptr(P("decoder.lin2.bias")), b_d3=ptr(P("decoder.lin3.bias")), eps=ptr(eps),
+                          h1=ptr(buf.h1), h2=ptr(buf.h2), ml=ptr(buf.ml), mu=ptr(buf.mu), logvar=ptr(buf.logvar), z=ptr(buf.z),
+                          kl_part=None if kl_dim is None else ptr(kl_dim) + 64, d1=ptr(buf.d1), d2=ptr(buf.d2), d3=ptr(buf.d3),
+                          n_enc=n_enc, n_kl=n_kl, n_dec=n_dec, D=self.latent_dim)
+        call("dvae_fc_chain_fwd", addr, _stream())
+
+    def fc_chain_bwd(self, buf, eps, dz2, dz3, dmu_x, dlv_x, scal, coef, n):
+        """buf.gd3 -> gd2, gd1, dz, dml, gh2, gh1, ga_flat (rows < n) in ONE launch (dvae_fc_chain_bwd): the input gradients
+        of the six FC layers with dvae_reparam_kl_bwd's arithmetic in the middle (training.py:157)."""
+        I = self._img
+        addr = self._args(("fcb", id(buf), ptr(eps), ptr(dz2), ptr(dz3), ptr(dmu_x), ptr(dlv_x), ptr(scal), ptr(coef), n,
+                           self._images.buf.data_ptr()),
+                          _lib.FcChainBwdArgs, gd3=ptr(buf.gd3),
+                          w_d3=I("decoder.lin3", "bwd"), w_d2=I("decoder.lin2", "bwd"), w_d1=I("decoder.lin1", "bwd"),
+                          w_ml=I("encoder.mu_logvar_gen", "bwd"), w_e2=I("encoder.lin2", "bwd"), w_e1=I("encoder.lin1", "bwd"),
+                          d2=ptr(buf.d2), d1=ptr(buf.d1), h2=ptr(buf.h2), h1=ptr(buf.h1), a_flat=ptr(buf.a_flat),
+                          mu=ptr(buf.mu), logvar=ptr(buf.logvar), eps=ptr(eps), dz2=ptr(dz2), dz3=ptr(dz3),
+                          dmu_x=ptr(dmu_x), dlv_x=ptr(dlv_x), scal=ptr(scal), coef=ptr(coef),
+                          gd2=ptr(buf.gd2), gd1=ptr(buf.gd1), dz=ptr(buf.dz), dml=ptr(buf.dml), gh2=ptr(buf.gh2),
+                          gh1=ptr(buf.gh1), ga_flat=ptr(buf.ga_flat), n=n, D=self.latent_dim)
+        call("dvae_fc_chain_bwd", addr, _stream())
+
+    def decode_convs(self, buf, n, fuse_loss=None):
+        """buf.d3[B,512] -> buf.recon[B,C,H,W] (NCHW, post-sigmoid): the convT stack of decoders.py:74-82.
+        fuse_loss = (target, dist_code, coef, partials): the last layer also evaluates the reconstruction likelihood
+        against `target` (partial sums -> partials) and writes dLoss/dlogit into buf.g_logit in the same pass."""
         s = _stream()
-        ws = ptr(self._ws)
-        B = z.shape[0] if n is None else n
-        D = self.latent_dim
-        call("dvae_linear_fwd", ptr(z), ptr(self.p("decoder.lin1.weight")), ptr(self.p("decoder.lin1.bias")),
-             ptr(buf.d1), B, D, HIDDEN_DIM, ACT_RELU, ws, s)
-        call("dvae_linear_fwd", ptr(buf.d1), ptr(self.p("decoder.lin2.weight")), ptr(self.p("decoder.lin2.bias")),
-             ptr(buf.d2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, ws, s)
-        call("dvae_linear_fwd", ptr(buf.d2), ptr(self.p("decoder.lin3.weight")), ptr(self.p("decoder.lin3.bias")),
-             ptr(buf.d3), B, HIDDEN_DIM, HID * 16, ACT_RELU, ws, s)
+        B = n
         # lin3's output [B, 32*4*4] in (c,h,w) order IS the NCHW 4x4x32 input of the first convT
         # (decoders.py:74): read as such, no relayout pass
         src, src_layout, h = buf.d3, NCHW, 4
         for name, act in zip(self.dec_names, buf.dec_act):
-            call("dvae_convT4s2_fwd", ptr(src), src_layout, ptr(self.p("decoder.%s.weight" % name)),
-                 ptr(self.p("decoder.%s.bias" % name)), ptr(act), NHWC, B, HID, h, h, HID, ACT_RELU, s)
+            lname = "decoder.%s" % name
+            call("dvae_conv32_up", ptr(src), src_layout, self._img(lname, "up"), ptr(self.p(lname + ".bias")), None, ptr(act),
+                 B, h, ACT_RELU, s)
             src, src_layout, h = act, NHWC, h * 2
         c = self.img_size[0]
         if fuse_loss is None:
@@ -372,20 +447,34 @@ class VAEEngine:
                      ptr(self.p("decoder.convT3.bias")), ptr(target), ptr(buf.recon), ptr(buf.g_logit), dist_code,
                      ptr(coef), ptr(partials), B, HID, h, h, c, s)
 
+    def decode(self, z, buf, n=None, fuse_loss=None, staged=False):
+        """z[B,D] -> buf.recon, layer by layer (decoders.py:67-84; the autograd-compatible entry points)."""
+        s = _stream()
+        ws = ptr(self._ws)
+        B = z.shape[0] if n is None else n
+        D = self.latent_dim
+        if not staged:
+            self.stage()
+        call("dvae_linear_fwd", ptr(z), ptr(self.p("decoder.lin1.weight")), ptr(self.p("decoder.lin1.bias")),
+             ptr(buf.d1), B, D, HIDDEN_DIM, ACT_RELU, ws, s)
+        call("dvae_linear_fwd", ptr(buf.d1), ptr(self.p("decoder.lin2.weight")), ptr(self.p("decoder.lin2.bias")),
+             ptr(buf.d2), B, HIDDEN_DIM, HIDDEN_DIM, ACT_RELU, ws, s)
+        call("dvae_linear_fwd", ptr(buf.d2), ptr(self.p("decoder.lin3.weight")), ptr(self.p("decoder.lin3.bias")),
+             ptr(buf.d3), B, HIDDEN_DIM, HID * 16, ACT_RELU, ws, s)
+        self.decode_convs(buf, B, fuse_loss)
+
     # ------------------------------------------------------------------ backward
-    def decode_backward(self, z, buf, n=None, join=True, defer_fc_wgrad=False):
+    def decode_backward(self, z, buf, n=None, join=True, defer_fc_wgrad=False, fc_chain=None):
         """buf.g_logit (grad w.r.t. the pre-sigmoid output) -> decoder weight grads, buf.dz.
         defer_fc_wgrad: the three FC weight gradients are not launched here but handed to the next
-        encode_backward, which computes all six FC weight gradients of the step in one grouped launch."""
+        encode_backward, which computes all six FC weight gradients of the step in one grouped launch.
+        fc_chain: callable that enqueues fc_chain_bwd (the native training step): it replaces the three FC input-gradient
+        launches here AND the latent glue + the encoder's three of the following encode_backward(fc_chain=True)."""
         s = _stream()
         B = z.shape[0] if n is None else n
         D = self.latent_dim
         c = self.img_size[0]
         ws = ptr(self._ws)
-        # an encode_backward follows (defer_fc_wgrad): leave the conv reductions to its grouped launch as well
-        self._defer_reduce = bool(defer_fc_wgrad) and self.is64 and _DEFER_REDUCE
-        if not self._defer_reduce:
-            self._reduce_pending = []
         acts = [buf.d3] + buf.dec_act           # inputs of convT_64/convT1/convT2/convT3 (the first one NCHW = lin3's output)
         gacts = [buf.gd3] + buf.dec_gact
         names = self.dec_names + ["convT3"]
@@ -400,18 +489,19 @@ class VAEEngine:
         pending, deferred, queued = [], [], []
         for k in range(len(names) - 1, -1, -1):
             name, x_in, gx, h = names[k], acts[k], gacts[k], hs[k]
+            lname = "decoder.%s" % name
             wargs = ("dvae_convT4s2_wgrad", ptr(x_in), NCHW if k == 0 else NHWC, ptr(dy), dy_layout,
-                     ptr(self.g("decoder.%s.weight" % name)), ptr(self.g("decoder.%s.bias" % name)),
-                     B, HID, h, h, couts[k])
+                     ptr(self.g(lname + ".weight")), ptr(self.g(lname + ".bias")), B, HID, h, h, couts[k])
             (pending if h >= 16 else deferred).append(wargs)
-            if k == 0:
-                # the first decoder layer's input gradient leaves NCHW = (c,h,w) order, straight into gd3 (the
-                # gradient of lin3's output; ReLU mask = lin3's output d3 in the same order): no relayout pass
-                call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(buf.d3),
-                     ptr(buf.gd3), NCHW, B, HID, h, h, couts[k], s)
+            # the first decoder layer's input gradient leaves NCHW = (c,h,w) order, straight into gd3 (the
+            # gradient of lin3's output; ReLU mask = lin3's output d3 in the same order): no relayout pass
+            out_layout = NCHW if k == 0 else NHWC
+            if couts[k] == HID:
+                call("dvae_conv32_down", ptr(dy), self._img(lname, "down"), None, ptr(x_in), ptr(gx), out_layout, B, h,
+                     ACT_NONE, s)
             else:
-                call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("decoder.%s.weight" % name)), ptr(x_in), ptr(gx),
-                     NHWC, B, HID, h, h, couts[k], s)
+                call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p(lname + ".weight")), ptr(x_in), ptr(gx),
+                     out_layout, B, HID, h, h, couts[k], s)
             dy, dy_layout = gx, NHWC
             for w_ in queued:                    # side launches of the previous fork, issued AFTER this stream's next kernel
                 self._conv_wgrad(*w_, fork=False)
@@ -421,12 +511,15 @@ class VAEEngine:
                 queued, pending = pending, []
         for w_ in queued:
             self._conv_wgrad(*w_, fork=False)
-        call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
-             B, HIDDEN_DIM, HID * 16, ws, s)
-        call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
-             B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
-        call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
-             B, D, HIDDEN_DIM, ws, s)
+        if fc_chain is not None:
+            fc_chain()
+        else:
+            call("dvae_linear_dgrad", ptr(buf.gd3), ptr(self.p("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
+                 B, HIDDEN_DIM, HID * 16, ws, s)
+            call("dvae_linear_dgrad", ptr(buf.gd2), ptr(self.p("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
+                 B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
+            call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
+                 B, D, HIDDEN_DIM, ws, s)
         # small conv layers + the three FC weight gradients: one fork, then they co-run with whatever follows
         self.fork_side()
         for wargs in deferred:
@@ -438,24 +531,23 @@ class VAEEngine:
             self._fc_pending = fc
         else:
             self._side_wgrad_grouped(fc)
-        self._defer_reduce = False
         if join:
             self._join_side()
 
-    def encode_backward(self, x, buf, n=None):
-        """buf.dml (grad w.r.t. the interleaved mu/logvar output) -> encoder weight grads."""
+    def encode_backward(self, x, buf, n=None, fc_chain=False):
+        """buf.dml (grad w.r.t. the interleaved mu/logvar output) -> encoder weight grads.  fc_chain: the three FC input
+        gradients were already computed by fc_chain_bwd (buf.gh2, gh1, ga_flat are final)."""
         s = _stream()
         B = x.shape[0] if n is None else n
         c, H, _ = self.img_size
         ws = ptr(self._ws)
-        self._reduce_pending = [p_ for p_ in self._reduce_pending if p_[3] == B]     # the decoder's, if it deferred them
-        self._defer_reduce = self.is64 and _DEFER_REDUCE
-        call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
-             ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
-        call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
-             B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
-        call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
-             ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, ws, s)
+        if not fc_chain:
+            call("dvae_linear_dgrad", ptr(buf.dml), ptr(self.p("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU,
+                 ptr(buf.gh2), B, HIDDEN_DIM, 2 * self.latent_dim, ws, s)
+            call("dvae_linear_dgrad", ptr(buf.gh2), ptr(self.p("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
+                 B, HIDDEN_DIM, HIDDEN_DIM, ws, s)
+            call("dvae_linear_dgrad", ptr(buf.gh1), ptr(self.p("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU,
+                 ptr(buf.ga_flat), B, HID * 16, HIDDEN_DIM, ws, s)
         # weight gradients wait for the next fork (they only have to be done by the end of the backward pass): the
         # encoder's three FC layers + the decoder's three when decode_backward deferred them = one grouped launch
         pend, self._fc_pending = [p_ for p_ in self._fc_pending if p_[4] == B], []
@@ -471,6 +563,7 @@ class VAEEngine:
         last = len(self.enc_names) - 1
         for k in range(last, -1, -1):
             name = self.enc_names[k]
+            lname = "encoder.%s" % name
             h_in = self.enc_sizes[k] * 2
             if k > 0:
                 x_in, x_layout, cin = buf.enc_act[k - 1], NHWC, HID
@@ -482,8 +575,7 @@ class VAEEngine:
             # along with it), one per big layer after that
             big = h_in >= 32
             wargs = ("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), dy_layout,
-                     ptr(self.g("encoder.%s.weight" % name)), ptr(self.g("encoder.%s.bias" % name)),
-                     B, cin, h_in, h_in, HID)
+                     ptr(self.g(lname + ".weight")), ptr(self.g(lname + ".bias")), B, cin, h_in, h_in, HID)
             side = []
             if k == 0:
                 # the first layer has no dgrad: this stream has nothing else left, so it computes the last
@@ -492,8 +584,8 @@ class VAEEngine:
                     self.fork_side()
                     side, deferred = deferred, []
                 if x.dtype == torch.uint8:
-                    call("dvae_conv4s2_wgrad_u8", ptr(x), ptr(dy), ptr(self.g("encoder.%s.weight" % name)),
-                         ptr(self.g("encoder.%s.bias" % name)), B, cin, h_in, h_in, HID, ptr(self._ws), s)
+                    call("dvae_conv4s2_wgrad_u8", ptr(x), ptr(dy), ptr(self.g(lname + ".weight")),
+                         ptr(self.g(lname + ".bias")), B, cin, h_in, h_in, HID, ptr(self._ws), s)
                 else:
                     self._conv_wgrad(*wargs, fork=False, main=True)
                 for w_ in tail_main:
@@ -506,8 +598,8 @@ class VAEEngine:
             else:
                 deferred.append(lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False))
             if k > 0:                            # this stream's next kernel first, then the side launches
-                call("dvae_conv4s2_dgrad", ptr(dy), dy_layout, ptr(self.p("encoder.%s.weight" % name)), ptr(x_in),
-                     ptr(buf.enc_gact[k - 1]), NHWC, B, cin, h_in, h_in, HID, s)
+                call("dvae_conv32_up", ptr(dy), dy_layout, self._img(lname, "up"), None, ptr(x_in), ptr(buf.enc_gact[k - 1]),
+                     B, h_in // 2, ACT_NONE, s)
             for launch in side:
                 launch()
         if deferred:
@@ -515,5 +607,3 @@ class VAEEngine:
             for launch in deferred:
                 launch()
         self._join_side()
-        self._defer_reduce = False
-        self._reduce_convs()

@@ -12,7 +12,6 @@ Two ways in:
 Host-side state (n_train_steps, annealing, storer cadence) follows losses.py:71-75,105-114.
 """
 import abc
-import os
 
 import torch
 
@@ -21,6 +20,7 @@ from .._lib import call, ptr, record_py
 from ..utils.math import log_importance_weights
 from .discriminator import Discriminator
 from ..graph import StepGraphs
+from .._debug import knob
 
 LOSSES = ["VAE", "betaH", "betaB", "factor", "btcvae"]  # losses.py:17
 RECON_DIST = ["bernoulli", "laplace", "gaussian"]        # losses.py:18
@@ -72,7 +72,8 @@ class _Scratch:
         self.scal = f(_lib.NSCAL)
         self.packed = f(_lib.NPACK)
         self.partials = f(_lib.REC_NPART)
-        self.kl_dim = f(16 + 64 * 16)   # DVAE_KL_FLOATS: per-dim KL + partial-sum scratch
+        self.kl_dim = f(_lib.KL_FLOATS)   # DVAE_KL_FLOATS: per-dim KL + per-workgroup partial blocks
+        self.scal_ready = None            # event: the (all-reduced) loss scalars of the step are final (sharded batches)
         self.disc_sums = f(4)
         self.log_w = f(4)
         self._log_w_key = None
@@ -85,6 +86,12 @@ class _Scratch:
             h[getattr(_lib, "C_" + k)] = float(v)
         # values travel as kernel arguments: ordered with the stream, no host sync
         call("dvae_set_coef", ptr(self.coef), *h, _stream())
+
+    def set_coef_host(self, **kw):
+        """Host copy only: the values reach the device with the step's weight-staging launch (engine.stage)."""
+        h = self.coef_host
+        for k, v in kw.items():
+            h[getattr(_lib, "C_" + k)] = float(v)
 
     def set_log_w(self, batch, n_data):
         key = (batch, n_data)
@@ -120,7 +127,7 @@ class BaseLoss(abc.ABC):
         # results); "graph" = hipGraph; "auto" (default) = plan while the iteration is launch-bound
         # (batch tensor <= AUTO_PLAN_ELEMS elements: measured cross-over), eager
         # above.  Single-process only (collectives stay eager)
-        mode = os.environ.get("DVAE_REPLAY", "auto")
+        mode = knob("DVAE_REPLAY", "auto")
         if mode not in ("plan", "graph", "eager", "auto"):
             raise ValueError("DVAE_REPLAY={!r}: expected one of auto, eager, plan, graph".format(mode))
         self.replay = {"plan": "plan", "graph": "graph", "eager": None, "auto": "auto"}[mode]
@@ -140,10 +147,10 @@ class BaseLoss(abc.ABC):
 
     AUTO_PLAN_ELEMS = 256 * 3 * 64 * 64
     # one HIP stream instead of two below this many input elements per step (engine.single_stream); DVAE_STREAMS=1|2 forces
-    SINGLE_STREAM_ELEMS = int(os.environ.get("DVAE_SINGLE_STREAM_ELEMS", 64 * 3 * 64 * 64))   # measured: profiles/r02_run10_streams.txt
+    SINGLE_STREAM_ELEMS = int(knob("DVAE_SINGLE_STREAM_ELEMS", 64 * 3 * 64 * 64))   # measured: profiles/r02_run10_streams.txt
 
     def _streams(self, model, data):
-        mode = os.environ.get("DVAE_STREAMS", "auto")
+        mode = knob("DVAE_STREAMS", "auto")
         single = mode == "1" or (mode == "auto" and data.numel() <= self.SINGLE_STREAM_ELEMS)
         model.engine.single_stream = bool(single) and self._world()[0] == 1
         return model.engine.single_stream
@@ -179,6 +186,17 @@ class BaseLoss(abc.ABC):
         if self._scratch is None or self._scratch.device != device:
             self._scratch = _Scratch(device)
         return self._scratch
+
+    @staticmethod
+    def _mark_scalars(sc):
+        """(sharded batches, on the side stream) the all-reduced loss scalars are final from here on."""
+        if sc.scal_ready is None:
+            sc.scal_ready = torch.cuda.Event()
+        record_py(sc.scal_ready.record, torch.cuda.current_stream())
+
+    @staticmethod
+    def _wait_scalars(sc):
+        record_py(torch.cuda.current_stream().wait_event, sc.scal_ready)
 
     def _rec_code(self):
         if self.rec_dist not in _lib.REC:
@@ -360,7 +378,9 @@ class _SingleOptimizerLoss(BaseLoss):
         B, D = data.shape[0], model.latent_dim
         world, rank = self._world()
         sc = self.scratch(data.device)
-        sc.set_coef(INV_B=1.0 / (B * world), **self._coefs(is_train))
+        # ONE launch: this step's weight images (32-channel conv layers, FC chain) + its loss coefficients
+        sc.set_coef_host(INV_B=1.0 / (B * world), **self._coefs(is_train))
+        model.engine.stage(sc.coef, sc.coef_host)
         data = data.contiguous()
         self._streams(model, data)
         if self.KIND == _lib.LOSS_BTCVAE:
@@ -400,9 +420,12 @@ class _SingleOptimizerLoss(BaseLoss):
             record_py(eps.normal_)             # = torch.randn_like (vae.py:67): same Philox consumption
         if not is_train:
             eps = None
-        eng.encode(data, buf)
-        # single process: the KL partials are finished by the one-launch loss epilogue
-        eng.reparam(buf, eps, sc.kl_dim, sc.coef if world > 1 else None)
+        eng.encode_convs(data, buf)
+        # the FC core in one launch: lin1 -> lin2 -> mu_logvar -> reparameterise (+ KL partial blocks) -> lin1 -> lin2 -> lin3
+        eng.fc_chain_fwd(buf, eps, sc.kl_dim, B)
+        klb = eng.kl_blocks(B)            # single process: the one-launch loss epilogue finishes the KL partials
+        if world > 1:
+            call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, s)
         rowstats = None
         dz_x = dmu_x = dlv_x = None
         if self.KIND == _lib.LOSS_BTCVAE:
@@ -432,34 +455,39 @@ class _SingleOptimizerLoss(BaseLoss):
                     if world > ew:                # local estimator: its mean runs over B, the loss over B * world
                         for t_ in (dz_x, dmu_x, dlv_x):
                             t_.mul_(1.0 / world)
-        # decoder; its last layer also evaluates the reconstruction likelihood and dL/dlogit
-        eng.decode(buf.z, buf, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
+        # decoder convT stack; its last layer also evaluates the reconstruction likelihood and dL/dlogit
+        eng.decode_convs(buf, B, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         if self.KIND == _lib.LOSS_BTCVAE:
             eng._join_side()
         if world > 1:
             call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
-            # the global loss sums are first needed by reparam_kl_bwd (a whole decoder backward later): their
-            # all-reduce and the scalar epilogue leave the critical path; decode_backward's join covers them
+            # the global loss sums are first needed by the latent glue of the backward FC chain (a whole convT backward
+            # later): their all-reduce and the scalar epilogue leave the critical path; an event marks them final
             eng.fork_side()
             with torch.cuda.stream(eng.side_stream):
                 self.comm.all_reduce(sc.packed)
                 call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), _stream())
+                self._mark_scalars(sc)
             if not is_train:
                 eng._join_side()
         else:
-            call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), B, D, ptr(rowstats), B, None, Bg,
+            call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), B, None, Bg,
                  ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), s)
         if not is_train:
             return
+
+        def fc_chain():        # the six FC input gradients + the reparameterisation / KL backward in ONE launch
+            if world > 1:
+                self._wait_scalars(sc)
+            eng.fc_chain_bwd(buf, eps, dz_x, None, dmu_x, dlv_x, sc.scal, sc.coef, B)
+
         # single process: one join, at the end of the backward pass, and ONE grouped launch for all six FC weight
         # gradients (issued by encode_backward); sharded: the decoder's gradients are all-reduced early, so they are final here
-        eng.decode_backward(buf.z, buf, join=world > 1, defer_fc_wgrad=world == 1)
+        eng.decode_backward(buf.z, buf, join=world > 1, defer_fc_wgrad=world == 1, fc_chain=fc_chain)
         pending = []
         if world > 1:      # decoder gradients are final: their all-reduce overlaps the encoder backward
             pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
-        call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dz_x), None, ptr(dmu_x), ptr(dlv_x), ptr(buf.mu), ptr(buf.logvar), ptr(eps),
-             ptr(sc.scal), ptr(sc.coef), ptr(buf.dml), B, D, s)
-        eng.encode_backward(data, buf)
+        eng.encode_backward(data, buf, fc_chain=True)
         if world > 1:
             pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))
             for h_ in pending:
@@ -608,20 +636,27 @@ class FactorKLoss(BaseLoss):
         Bhg = Bh * world
         dev = data.device
         s = _stream()
+        # the N(0,1) draws of both halves in ONE [2*Bh, D] buffer (rows < Bh: data1, losses.py:254; the rest:
+        # sample_latent(data2), losses.py:286) -- two separate draws, like the reference, into its two halves
+        eps12 = sc.latent("eps12", 2 * Bh, D)
         if eps1 is None:
-            eps1, eps2 = sc.latent("eps1", Bh, D), sc.latent("eps2", Bh, D)
-            record_py(eps1.normal_)            # losses.py:254 (forward on data1)
-            record_py(eps2.normal_)            # losses.py:286 (sample_latent(data2))
+            record_py(eps12[:Bh].normal_)
+            record_py(eps12[Bh:].normal_)
+        else:
+            record_py(eps12[:Bh].copy_, eps1)
+            record_py(eps12[Bh:].copy_, eps2)
+        eps1 = eps12[:Bh]
         buf = eng.buffers(B)
         data = eng.input(data, buf)
-        eng.encode(data, buf, n=2 * Bh)                               # data1 and data2 in one pass
-        # reparameterise the two halves (KL only over data1, denominator = half batch; losses.py:255-259)
-        call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps1), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(sc.kl_dim),
-             ptr(sc.coef) if world > 1 else None, Bh, D, s)
-        eng.decode(buf.z, buf, n=Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
+        eng.encode_convs(data, buf, n=2 * Bh)                         # data1 and data2 in one pass
+        # FC core of both halves in one launch; KL only over data1 with the half batch as denominator (losses.py:255-259),
+        # decoder only for data1
+        eng.fc_chain_fwd(buf, eps12, sc.kl_dim, 2 * Bh, n_kl=Bh, n_dec=Bh)
+        klb = eng.kl_blocks(2 * Bh)
+        if world > 1:
+            call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, s)
+        eng.decode_convs(buf, Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         off = Bh
-        call("dvae_reparam_kl_fwd", ptr(buf.ml[off:]), ptr(eps2), ptr(buf.mu[off:]), ptr(buf.logvar[off:]),
-             ptr(buf.z[off:]), None, None, Bh, D, s)                  # sample_latent(data2), losses.py:286
         # z_perm: permute across the (global) half batch, losses.py:287
         zin = sc.latent("disc_in", 2 * Bh, D)
         record_py(zin[:Bh].copy_, buf.z[:Bh])
@@ -647,8 +682,9 @@ class FactorKLoss(BaseLoss):
             with torch.cuda.stream(eng.side_stream):
                 self.comm.all_reduce(sc.packed)
                 call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), _stream())
+                self._mark_scalars(sc)
         else:
-            call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), Bh, D, None, 0, ptr(sc.disc_sums),
+            call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), klb, D, None, 0, ptr(sc.disc_sums),
                  Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), s)
         # discriminator backward of d_tc_loss (weight grads + dz), losses.py:303-304
         dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
@@ -657,13 +693,17 @@ class FactorKLoss(BaseLoss):
             pending.append(self.comm.all_reduce_async(disc.arena.grad))
         # tc term of vae_loss through D: dgrad only, first half (its disc weight grads are zeroed at :303)
         dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2")
-        eng.decode_backward(buf.z, buf, n=Bh, join=world > 1, defer_fc_wgrad=world == 1)   # single process: joined at the end of encode_backward
+
+        def fc_chain():
+            # dz_a: quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1); dz_b: the tc term through D
+            if world > 1:
+                self._wait_scalars(sc)
+            eng.fc_chain_bwd(buf, eps1, dz_a, dz_b, None, None, sc.scal, sc.coef, Bh)
+
+        eng.decode_backward(buf.z, buf, n=Bh, join=world > 1, defer_fc_wgrad=world == 1, fc_chain=fc_chain)   # single process: joined at the end of encode_backward
         if world > 1:      # decoder gradients are final: overlapped with the encoder backward
             pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
-        # dz_a: quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1); dz_b: the tc term through D
-        call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dz_a), ptr(dz_b), None, None, ptr(buf.mu), ptr(buf.logvar), ptr(eps1), ptr(sc.scal),
-             ptr(sc.coef), ptr(buf.dml), Bh, D, s)
-        eng.encode_backward(data, buf, n=Bh)
+        eng.encode_backward(data, buf, n=Bh, fc_chain=True)
         if world > 1:
             pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))
             for h_ in pending:
@@ -686,7 +726,8 @@ class FactorKLoss(BaseLoss):
         s = _stream()
         sc = self.scratch(dev)
         anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
-        sc.set_coef(INV_B=1.0 / Bhg, ANNEAL=anneal, BETA=self.gamma)
+        sc.set_coef_host(INV_B=1.0 / Bhg, ANNEAL=anneal, BETA=self.gamma)
+        eng.stage(sc.coef, sc.coef_host)       # ONE launch: this step's weight images + its loss coefficients
         data = data.contiguous()
         self._streams(model, data)
         if noise is not None:
@@ -712,11 +753,11 @@ class FactorKLoss(BaseLoss):
         else:
             buf = eng.buffers(B)
             data = eng.input(data, buf)
-            eng.encode(data, buf, n=Bh)
+            eng.encode_convs(data, buf, n=Bh)
             # z = mean; KL over data1 with the half batch as denominator (losses.py:255-259)
-            call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps1), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(sc.kl_dim),
-                 ptr(sc.coef), Bh, D, s)
-            eng.decode(buf.z, buf, n=Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
+            eng.fc_chain_fwd(buf, None, sc.kl_dim, Bh)
+            call("dvae_kl_finish", ptr(sc.kl_dim), eng.kl_blocks(Bh), ptr(sc.coef), D, s)
+            eng.decode_convs(buf, Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
             # evaluation: vae_loss only (losses.py:276-278); discriminator on z1
             logits = disc.forward_raw(buf.z, Bh)
             g_dtc = sc.latent("g_dtc", 2 * Bh, 2)

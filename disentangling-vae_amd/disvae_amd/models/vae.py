@@ -15,6 +15,7 @@ from ..engine import VAEEngine, ParamArena, vae_param_shapes
 from .. import _lib
 from .._lib import call, ptr
 from ..utils.initialization import reference_init_
+from .._debug import knob
 
 MODELS = ["Burgess"]  # disvae/models/vae.py:12
 
@@ -144,7 +145,7 @@ class VAE(nn.Module):
             self._engine = VAEEngine(self.img_size, self.latent_dim, self._arena)
         return self._engine
 
-    FLAT_CHUNK = int(__import__("os").environ.get("DVAE_FLAT_CHUNK", 8192))
+    FLAT_CHUNK = int(knob("DVAE_FLAT_CHUNK", 8192))
 
     def _arena_chunks(self, grad=False):
         buf = self._arena.grad if grad else self._arena.flat
@@ -155,7 +156,11 @@ class VAE(nn.Module):
         ``torch.optim.Adam(model.flat_parameters(), ...)`` performs exactly the same element-wise
         update as ``Adam(model.parameters(), ...)`` (the 16-byte alignment padding has zero
         gradient and stays zero); the uniform 8192-element chunks give torch's fused multi-tensor
-        Adam kernel ~60 equally sized workgroups instead of 8 large ones."""
+        Adam kernel ~60 equally sized workgroups instead of 8 large ones.
+        Only the native training step (``loss_f.fused_step`` / ``call_optimize``) fills the chunks' ``.grad``: the
+        autograd-compatible path (``model(x)`` ... ``loss.backward()``) delivers gradients to the layer Parameters and
+        refuses to run once the chunks have been handed out (an optimizer over them would step with stale gradients)."""
+        self._flat_handed_out = True
         return list(self._flat_params)
 
     def assign_grads(self):
@@ -181,6 +186,11 @@ class VAE(nn.Module):
         of it.  After a fused step ``Parameter.grad`` IS a view of that arena (assign_grads): autograd would then
         accumulate the clone into the very buffer the kernels just wrote (doubling the gradient under
         ``zero_grad(set_to_none=False)``).  Give every aliased ``.grad`` its own storage first (values kept)."""
+        if getattr(self, "_flat_handed_out", False):
+            raise _lib.DvaeHipError("this model's flat_parameters() were handed to an optimizer: autograd delivers gradients "
+                                    "to model.parameters() only, so optimizer.step() would use stale gradients -- build "
+                                    "the optimizer on model.parameters() to use loss.backward(), or train through the "
+                                    "native step (Trainer / loss_f.fused_step / call_optimize)")
         lo = self._arena.grad.data_ptr()
         hi = lo + self._arena.grad.numel() * 4
         for p_ in list(self.parameters()) + list(self._flat_params):
@@ -255,7 +265,7 @@ class _VAEFn(torch.autograd.Function):
         eng.encode(x, buf)
         eng.reparam(buf, eps)
         if decode:
-            eng.decode(buf.z, buf)
+            eng.decode(buf.z, buf, staged=True)      # encode() above staged this pass's weight images
         model._fwd_version += 1
         ctx.model, ctx.x, ctx.eps, ctx.decode, ctx.version = model, x, eps, decode, model._fwd_version
         recon = buf.recon.clone() if decode else buf.recon.new_zeros(())

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DVAE_VERSION 102
+#define DVAE_VERSION 103
 
 /* latent dimensions the fused kernels cover (the reference's --latent-dim is 10 in every experiment of
  * hyperparam.ini): reparameterisation / KL / scalar slots up to 16, the beta-TCVAE estimator up to 12
@@ -83,23 +83,41 @@ int dvae_convT4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_la
                         float* db, int N, int Cin, int H, int W, int Cout, float* ws, void* stream);
 size_t dvae_conv_wgrad_ws_floats(void);
 
-/* Deferred reduction of the conv / convT weight gradients (tuned geometries only: 64x64 images, C in {1,3,32}):
- * dvae_conv4s2_wgrad_partial / dvae_convT4s2_wgrad_partial run the accumulation kernel of dvae_conv*_wgrad and leave the
- * per-workgroup partial sums in `ws` (dvae_conv_wgrad_ws_floats() floats, ONE workspace per layer, untouched until reduced);
- * dvae_conv_wgrad_reduce_grouped finishes up to DVAE_WGR_MAX layers in ONE launch -- same fixed summation order, hence
- * bit-identical to the one-call forms.  `descs` is a host array read during the call.                                */
-#define DVAE_WGR_MAX 8
+/* ---- per-step weight staging + the tuned 32 <-> 32 channel kernels on pre-staged weights ------------------------------
+ * The six hidden conv / convT layers of the 64x64 Burgess stack (encoders.py:55-60, decoders.py:57-64; on 32x32 images the
+ * four that exist) are 18 launches per training iteration that each keep a re-laid 64 KB image of the layer's weights in
+ * LDS, and the six fully-connected layers (encoders.py:63-67, decoders.py:53-55) are streamed by the FC-chain kernels below
+ * in k-chunked order.  dvae_stage_weights writes all of those images in ONE launch at the head of a forward pass (the
+ * parameters only change in optimizer.step(), training.py:158), optionally together with the step's loss coefficients
+ * (= dvae_set_coef).  Images: conv img_down / img_up = 16384 floats each (wl[tap][kc/4][n][kc%4], kc = cb / cs);
+ * fc img_fwd = [ceil(K/4)][N][4] floats, img_bwd = [ceil(N/4)][K][4] floats (zero padded).  Any image pointer may be NULL
+ * (skipped).  `conv`, `fc`, `coef_vals` are HOST arrays read during the call.                                        */
+#define DVAE_STAGE_MAX_CONV 6
+#define DVAE_STAGE_MAX_FC 8
 typedef struct {
-  const float* ws;      /* the workspace the partial call filled */
-  float* dw; float* db; /* outputs as in dvae_conv*_wgrad (db may be NULL) */
-  int N, Cin, H, W, Cout;   /* the layer's geometry, as passed to the partial call */
-  int transposed;       /* 0: dvae_conv4s2_wgrad_partial, 1: dvae_convT4s2_wgrad_partial */
-} dvae_conv_wgrad_desc;
-int dvae_conv4s2_wgrad_partial(const float* x, int x_layout, const float* dy, int dy_layout, int N, int Cin, int H,
-                               int W, int Cout, float* ws, void* stream);
-int dvae_convT4s2_wgrad_partial(const float* x, int x_layout, const float* dy, int dy_layout, int N, int Cin, int H,
-                                int W, int Cout, float* ws, void* stream);
-int dvae_conv_wgrad_reduce_grouped(const dvae_conv_wgrad_desc* descs, int n, void* stream);
+  const float* w;       /* Conv2d [32,32,4,4] or ConvTranspose2d [32,32,4,4] weight = w[cs][cb][kh][kw] */
+  float* img_down;      /* consumed by dvae_conv32_down */
+  float* img_up;        /* consumed by dvae_conv32_up   */
+} dvae_conv_image_desc;
+typedef struct {
+  const float* w;       /* nn.Linear weight [N,K] */
+  float* img_fwd;       /* forward operand stream of dvae_fc_chain_fwd */
+  float* img_bwd;       /* input-gradient operand stream of dvae_fc_chain_bwd */
+  int N, K;
+} dvae_fc_image_desc;
+int dvae_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc,
+                       float* coef /* device, may be NULL */, const float* coef_vals /* host float[8], may be NULL */,
+                       void* stream);
+/* "down" = big[N,32,2Hs,2Hs] -> small[N,32,Hs,Hs]: Conv2d forward (encoders.py:75-77: bias + ReLU, mask NULL) and
+ * ConvTranspose2d input gradient (decoders.py:77-80 under training.py:157: bias NULL, act none, mask = the producing
+ * layer's post-ReLU output, gradient zeroed where it is 0).  "up" = small -> big: ConvTranspose2d forward / Conv2d
+ * input gradient.  Hs in {4, 8, 16}; NHWC on both sides, except that the 4x4 side of Hs = 4 may be NCHW (= the (c,h,w)
+ * flatten order of encoders.py:80 / decoders.py:74).  Same kernels, same results as dvae_conv4s2_* / dvae_convT4s2_* on the
+ * raw weights: only the prologue differs.                                                                         */
+int dvae_conv32_down(const float* big, const float* img_down, const float* bias, const float* mask, float* out,
+                     int out_layout, int N, int Hs, int act, void* stream);
+int dvae_conv32_up(const float* small, int small_layout, const float* img_up, const float* bias, const float* mask,
+                   float* out, int N, int Hs, int act, void* stream);
 
 /* ---- uint8 input pipeline: utils/datasets.py:204-213 (dSprites: imgs * 255 -> ToTensor), :282-291 (CelebA:
  * imread -> ToTensor).  The batch stays uint8 [N,C,H,W] in HBM (NCHW = ToTensor's output order, 1 byte per pixel);
@@ -154,15 +172,53 @@ typedef struct {
 } dvae_linear_wgrad_desc;
 int dvae_linear_wgrad_grouped(const dvae_linear_wgrad_desc* descs, int n, void* stream);
 
+/* ---- the fully-connected core as one launch per direction (fc_chain.hip) ---------------------------------------------
+ * forward : encoder lin1 -> lin2 -> mu_logvar_gen (encoders.py:81-87) -> reparameterise + per-dim KL partials
+ *           (vae.py:52-71, losses.py:452-480) -> decoder lin1 -> lin2 -> lin3 (decoders.py:71-73), for rows [0, n_enc);
+ *           KL terms only from rows < n_kl, decoder only for rows < n_dec (FactorVAE: both halves of the batch are encoded,
+ *           the first half enters the KL and is decoded, losses.py:254-259,286).  Hidden sizes are the Burgess ones
+ *           (512 -> 256 -> 256 -> 2D, D -> 256 -> 256 -> 512), 1 <= D <= DVAE_MAX_D, n_enc <= 8 * DVAE_KL_MAX_BLOCKS.
+ * backward: the input-gradient chain of the same six layers with the ReLU masks of the saved activations and
+ *           dvae_reparam_kl_bwd's arithmetic in the middle, rows [0, n) (weight gradients: dvae_linear_wgrad_grouped).
+ * Weight operands are the img_fwd / img_bwd images of dvae_stage_weights.  Same results as the per-layer entry points
+ * up to fp32 summation order (documented tolerance: rtol 1e-5 of the layer scale).  Structs are HOST memory.        */
+typedef struct {
+  const float* a_flat;                                      /* [n_enc,512] conv-stack output, (c,h,w) order, post-ReLU */
+  const float *w_e1, *w_e2, *w_ml, *w_d1, *w_d2, *w_d3;     /* img_fwd of encoder.lin1, lin2, mu_logvar_gen, decoder.lin1..3 */
+  const float *b_e1, *b_e2, *b_ml, *b_d1, *b_d2, *b_d3;     /* their biases */
+  const float* eps;                                         /* [n_enc,D] N(0,1) draws; NULL: z = mu (eval mode) */
+  float *h1, *h2, *ml, *mu, *logvar, *z;                    /* [n_enc,256] x2, [n_enc,2D] (interleaved), [n_enc,D] x3 */
+  float* kl_part;                                           /* [ceil(n_enc/8),16] partial blocks (= kl_dim + 16) or NULL */
+  float *d1, *d2, *d3;                                      /* [n_dec,256] x2, [n_dec,512] */
+  int n_enc, n_kl, n_dec, D;
+} dvae_fc_chain_fwd_args;
+typedef struct {
+  const float* gd3;                                         /* [n,512] gradient w.r.t. decoder.lin3's pre-activation output */
+  const float *w_d3, *w_d2, *w_d1, *w_ml, *w_e2, *w_e1;     /* img_bwd of the six layers */
+  const float *d2, *d1, *h2, *h1, *a_flat;                  /* saved post-ReLU activations (masks) */
+  const float *mu, *logvar, *eps;                           /* [n,D]; eps NULL: z = mu */
+  const float *dz2, *dz3, *dmu_x, *dlv_x;                   /* as in dvae_reparam_kl_bwd; each may be NULL */
+  const float *scal, *coef;
+  float *gd2, *gd1, *dz /* may be NULL */, *dml, *gh2, *gh1, *ga_flat;   /* [n,256] x2, [n,D], [n,2D], [n,256] x2, [n,512] */
+  int n, D;
+} dvae_fc_chain_bwd_args;
+int dvae_fc_chain_fwd(const dvae_fc_chain_fwd_args* args, void* stream);
+int dvae_fc_chain_bwd(const dvae_fc_chain_bwd_args* args, void* stream);
+
 /* ---- reparameterisation + per-dim Gaussian KL: vae.py:52-71, losses.py:452-480 -----------
  * ml[B,2D] is the interleaved output of mu_logvar_gen (encoders.py:87: mu = ml[:,0::2],
  * logvar = ml[:,1::2]).  z = mu + exp(.5 logvar) eps (eps == NULL: z = mu, eval mode).
  * kl_dim (may be NULL): float[DVAE_KL_FLOATS]; [0,D) = coef[INV_B] * sum_b 0.5(-1 - lv + mu^2 + e^lv),
- * the rest is scratch for the per-workgroup partial sums.  With kl_dim != NULL and coef == NULL only
- * the partials are written (no finishing launch): dvae_loss_epilogue(kl_rows = B) finishes them.   */
-#define DVAE_KL_FLOATS (16 + 64 * 16)
+ * the rest (kl_dim + 16) holds per-workgroup partial sums, blocks of 16 floats.  With kl_dim != NULL and coef == NULL
+ * only the dvae_reparam_kl_blocks(B) partial blocks are written (no finishing launch): dvae_loss_epilogue(kl_blocks = that
+ * count) or dvae_kl_finish completes them -- every consumer adds the blocks in the same fixed order.            */
+#define DVAE_KL_MAX_BLOCKS 1024
+#define DVAE_KL_FLOATS (16 + DVAE_KL_MAX_BLOCKS * 16)
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z,
                         float* kl_dim, const float* coef, int B, int D, void* stream);
+int dvae_reparam_kl_blocks(int B);
+/* kl_dim[0,D) <- coef[INV_B] * (sum of the kl_blocks partial blocks at kl_dim + 16)  (sharded batches: before dvae_loss_pack) */
+int dvae_kl_finish(float* kl_dim, int kl_blocks, const float* coef, int D, void* stream);
 /* dml[B,2D] (interleaved) from dz + dz2 + dz3 [B,D] (each may be NULL: gradients that reach z
  * through the decoder, the TC estimator, the discriminator -- quirk Q1) and optional direct grads
  * dmu_x/dlv_x[B,D]; the KL term enters with weight scal[DVAE_S_KLW] * coef[INV_B].             */
@@ -246,9 +302,10 @@ int dvae_loss_pack(const float* rec_partials, const float* kl_dim, int D, const 
 int dvae_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal,
                        void* stream);
 /* Un-sharded batches: dvae_loss_pack and dvae_loss_finalize in ONE launch (scal == NULL: pack only).
- * kl_rows > 0: kl_dim holds the un-finished partials of dvae_reparam_kl_fwd(coef = NULL) over
- * kl_rows rows; they are summed (same order as the finishing kernel) and scaled by coef[INV_B].   */
-int dvae_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_rows, int D,
+ * kl_blocks > 0: kl_dim + 16 holds that many un-finished partial blocks (dvae_reparam_kl_fwd(coef = NULL):
+ * dvae_reparam_kl_blocks(B) of them; dvae_fc_chain_fwd: ceil(n_enc / 8)); they are summed (same order as
+ * dvae_kl_finish) and scaled by coef[INV_B].  kl_blocks == 0: kl_dim[0,D) is final.                 */
+int dvae_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_blocks, int D,
                        const float* rowstats, int Bl, const float* disc_sums, int Bg,
                        const float* coef, float* packed, float* scal, void* stream);
 

@@ -1,0 +1,263 @@
+"""-m gpu: the round-3 launches that shorten the step's latency chain, through the C-ABI:
+  * dvae_stage_weights -- the pre-staged LDS weight images of the 32-channel conv layers and the k-chunked operand
+    streams of the FC layers (exact re-layouts: compared bit for bit with the layout definition);
+  * dvae_conv32_down / dvae_conv32_up -- the tuned conv kernels on pre-staged images == the same kernels on raw weights,
+    bit for bit (only the prologue differs), at sizes where every persistent workgroup loops;
+  * dvae_fc_chain_fwd / dvae_fc_chain_bwd -- the FC core in one launch per direction vs fp64 torch (rtol 1e-5 + 2e-6 of the
+    tensor's scale) and vs the per-layer entry points it replaces in the training step.
+Reference lines: encoders.py:73-87, vae.py:52-71, losses.py:452-480, decoders.py:71-80."""
+import ctypes
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import *  # noqa
+from gpu_util import _lib  # noqa
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _stage(conv=(), fc=(), coef=None, coef_vals=None):
+    """conv: [(w, img_down, img_up)], fc: [(w, img_fwd, img_bwd, N, K)] (device tensors / None)."""
+    cd = (_lib.ConvImageDesc * max(1, len(conv)))()
+    for d, (w, a, b) in zip(cd, conv):
+        d.w, d.img_down, d.img_up = ptr(w), ptr(a), ptr(b)
+    fd = (_lib.FcImageDesc * max(1, len(fc)))()
+    for d, (w, a, b, N, K) in zip(fd, fc):
+        d.w, d.img_fwd, d.img_bwd, d.N, d.K = ptr(w), ptr(a), ptr(b), N, K
+    cv = None
+    if coef_vals is not None:
+        arr = (ctypes.c_float * 8)(*coef_vals)
+        cv = ctypes.addressof(arr)
+    call("dvae_stage_weights", ctypes.addressof(cd), len(conv), ctypes.addressof(fd), len(fc), ptr(coef), cv, stream())
+    torch.cuda.synchronize()
+
+
+def _conv_image(w, down):
+    """wl[tap][kc/4][n][kc%4] of conv_mfma_common.h from w[cs][cb][4][4]: down kc = cb, n = cs; up kc = cs, n = cb."""
+    t = w.reshape(32, 32, 16)                       # [cs][cb][tap]
+    t = t.permute(2, 1, 0) if down else t.permute(2, 0, 1)     # [tap][kc][n]
+    return t.reshape(16, 8, 4, 32).permute(0, 1, 3, 2).contiguous().reshape(-1)   # [tap][kc4][n][r]
+
+
+def _fc_images(w):
+    N, K = w.shape
+    kp = (K + 3) // 4 * 4
+    wk = torch.zeros(N, kp)
+    wk[:, :K] = w
+    fwd = wk.reshape(N, kp // 4, 4).permute(1, 0, 2).contiguous().reshape(-1)       # [K/4][N][4]
+    npad = (N + 3) // 4 * 4
+    wn = torch.zeros(npad, K)
+    wn[:N] = w
+    bwd = wn.reshape(npad // 4, 4, K).permute(0, 2, 1).contiguous().reshape(-1)     # [N/4][K][4]
+    return fwd, bwd
+
+
+def test_stage_weights_layouts_and_coefficients():
+    w1, w2 = _rand(32, 32, 4, 4, seed=1), _rand(32, 32, 4, 4, seed=2)
+    f = lambda n: torch.full((n,), 7.0, device=DEV)
+    imgs = [(dev(w1), f(16384), f(16384)), (dev(w2), f(16384), None)]
+    fcs = []
+    shapes = [(256, 512), (20, 256), (256, 10), (512, 256), (2, 256), (256, 1)]
+    ws = [_rand(N, K, seed=10 + i) for i, (N, K) in enumerate(shapes)]
+    for w, (N, K) in zip(ws, shapes):
+        fcs.append((dev(w), f((K + 3) // 4 * N * 4), f((N + 3) // 4 * K * 4), N, K))
+    coef = torch.zeros(_lib.NCOEF, device=DEV)
+    _stage(imgs, fcs, coef, [0.5, 1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5])
+    assert torch.equal(imgs[0][1].cpu(), _conv_image(w1, True))
+    assert torch.equal(imgs[0][2].cpu(), _conv_image(w1, False))
+    assert torch.equal(imgs[1][1].cpu(), _conv_image(w2, True))
+    for w, (wd, a, b, N, K) in zip(ws, fcs):
+        fwd, bwd = _fc_images(w)
+        assert torch.equal(a.cpu(), fwd), (N, K)
+        assert torch.equal(b.cpu(), bwd), (N, K)
+    assert coef.cpu().tolist() == [0.5, 1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5]
+    # coefficients alone (no image): one tiny launch
+    _stage((), (), coef, [1.0] * 8)
+    assert coef.cpu().tolist() == [1.0] * 8
+
+
+@pytest.mark.parametrize("N,Hs", [(3, 16), (70, 16), (1030, 16), (5, 8), (1100, 8), (3, 4), (70, 4), (4099, 4)])
+def test_conv32_on_staged_images_is_bit_identical_to_the_raw_weight_path(N, Hs):
+    """Conv2d forward / ConvT dgrad (down) and ConvT forward / Conv dgrad (up) on pre-staged images vs the raw-weight entry
+    points: the same kernels, only the weight prologue differs."""
+    C, Hb = 32, 2 * Hs
+    w = _rand(C, C, 4, 4, seed=2, scale=0.2)
+    b = _rand(C, seed=3, scale=0.1)
+    wd, bd = dev(w), dev(b)
+    img_d, img_u = torch.empty(16384, device=DEV), torch.empty(16384, device=DEV)
+    _stage([(wd, img_d, img_u)])
+    big = nhwc(_rand(N, C, Hb, Hb, seed=1))
+    small_act = torch.relu(_rand(N, C, Hs, Hs, seed=5))
+    layouts = [_lib.NHWC] + ([_lib.NCHW] if Hs == 4 else [])
+    for lay in layouts:
+        shape = (N, Hs, Hs, C) if lay == _lib.NHWC else (N, C, Hs, Hs)
+        # down, forward flavour: bias + ReLU, no mask
+        y0, y1 = torch.empty(shape, device=DEV), torch.empty(shape, device=DEV)
+        call("dvae_conv4s2_fwd", ptr(big), _lib.NHWC, ptr(wd), ptr(bd), ptr(y0), lay, N, C, Hb, Hb, C, _lib.ACT_RELU, stream())
+        call("dvae_conv32_down", ptr(big), ptr(img_d), ptr(bd), None, ptr(y1), lay, N, Hs, _lib.ACT_RELU, stream())
+        assert torch.equal(y0, y1), "down fwd layout %d" % lay
+        # down, dgrad flavour (ConvT dgrad): mask, no bias
+        mask = nhwc(small_act) if lay == _lib.NHWC else dev(small_act)
+        call("dvae_convT4s2_dgrad", ptr(big), _lib.NHWC, ptr(wd), ptr(mask), ptr(y0), lay, N, C, Hs, Hs, C, stream())
+        call("dvae_conv32_down", ptr(big), ptr(img_d), None, ptr(mask), ptr(y1), lay, N, Hs, _lib.ACT_NONE, stream())
+        assert torch.equal(y0, y1), "down dgrad layout %d" % lay
+        # up, forward flavour (ConvT forward)
+        small = nhwc(small_act) if lay == _lib.NHWC else dev(small_act)
+        o0, o1 = torch.empty(N, Hb, Hb, C, device=DEV), torch.empty(N, Hb, Hb, C, device=DEV)
+        call("dvae_convT4s2_fwd", ptr(small), lay, ptr(wd), ptr(bd), ptr(o0), _lib.NHWC, N, C, Hs, Hs, C, _lib.ACT_RELU, stream())
+        call("dvae_conv32_up", ptr(small), lay, ptr(img_u), ptr(bd), None, ptr(o1), N, Hs, _lib.ACT_RELU, stream())
+        assert torch.equal(o0, o1), "up fwd layout %d" % lay
+        # up, dgrad flavour (Conv dgrad): mask = the big-side activation
+        bmask = nhwc(torch.relu(_rand(N, C, Hb, Hb, seed=7)))
+        call("dvae_conv4s2_dgrad", ptr(small), lay, ptr(wd), ptr(bmask), ptr(o0), _lib.NHWC, N, C, Hb, Hb, C, stream())
+        call("dvae_conv32_up", ptr(small), lay, ptr(img_u), None, ptr(bmask), ptr(o1), N, Hs, _lib.ACT_NONE, stream())
+        assert torch.equal(o0, o1), "up dgrad layout %d" % lay
+
+
+def _fc_params(D, seed=0):
+    shapes = {"e1": (256, 512), "e2": (256, 256), "ml": (2 * D, 256), "d1": (256, D), "d2": (256, 256), "d3": (512, 256)}
+    W = {k: _rand(N, K, seed=seed + i, scale=math.sqrt(6.0 / K)) for i, (k, (N, K)) in enumerate(shapes.items())}
+    Bv = {k: _rand(N, seed=seed + 20 + i, scale=1.0 / math.sqrt(K)) for i, (k, (N, K)) in enumerate(shapes.items())}
+    return shapes, W, Bv
+
+
+def _fc_stage(shapes, W):
+    f = lambda n: torch.empty(n, device=DEV)
+    ent = {}
+    for k, (N, K) in shapes.items():
+        ent[k] = (dev(W[k]), f((K + 3) // 4 * N * 4), f((N + 3) // 4 * K * 4), N, K)
+    _stage((), list(ent.values()))
+    return ent
+
+
+@pytest.mark.parametrize("n_enc,n_kl,n_dec,D,noise", [(1, 1, 1, 10, True), (8, 8, 8, 10, True), (13, 13, 13, 10, False),
+                                                     (128, 128, 128, 10, True), (1030, 1030, 1030, 10, True),
+                                                     (262, 131, 131, 10, True), (40, 20, 20, 1, True), (77, 77, 77, 16, True),
+                                                     (2048, 1024, 1024, 10, True), (50, 50, 0, 6, True)])
+def test_fc_chain_forward(n_enc, n_kl, n_dec, D, noise):
+    shapes, W, Bv = _fc_params(D, seed=3)
+    ent = _fc_stage(shapes, W)
+    a = torch.relu(_rand(n_enc, 512, seed=1))
+    eps = torch.randn(n_enc, D, generator=torch.Generator().manual_seed(2)) if noise else None
+    f = lambda *s: torch.full(s, 7.0, device=DEV)
+    out = dict(h1=f(n_enc, 256), h2=f(n_enc, 256), ml=f(n_enc, 2 * D), mu=f(n_enc, D), logvar=f(n_enc, D), z=f(n_enc, D),
+               d1=f(max(n_dec, 1), 256), d2=f(max(n_dec, 1), 256), d3=f(max(n_dec, 1), 512))
+    kl = torch.full((_lib.KL_FLOATS,), 7.0, device=DEV)
+    bd = {k: dev(v) for k, v in Bv.items()}
+    ad, ed = dev(a), (dev(eps) if noise else None)
+    st, addr = _lib.struct_of(_lib.FcChainFwdArgs, a_flat=ptr(ad), eps=ptr(ed), kl_part=ptr(kl) + 64,
+                              n_enc=n_enc, n_kl=n_kl, n_dec=n_dec, D=D,
+                              **{"w_" + k: ptr(ent[k][1]) for k in shapes}, **{"b_" + k: ptr(bd[k]) for k in shapes},
+                              **{k: ptr(v) for k, v in out.items()})
+    call("dvae_fc_chain_fwd", addr, stream())
+    # fp64 reference (encoders.py:81-87, vae.py:66-68, decoders.py:71-73)
+    Wd = {k: v.double() for k, v in W.items()}
+    Bd = {k: v.double() for k, v in Bv.items()}
+    h1 = torch.relu(F.linear(a.double(), Wd["e1"], Bd["e1"]))
+    h2 = torch.relu(F.linear(h1, Wd["e2"], Bd["e2"]))
+    ml = F.linear(h2, Wd["ml"], Bd["ml"])
+    mu, lv = ml.view(n_enc, D, 2).unbind(-1)
+    z = mu + torch.exp(0.5 * lv) * eps.double() if noise else mu
+    tol = dict(rtol=1e-5, atol_rel=2e-6)
+    check(out["h1"], h1, what="chain h1", **tol)
+    check(out["h2"], h2, what="chain h2", **tol)
+    check(out["ml"], ml, what="chain ml", **tol)
+    check(out["mu"], mu, what="chain mu", **tol)
+    check(out["logvar"], lv, what="chain logvar", **tol)
+    check(out["z"], z, what="chain z", **tol)
+    klref = (0.5 * (-1 - lv + mu * mu + torch.exp(lv)))[:n_kl].sum(0)
+    nblk = (n_enc + 7) // 8
+    parts = kl[16:16 + nblk * 16].view(nblk, 16).cpu().double()
+    check(parts.sum(0)[:D], klref, rtol=1e-5, atol_rel=2e-6, what="chain KL partial blocks")
+    assert torch.all(parts[:, D:] == 0)
+    if n_dec:
+        d1 = torch.relu(F.linear(z[:n_dec], Wd["d1"], Bd["d1"]))
+        d2 = torch.relu(F.linear(d1, Wd["d2"], Bd["d2"]))
+        d3 = torch.relu(F.linear(d2, Wd["d3"], Bd["d3"]))
+        check(out["d1"], d1, what="chain d1", **tol)
+        check(out["d2"], d2, what="chain d2", **tol)
+        check(out["d3"], d3, what="chain d3", **tol)
+    else:
+        assert torch.all(out["d3"] == 7.0)
+    # the finishing launch and the one-launch loss epilogue add the partial blocks in the same order (bit-identical)
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / max(n_kl, 1); coef[_lib.C_BETA] = 4.0; coef[_lib.C_ANNEAL] = 1.0
+    coefd = dev(coef)
+    packed, scal = torch.zeros(_lib.NPACK, device=DEV), torch.zeros(_lib.NSCAL, device=DEV)
+    partials = torch.zeros(_lib.REC_NPART, device=DEV)
+    call("dvae_loss_epilogue", _lib.LOSS_BETAH, ptr(partials), ptr(kl), nblk, D, None, 0, None, max(n_kl, 1), ptr(coefd), ptr(packed),
+         ptr(scal), stream())
+    call("dvae_kl_finish", ptr(kl), nblk, ptr(coefd), D, stream())
+    assert torch.equal(kl[:D].cpu(), packed[1:1 + D].cpu())
+    check(kl[:D], klref / max(n_kl, 1), rtol=1e-5, atol_rel=2e-6, what="chain KL finished")
+    # vs the per-layer entry points the training step used before (same tolerance, now on fp32 against fp32)
+    h1p, mlp = torch.empty(n_enc, 256, device=DEV), torch.empty(n_enc, 2 * D, device=DEV)
+    h2p = torch.empty(n_enc, 256, device=DEV)
+    call("dvae_linear_fwd", ptr(ad), ptr(ent["e1"][0]), ptr(bd["e1"]), ptr(h1p), n_enc, 512, 256, _lib.ACT_RELU, None, stream())
+    call("dvae_linear_fwd", ptr(h1p), ptr(ent["e2"][0]), ptr(bd["e2"]), ptr(h2p), n_enc, 256, 256, _lib.ACT_RELU, None, stream())
+    call("dvae_linear_fwd", ptr(h2p), ptr(ent["ml"][0]), ptr(bd["ml"]), ptr(mlp), n_enc, 256, 2 * D, _lib.ACT_NONE, None, stream())
+    check(out["ml"], mlp.cpu(), rtol=2e-5, atol_rel=4e-6, what="chain ml vs per-layer kernels")
+
+
+@pytest.mark.parametrize("n,D,noise,extra", [(1, 10, True, 0), (8, 10, True, 1), (13, 10, False, 0), (128, 10, True, 2),
+                                            (1030, 10, True, 1), (77, 16, True, 2), (40, 1, True, 1), (1024, 10, True, 2)])
+def test_fc_chain_backward(n, D, noise, extra):
+    """extra: 0 = no external latent gradients, 1 = the btcvae set (dz2, dmu_x, dlv_x), 2 = the factor set (dz2, dz3)."""
+    shapes, W, Bv = _fc_params(D, seed=5)
+    ent = _fc_stage(shapes, W)
+    gd3 = _rand(n, 512, seed=1)
+    acts = {k: torch.relu(_rand(n, w, seed=10 + i)) for i, (k, w) in enumerate(
+        [("d2", 256), ("d1", 256), ("h2", 256), ("h1", 256), ("a_flat", 512)])}
+    mu, lv = _rand(n, D, seed=20), _rand(n, D, seed=21, scale=0.7)
+    eps = torch.randn(n, D, generator=torch.Generator().manual_seed(3)) if noise else None
+    dz2 = _rand(n, D, seed=22) if extra else None
+    dz3 = _rand(n, D, seed=23) if extra == 2 else None
+    dmu_x = _rand(n, D, seed=24) if extra == 1 else None
+    dlv_x = _rand(n, D, seed=25) if extra == 1 else None
+    scal = torch.zeros(_lib.NSCAL); scal[_lib.S_KLW] = 1.7
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / n
+    f = lambda *s: torch.full(s, 7.0, device=DEV)
+    out = dict(gd2=f(n, 256), gd1=f(n, 256), dz=f(n, D), dml=f(n, 2 * D), gh2=f(n, 256), gh1=f(n, 256), ga_flat=f(n, 512))
+    dv = lambda t: None if t is None else dev(t)
+    ins = dict(gd3=dev(gd3), mu=dev(mu), logvar=dev(lv), eps=dv(eps), dz2=dv(dz2), dz3=dv(dz3), dmu_x=dv(dmu_x), dlv_x=dv(dlv_x),
+               scal=dev(scal), coef=dev(coef), **{k: dev(v) for k, v in acts.items()})
+    st, addr = _lib.struct_of(_lib.FcChainBwdArgs, n=n, D=D, **{"w_" + k: ptr(ent[k][2]) for k in shapes},
+                              **{k: ptr(v) for k, v in ins.items()}, **{k: ptr(v) for k, v in out.items()})
+    call("dvae_fc_chain_bwd", addr, stream())
+    Wd = {k: v.double() for k, v in W.items()}
+    g = gd3.double()
+    gd2 = (g @ Wd["d3"]) * (acts["d2"] > 0)
+    gd1 = (gd2 @ Wd["d2"]) * (acts["d1"] > 0)
+    dz = gd1 @ Wd["d1"]
+    gz = dz.clone()
+    if dz2 is not None:
+        gz = gz + dz2.double()
+    if dz3 is not None:
+        gz = gz + dz3.double()
+    klw = 1.7 / n
+    m, l = mu.double(), lv.double()
+    dm = gz + klw * m
+    dl = klw * 0.5 * (torch.exp(l) - 1)
+    if noise:
+        dl = dl + gz * eps.double() * 0.5 * torch.exp(0.5 * l)
+    if dmu_x is not None:
+        dm, dl = dm + dmu_x.double(), dl + dlv_x.double()
+    dml = torch.stack((dm, dl), dim=-1).reshape(n, 2 * D)
+    gh2 = (dml @ Wd["ml"]) * (acts["h2"] > 0)
+    gh1 = (gh2 @ Wd["e2"]) * (acts["h1"] > 0)
+    ga = (gh1 @ Wd["e1"]) * (acts["a_flat"] > 0)
+    tol = dict(rtol=1e-5, atol_rel=2e-6)
+    for k, ref in (("gd2", gd2), ("gd1", gd1), ("dz", dz), ("dml", dml), ("gh2", gh2), ("gh1", gh1), ("ga_flat", ga)):
+        check(out[k], ref, what="chain bwd " + k, **tol)
+    # vs the per-layer entry points (dvae_linear_dgrad with the fused ReLU mask) on the first two layers
+    gd2p, gd1p = torch.empty(n, 256, device=DEV), torch.empty(n, 256, device=DEV)
+    call("dvae_linear_dgrad", ptr(ins["gd3"]), ptr(ent["d3"][0]), ptr(ins["d2"]), _lib.ACT_RELU, ptr(gd2p), n, 256, 512, None, stream())
+    call("dvae_linear_dgrad", ptr(gd2p), ptr(ent["d2"][0]), ptr(ins["d1"]), _lib.ACT_RELU, ptr(gd1p), n, 256, 256, None, stream())
+    check(out["gd1"], gd1p.cpu(), rtol=2e-5, atol_rel=4e-6, what="chain gd1 vs per-layer kernels")

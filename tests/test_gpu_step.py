@@ -3,10 +3,11 @@ and vs the golden vectors recorded from the real reference, same seeds / weights
 
 Stated fp32 tolerances (north_star: "within a stated fp32 tolerance"):
   FIRST step (identical weights on both sides):
-    loss scalars rtol 2e-5 | activations rtol 1e-4 (+2e-5 max) | gradients rtol 1e-3 (+1e-4 max|g|),
-    at most 0.5 % of a tensor's entries may exceed it (a ReLU unit whose pre-activation is within
-    fp32 rounding of 0 can flip between two fp32 implementations -- the fp32 and fp64 oracles
-    differ from each other by the same amount, see tools/debug_step.py);
+    loss scalars rtol 2e-5 | activations rtol 1e-4 (+2e-5 max) | gradients rtol 1e-5 (+2e-6 max|g|), NO outliers, against
+    the fp64 oracle evaluated with the engine's ReLU on/off pattern (oracle/gate_match.py: a unit whose pre-activation is
+    within fp32 rounding of 0 is gated differently by ANY two arithmetics -- the fp32 and fp64 oracles differ from each
+    other by 1e-5 .. 3e-4 of max|g| for that reason); the pattern itself is checked: units gated differently than in fp64
+    must sit within 1e-5 of the layer scale of zero -- the same bar as tests/test_gpu_bench_sizes.py;
     parameters after the Adam step: atol 2.5*lr (Adam's first update is lr*sign(g): a gradient
     entry that is ~0 up to rounding may move by 2*lr in opposite directions).
   LATER steps (each side follows its own trajectory; Adam's normalisation amplifies the above):
@@ -23,6 +24,7 @@ from gpu_util import *  # noqa
 from gpu_util import _lib  # noqa
 from golden_util import load, tensor_digest, assert_digest_close
 from oracle import disvae_oracle as O
+from oracle.gate_match import engine_gates, discriminator_gates, gate_mismatches
 from disvae_amd.models.vae import init_specific_model
 from disvae_amd.models.losses import get_loss_f
 from disvae_amd.training import Trainer
@@ -52,12 +54,18 @@ def check_frac(got, ref, rtol, atol_rel, max_bad, what):
     assert err.max().item() < 200, "%s: gross error x%.0f" % (what, err.max().item())
 
 
-def _compare_grads(model, ref_grads, what, first=True):
+def _compare_grads(model, ref_grads, what):
+    """LATER steps only (each side on its own trajectory): loose, with outliers."""
     for k, p in model.named_parameters():
-        if first:
-            check_frac(p.grad, ref_grads[k], 1e-3, 1e-4, 5e-3, "%s grad %s" % (what, k))
-        else:
-            check_frac(p.grad, ref_grads[k], 2e-2, 5e-3, 2e-2, "%s grad %s" % (what, k))
+        check_frac(p.grad, ref_grads[k], 2e-2, 5e-3, 2e-2, "%s grad %s" % (what, k))
+
+
+G_RTOL, G_ATOL = 1e-5, 2e-6        # first-step gradients vs the gate-matched fp64 oracle, no outliers
+
+
+def _assert_gate_pattern(gates, log, what):
+    n_diff, worst, ok = gate_mismatches(gates, log)
+    assert ok, "%s: a ReLU gated differently than in fp64 at |pre-activation| = %.2e of the layer scale" % (what, worst)
 
 
 @pytest.mark.parametrize("loss,img,B,rec_dist", [
@@ -84,15 +92,7 @@ def test_fused_step_vs_oracle(loss, img, B, rec_dist):
         pre = O.clone_params(orc.params, requires_grad=True)
         st = O.LossState(rec_dist=rec_dist, steps_anneal=HP["reg_anneal"]); st.n_train_steps = orc.state.n_train_steps
         ref_loss, ref_logs, ref_grads, ref_outs = O.train_iteration_grads(loss, hp, st, pre, data, eps)
-        if step == 0:
-            # gradient reference = the fp64 oracle: the fp32 torch-CPU arithmetic itself differs from fp64
-            # by up to ~10x the gradient tolerance (ReLU units flipping at rounding level, see
-            # tools/debug_step.py), the HIP engine agrees with fp64 to ~1e-6 relative
-            pre64 = O.clone_params(orc.params, dtype=torch.float64, requires_grad=True)
-            st64 = O.LossState(rec_dist=rec_dist, steps_anneal=HP["reg_anneal"]); st64.n_train_steps = orc.state.n_train_steps
-            _, _, grads64, _ = O.train_iteration_grads(loss, hp, st64, pre64, data.double(), eps.double())
-            for k, p in model.named_parameters():
-                pass
+        p_step = O.clone_params(orc.params)
         orc.train_iteration(data, eps=eps)
         storer = defaultdict(list)
         out = loss_f.fused_step(dev(data), model, opt, storer, eps=dev(eps))
@@ -104,10 +104,22 @@ def test_fused_step_vs_oracle(loss, img, B, rec_dist):
             check(buf.logvar, ref_outs["logvar"], what="logvar")
             check(buf.z, ref_outs["z"], what="z")
             check(buf.recon, ref_outs["recon"], what="recon")
-        _compare_grads(model, ref_grads, "%s step %d" % (loss, step), first)
         if first:
-            for k, p in model.named_parameters():   # tight check against fp64
-                check(p.grad, grads64[k], rtol=1e-3, atol_rel=1e-4, what="%s grad vs fp64 %s" % (loss, k))
+            # gradient reference = the fp64 oracle evaluated with the engine's ReLU on/off pattern; the pattern is checked
+            gates = engine_gates(model, B)
+            log = []
+            with torch.no_grad(), O.gates(None, record=log):
+                O.vae_forward(O.clone_params(p_step, dtype=torch.float64), data.double(), eps.double())
+            _assert_gate_pattern(gates, log, "%s B=%d" % (loss, B))
+            st64 = O.LossState(rec_dist=rec_dist, steps_anneal=HP["reg_anneal"])
+            with O.gates(gates):
+                _, _, grads64, _ = O.train_iteration_grads(loss, hp, st64, O.clone_params(p_step, dtype=torch.float64,
+                                                                                         requires_grad=True),
+                                                           data.double(), eps.double())
+            for k, p in model.named_parameters():
+                check(p.grad, grads64[k], rtol=G_RTOL, atol_rel=G_ATOL, what="%s grad vs gate-matched fp64 %s" % (loss, k))
+        else:
+            _compare_grads(model, ref_grads, "%s step %d" % (loss, step))
         if step == 0:
             assert list(storer.keys()) == list(ref_logs.keys()), (list(storer.keys()), list(ref_logs.keys()))
             for k in ref_logs:
@@ -141,6 +153,7 @@ def test_factor_step_vs_oracle(img, B):
         pre, dpre = O.clone_params(orc.params, requires_grad=True), O.clone_params(orc.dparams, requires_grad=True)
         st = O.LossState(steps_anneal=HP["reg_anneal"]); st.n_train_steps = orc.state.n_train_steps
         ref_loss, ref_logs, g, gd, outs = O.factor_iteration_grads(hp, st, pre, dpre, data, eps1, eps2, list(perms))
+        p_step, d_step = O.clone_params(orc.params), O.clone_params(orc.dparams)
         orc.train_iteration(data, eps=eps1, eps2=eps2, perms=list(perms))
         storer = defaultdict(list)
         out = loss_f.call_optimize(dev(data), model, opt, storer, noise=(dev(eps1), dev(eps2), perms))
@@ -150,10 +163,26 @@ def test_factor_step_vs_oracle(img, B):
         if first:
             check(buf.z[:Bh], outs["z1"], what="z1")
             check(buf.z[Bh:2 * Bh], outs["z2"], what="z2")
-        _compare_grads(model, g, "factor vae step %d" % step, first)
-        for k, p in loss_f.discriminator.named_parameters():
-            check_frac(p.grad, gd[k], 1e-3 if first else 2e-2, 1e-4 if first else 5e-3, 5e-3 if first else 2e-2,
-                       "disc grad %s step %d" % (k, step))
+        if first:
+            gates = engine_gates(model, B, splits=[slice(0, Bh), slice(Bh, 2 * Bh)], dec_rows=slice(0, Bh))
+            gates.update(discriminator_gates(loss_f.discriminator, 2 * Bh, Bh))
+            c64 = lambda p_: O.clone_params(p_, dtype=torch.float64, requires_grad=True)
+            args64 = lambda: (hp, O.LossState(steps_anneal=HP["reg_anneal"]), c64(p_step), c64(d_step), data.double(),
+                              eps1.double(), eps2.double(), list(perms))
+            log = []
+            with O.gates(None, record=log):
+                O.factor_iteration_grads(*args64())
+            _assert_gate_pattern(gates, log, "factor B=%d" % B)
+            with O.gates(gates):
+                _, _, g64, gd64, _ = O.factor_iteration_grads(*args64())
+            for k, p in model.named_parameters():
+                check(p.grad, g64[k], rtol=G_RTOL, atol_rel=G_ATOL, what="factor grad vs gate-matched fp64 " + k)
+            for k, p in loss_f.discriminator.named_parameters():
+                check(p.grad, gd64[k], rtol=G_RTOL, atol_rel=G_ATOL, what="factor disc grad vs gate-matched fp64 " + k)
+        else:
+            _compare_grads(model, g, "factor vae step %d" % step)
+            for k, p in loss_f.discriminator.named_parameters():
+                check_frac(p.grad, gd[k], 2e-2, 5e-3, 2e-2, "disc grad %s step %d" % (k, step))
         if step == 0:
             assert list(storer.keys()) == list(ref_logs.keys()), (list(storer.keys()), list(ref_logs.keys()))
             for k in ref_logs:
@@ -257,7 +286,9 @@ def test_reference_style_loop_matches_fused():
     for k in st1:
         np.testing.assert_allclose(st1[k][0], st2[k][0], rtol=2e-5, atol=1e-6, err_msg=k)
     for k, p in m2.named_parameters():
-        check(g1[k], p.grad, rtol=1e-5, atol_rel=1e-6, what="autograd-vs-fused " + k)   # same kernels both ways
+        # same conv kernels both ways; the FC core runs layer by layer here and as ONE launch in the fused step (fp32
+        # summation order differs)
+        check(g1[k], p.grad, rtol=1e-5, atol_rel=4e-6, what="autograd-vs-fused " + k)
     # encoder / decoder sub-module call surface (visualize.py:122-123,163,219)
     m1.eval()
     with torch.no_grad():
@@ -446,4 +477,4 @@ def test_autograd_path_after_fused_step_does_not_double_gradients():
     loss.backward()
     l2.fused_step(data2, m2, o2, None, eps=eps2)                  # same iteration through the fused path
     for (k, p), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
-        check(p.grad, p2.grad, rtol=1e-5, atol_rel=1e-6, what="grad after mixing paths " + k)
+        check(p.grad, p2.grad, rtol=1e-5, atol_rel=4e-6, what="grad after mixing paths " + k)

@@ -1,0 +1,131 @@
+"""-m gpu: the configuration bench.py TIMES, pinned.
+
+bench.py steps the model with ``torch.optim.Adam(model.flat_parameters(), lr, fused=True)`` (the parameter arena as equal
+8192-element chunks) where a drop-in user writes ``optim.Adam(model.parameters(), lr)`` (main.py:208).  Here:
+  * both optimizer constructions, from the same state, on the same batches and injected noise, at the bench batch, for
+    3 steps: parameters equal to each other and to torch's CPU Adam fed with the engine's gradients (atol 3e-8: a few
+    ulp of a 0.05-sized weight; the three implementations differ in operation order only);
+  * the 10-step training trajectory of SURVEY.md 8c at the bench batch sizes (btcvae 64x64x3 B = 1024, factor 64x64x1
+    tensor 256) with injected noise, stepped with the timed optimizer construction: loss rtol 1e-3 against the oracle
+    following its own trajectory (training.py:137-164, losses.py:243-313,356-391); step >= 2 exercises arena reuse, the
+    cached gradient views and Adam state at these sizes;
+  * the ADVICE r2 hazard: a flat-chunk optimizer combined with the autograd-compatible path raises instead of stepping
+    with stale gradients."""
+from collections import defaultdict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import *  # noqa
+from gpu_util import _lib  # noqa
+from oracle import disvae_oracle as O
+from disvae_amd.models.vae import init_specific_model
+from disvae_amd.models.losses import get_loss_f
+
+HP = dict(rec_dist="bernoulli", reg_anneal=10000, betaH_B=4, betaB_initC=0, betaB_finC=25, betaB_G=1000,
+          factor_G=6.4, latent_dim=10, btcvae_A=1, btcvae_B=6.4, btcvae_G=1)
+
+
+def _timed_optimizer(model, lr):
+    import bench
+    return bench.make_optimizer(model, lr)          # the very function the timed loop uses
+
+
+def _native(loss, img, seed, n_data, lr, lr_disc, flat):
+    torch.manual_seed(seed)
+    model = init_specific_model("Burgess", img, 10).to(DEV)
+    opt = _timed_optimizer(model, lr) if flat else torch.optim.Adam(model.parameters(), lr=lr)
+    loss_f = get_loss_f(loss, n_data=n_data, device=torch.device(DEV), lr_disc=lr_disc, **HP)
+    loss_f.replay = None
+    model.train()
+    return model, opt, loss_f
+
+
+def test_flat_fused_adam_equals_adam_over_the_state_dict_views():
+    img, B, seed, n_data, lr = (3, 64, 64), 1024, 1234, 202599, 5e-4
+    ma, oa, la = _native("btcvae", img, seed, n_data, lr, 1e-5, True)       # the timed configuration
+    mb, ob, lb = _native("btcvae", img, seed, n_data, lr, 1e-5, False)      # the drop-in configuration
+    assert torch.equal(ma.arena.flat, mb.arena.flat)
+    cpu = [p.detach().cpu().clone().requires_grad_(True) for p in mb.parameters()]
+    oc = torch.optim.Adam(cpu, lr=lr)                                       # the oracle's optimizer (torch CPU Adam)
+    gen = torch.Generator().manual_seed(seed + 1)
+    for step in range(3):
+        data = dev(torch.rand((B,) + img, generator=gen))
+        eps = dev(torch.randn(B, 10, generator=gen))
+        l1 = la.fused_step(data, ma, oa, None, eps=eps)
+        l2 = lb.fused_step(data, mb, ob, None, eps=eps)
+        # same kernels, same inputs, fixed-order reductions: the gradients are bit-identical as long as the parameters are
+        if step == 0:
+            assert torch.equal(ma.arena.grad, mb.arena.grad)
+            assert l1.item() == l2.item()
+        for pc, pb in zip(cpu, mb.parameters()):
+            pc.grad = pb.grad.detach().cpu().clone()
+        oc.step()
+        da = (ma.arena.flat - mb.arena.flat).abs().max().item()
+        assert da <= 3e-8, "step %d: flat fused Adam vs Adam over the views: max |diff| %.3e" % (step, da)
+        for pc, (k, pb) in zip(cpu, mb.named_parameters()):
+            d = (pc.detach() - pb.detach().cpu()).abs().max().item()
+            assert d <= 3e-8, "step %d %s: GPU Adam vs torch CPU Adam on the same gradients: %.3e" % (step, k, d)
+        # the alignment padding of the arena stays zero under the flat optimizer (zero gradient -> zero update)
+        used = torch.zeros_like(ma.arena.flat, dtype=torch.bool)
+        for k, (off, n) in ma.arena.offsets.items():
+            used[off:off + n] = True
+        assert torch.all(ma.arena.flat[~used] == 0)
+
+
+@pytest.mark.parametrize("name,loss,img,B,n_data,lr,lr_disc", [
+    ("btcvae_celeba", "btcvae", (3, 64, 64), 1024, 202599, 5e-4, 1e-5),
+    ("factor_dsprites", "factor", (1, 64, 64), 256, 737280, 1e-4, 1e-4),
+    ("btcvae_b128", "btcvae", (3, 64, 64), 128, 202599, 5e-4, 1e-5),       # the per-GPU batch of the 8-GPU headline config
+])
+def test_ten_step_trajectory_at_bench_batch(name, loss, img, B, n_data, lr, lr_disc):
+    seed = 1234
+    model, opt, loss_f = _native(loss, img, seed, n_data, lr, lr_disc, True)
+    if name == "btcvae_b128":
+        loss_f.replay = "plan"                       # what `auto` selects at this size: the recorded launch plan
+    torch.manual_seed(seed)
+    params = O.init_vae_params(img, 10)
+    dparams = O.init_disc_params(10) if loss == "factor" else None
+    hp = dict(HP, n_data=n_data, lr_disc=lr_disc)
+    orc = O.OracleTrainer(loss, hp, img, 10, lr=lr, lr_disc=lr_disc, steps_anneal=HP["reg_anneal"], params=params,
+                          dparams=dparams)
+    gen = torch.Generator().manual_seed(seed + 1)
+    data_d = torch.empty((B,) + img, device=DEV)     # the batch keeps its address (plans are keyed on it)
+    got, want = [], []
+    for step in range(10):
+        data = torch.rand((B,) + img, generator=gen)
+        data_d.copy_(data)
+        if loss == "factor":
+            Bh = B // 2
+            eps1, eps2 = torch.randn(Bh, 10, generator=gen), torch.randn(Bh, 10, generator=gen)
+            perms = torch.stack([torch.randperm(Bh, generator=gen) for _ in range(10)])
+            ref, _ = orc.train_iteration(data, eps=eps1, eps2=eps2, perms=list(perms))
+            out = loss_f.call_optimize(data_d, model, opt, None, noise=(dev(eps1), dev(eps2), perms))
+        else:
+            eps = torch.randn(B, 10, generator=gen)
+            ref, _ = orc.train_iteration(data, eps=eps)
+            out = loss_f.fused_step(data_d, model, opt, None, eps=dev(eps))
+        got.append(out.item())
+        want.append(ref)
+    np.testing.assert_allclose(got, want, rtol=1e-3, err_msg="%s: loss trajectory" % name)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-5, err_msg="%s: first loss" % name)
+    assert want[-1] < want[0]                        # the workload actually trains
+    for k, p in model.named_parameters():            # parameters after 10 Adam steps: each update is <= ~lr in magnitude
+        d = (p.detach().cpu() - orc.params[k].detach()).abs().max().item()
+        assert d <= 2.5 * lr * 10, "%s: param %s after 10 steps: max diff %.3e" % (name, k, d)
+
+
+def test_flat_optimizer_with_the_autograd_path_is_refused():
+    """autograd delivers gradients to the layer Parameters only; an optimizer built on flat_parameters() would
+    step with whatever its chunks' .grad held.  The autograd-compatible backward refuses that combination."""
+    img, B = (1, 64, 64), 4
+    model, opt, loss_f = _native("btcvae", img, 3, 737280, 5e-4, 1e-4, True)
+    data = dev(torch.rand((B,) + img))
+    loss_f.fused_step(data, model, opt, None)        # flat chunks now carry arena gradients
+    recon, latent_dist, z = model(data)
+    loss = loss_f(data, recon, latent_dist, True, None, latent_sample=z)
+    with pytest.raises(_lib.DvaeHipError, match="flat_parameters"):
+        loss.backward()

@@ -212,8 +212,12 @@ def test_unknown_replay_mode_is_reported(monkeypatch):
     import pytest
     from disvae_amd.models.losses import BetaHLoss
     monkeypatch.setenv("DVAE_REPLAY", "sometimes")
+    assert BetaHLoss().replay == "auto"          # host A/B switches are inert without DVAE_DEBUG=1 (disvae_amd/_debug.py)
+    monkeypatch.setenv("DVAE_DEBUG", "1")
     with pytest.raises(ValueError, match="DVAE_REPLAY"):
         BetaHLoss()
+    monkeypatch.setenv("DVAE_REPLAY", "eager")
+    assert BetaHLoss().replay is None
 
 
 def test_bench_reads_hbm_traffic_from_the_newest_pmc_summary(tmp_path, monkeypatch):

@@ -6,6 +6,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "disentangling-vae_amd")):
     sys.path.insert(0, p)
+import ctypes
 import torch
 from disvae_amd import _lib
 from disvae_amd._lib import call, ptr, NCHW, NHWC
@@ -46,6 +47,15 @@ for H in (32, 16, 8):        # big side H x H x 32 <-> small side H/2
     report("convT fwd  %dx%d->%dx%d" % (hs, hs, H, H), timeit(lambda: call("dvae_convT4s2_fwd", ptr(small), NHWC, ptr(w), ptr(b), ptr(big), NHWC, B, 32, hs, hs, 32, 1, s)), 2 * macs, nb + ns)
     report("conv dgrad (up+mask)", timeit(lambda: call("dvae_conv4s2_dgrad", ptr(small), NHWC, ptr(w), ptr(big), ptr(big), NHWC, B, 32, H, H, 32, s)), 2 * macs, 2 * nb + ns)
     report("conv wgrad (+reduce)", timeit(lambda: call("dvae_conv4s2_wgrad", ptr(big), NHWC, ptr(small), NHWC, ptr(dw), ptr(db), B, 32, H, H, 32, ptr(ws), s)), 2 * macs, nb + ns)
+    # the same kernels on pre-staged weight images (dvae_stage_weights): what the training step launches
+    imd, imu = torch.empty(16384, device=dev), torch.empty(16384, device=dev)
+    cd = (_lib.ConvImageDesc * 1)()
+    cd[0].w, cd[0].img_down, cd[0].img_up = ptr(w), ptr(imd), ptr(imu)
+    call("dvae_stage_weights", ctypes.addressof(cd), 1, None, 0, None, None, s)
+    report("  staged: conv fwd (down)", timeit(lambda: call("dvae_conv32_down", ptr(big), ptr(imd), ptr(b), None, ptr(small), NHWC, B, hs, 1, s)), 2 * macs, nb + ns)
+    report("  staged: convT dgrad (down+mask)", timeit(lambda: call("dvae_conv32_down", ptr(big), ptr(imd), None, ptr(small), ptr(small), NHWC, B, hs, 0, s)), 2 * macs, nb + 2 * ns)
+    report("  staged: convT fwd (up)", timeit(lambda: call("dvae_conv32_up", ptr(small), NHWC, ptr(imu), ptr(b), None, ptr(big), B, hs, 1, s)), 2 * macs, nb + ns)
+    report("  staged: conv dgrad (up+mask)", timeit(lambda: call("dvae_conv32_up", ptr(small), NHWC, ptr(imu), None, ptr(big), ptr(big), B, hs, 0, s)), 2 * macs, 2 * nb + ns)
 for C in (3,):
     x = torch.rand(B, C, 64, 64, device=dev)
     a1 = torch.rand(B, 32, 32, 32, device=dev)
@@ -66,15 +76,6 @@ for C in (3,):
     report("convT3 fwd + likelihood (up_thin fused)", timeit(lambda: call("dvae_convT4s2_sigmoid_recon_fwd", ptr(a1), NHWC, ptr(w), ptr(bc), ptr(tgt), ptr(rec), ptr(g), 0, ptr(coef), ptr(parts), B, 32, 32, 32, C, s)), 2 * macs, 3 * nx + na)
     dbc = torch.empty(C, device=dev)
     report("convT3 wgrad (wgrad_thin+reduce)", timeit(lambda: call("dvae_convT4s2_wgrad", ptr(a1), NHWC, ptr(g), NCHW, ptr(dw), ptr(dbc), B, 32, 32, 32, C, ptr(ws), s)), 2 * macs, nx + na)
-    # the accumulation kernels alone, and the fixed-order reductions alone (one layer per launch)
-    report("conv1 wgrad, partial sums only", timeit(lambda: call("dvae_conv4s2_wgrad_partial", ptr(x), NCHW, ptr(a1), NHWC, B, C, 64, 64, 32, ptr(ws), s)), 2 * macs, nx + na)
-    d1 = _lib.conv_wgrad_descs([(ptr(ws), ptr(dw), ptr(db), B, C, 64, 64, 32, 0)])
-    report("conv1 wgrad, reduction only", timeit(lambda: call("dvae_conv_wgrad_reduce_grouped", d1[1], 1, s)), 0, 0)
-    big2, small2 = torch.rand(B, 32, 32, 32, device=dev), torch.rand(B, 16, 16, 32, device=dev)
-    dw2, db2 = torch.empty(32, 32, 4, 4, device=dev), torch.empty(32, device=dev)
-    report("conv2 wgrad, partial sums only", timeit(lambda: call("dvae_conv4s2_wgrad_partial", ptr(big2), NHWC, ptr(small2), NHWC, B, 32, 32, 32, 32, ptr(ws), s)), 2.0 * B * 256 * 32 * 512, big2.numel() * 4 + small2.numel() * 4)
-    d2 = _lib.conv_wgrad_descs([(ptr(ws), ptr(dw2), ptr(db2), B, 32, 32, 32, 32, 0)])
-    report("conv2 wgrad, reduction only", timeit(lambda: call("dvae_conv_wgrad_reduce_grouped", d2[1], 1, s)), 0, 0)
     report("recon_loss (bernoulli)", timeit(lambda: call("dvae_recon_loss", ptr(x), ptr(x), x.numel(), 0, ptr(coef), ptr(parts), ptr(g), 1, s)), 0, 3 * nx)
 for (M, K, N) in ((B, 512, 256), (B, 256, 256), (B, 256, 20), (B, 10, 256), (B, 256, 512), (B, 1000, 1000)):
     x = torch.rand(M, K, device=dev); w = torch.rand(N, K, device=dev); b = torch.zeros(N, device=dev)
@@ -83,6 +84,20 @@ for (M, K, N) in ((B, 512, 256), (B, 256, 256), (B, 256, 20), (B, 10, 256), (B, 
     report("linear fwd   %dx%dx%d" % (M, K, N), timeit(lambda: call("dvae_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, K, N, 1, ptr(ws), s)), fl, 4 * (M * K + N * K + M * N))
     report("linear dgrad", timeit(lambda: call("dvae_linear_dgrad", ptr(y), ptr(w), ptr(x), 1, ptr(dx), M, K, N, ptr(ws), s)), fl, 4 * (M * K + N * K + M * N))
     report("linear wgrad", timeit(lambda: call("dvae_linear_wgrad", ptr(x), ptr(y), ptr(dwt), ptr(b), M, K, N, ptr(ws), s)), fl, 4 * (M * K + N * K + M * N))
+# ---- the FC core as one launch per direction + the per-step staging launch
+from disvae_amd.models.vae import init_specific_model
+model = init_specific_model("Burgess", (3, 64, 64), 10).to(dev)
+eng = model.engine
+buf = eng.buffers(B)
+buf.a_flat.uniform_(0, 1)
+coefd = torch.full((8,), 1.0 / B, device=dev)
+scal = torch.zeros(32, device=dev)
+eps = torch.randn(B, 10, device=dev)
+kl = torch.zeros(_lib.KL_FLOATS, device=dev)
+report("stage_weights (6 conv + 6 fc + coef)", timeit(lambda: eng.stage(coefd, [1.0 / B] * 8)), 0, 0)
+fl = 2.0 * B * 400896
+report("fc_chain_fwd  (7 launches before)", timeit(lambda: eng.fc_chain_fwd(buf, eps, kl, B)), fl, 1.6e6)
+report("fc_chain_bwd  (7 launches before)", timeit(lambda: eng.fc_chain_bwd(buf, eps, None, None, None, None, scal, coefd, B)), fl, 1.6e6)
 D = 10
 z = torch.randn(B, D, device=dev); mu = torch.randn(B, D, device=dev); lv = torch.randn(B, D, device=dev) * 0.5
 lw = torch.tensor([-12.0, -7.0, -6.9, 0.0], device=dev); rs = torch.empty(B, 16, device=dev); tmp = torch.empty(3 * D, B, device=dev)

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT="$REPO/gpurun_out/pmc"
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-check"
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
 pass() {  # name counters...
   local name=$1; shift
   (cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -o p -- $CMD > "$OUT/$name.log" 2>&1)

@@ -1,5 +1,6 @@
 """Timeline of ONE training iteration from a rocprofv3 --kernel-trace run (rocpd sqlite db):
-every kernel of the last complete iteration (iterations are delimited by k_set_coef) with its queue,
+every kernel of the last complete iteration (iterations are delimited by the step's first launch: k_stage_weights,
+k_set_coef before round 3) with its queue,
 start offset, duration and the idle gap in front of it on the same queue, plus per-queue busy time
 and the union busy time (any queue active)."""
 import sqlite3
@@ -10,7 +11,7 @@ from prof_summary import short
 def main(db, which=-2):
     con = sqlite3.connect(db)
     rows = list(con.execute("select name, queue_id, start, end from kernels order by start"))
-    marks = [i for i, r in enumerate(rows) if "k_set_coef" in r[0]]
+    marks = [i for i, r in enumerate(rows) if "k_stage_weights" in r[0]] or [i for i, r in enumerate(rows) if "k_set_coef" in r[0]]
     a, b = marks[which], marks[which + 1]
     step = rows[a:b]
     t0 = step[0][2]
