@@ -26,9 +26,11 @@ if has probe; then echo "== probe"; timeout 120 tools/ubench/mfma4x4_probe 2>&1 
 if has fused; then
   echo "== pytest (round-3 kernels)"
   timeout 900 python -m pytest tests/test_gpu_fused_core.py tests/test_gpu_timed_config.py -m gpu -q --timeout=300 --no-header > gpurun_out/${TAG}_pytest_fused.log 2>&1
-  echo "pytest exit: $?" | tee -a gpurun_out/${TAG}_pytest_fused.log
+  FUSED_RC=$?
+  echo "pytest exit: $FUSED_RC" | tee -a gpurun_out/${TAG}_pytest_fused.log
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_fused.log | cut -c1-260 | head -40
   grep -n -m3 -A6 "^E  " gpurun_out/${TAG}_pytest_fused.log | cut -c1-300 | head -40
+  if [ "$FUSED_RC" != "0" ] && [ "${STOP_ON_FUSED_FAIL:-0}" = "1" ]; then echo "== round-3 kernel tests failed: skipping the remaining steps"; STEPS="${FAIL_STEPS:-}"; fi
 fi
 if has tests; then
   echo "== pytest -m gpu"
