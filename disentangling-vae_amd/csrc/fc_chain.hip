@@ -145,21 +145,21 @@ __device__ __forceinline__ void gemm_small_c(const float* __restrict__ wp, int c
 }
 
 // 8 x C rows of a row-major [n][C] tensor -> LDS tile (zero rows beyond n)
-template <int C>
+template <int C, int NT>
 __device__ __forceinline__ void load_rows(const float* __restrict__ x, int row0, int n, float* tile, int tid) {
   constexpr int Q = C / 4;                      // 16-byte chunks per row
-  constexpr int NP = FCC_R * Q / 256;
+  constexpr int NP = FCC_R * Q / NT;
   f32x4 v[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    const int idx = tid + 256 * p;
+    const int idx = tid + NT * p;
     const int r = idx / Q, q = idx % Q;
     v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (row0 + r < n) v[p] = *reinterpret_cast<const f32x4*>(x + (long)(row0 + r) * C + q * 4);
   }
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    const int idx = tid + 256 * p;
+    const int idx = tid + NT * p;
     *reinterpret_cast<f32x4*>(tile + (idx / Q) * FCC_XS + (idx % Q) * 4) = v[p];
   }
 }
@@ -167,36 +167,85 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ x, int row0,
 struct FwdArgs { dvae_fc_chain_fwd_args a; };
 struct BwdArgs { dvae_fc_chain_bwd_args a; };
 
+// Work split of a workgroup.  KS = 1: 4 waves, wave w owns output columns 64w .. 64w+63 of a 256-wide layer over the whole
+// contraction (both 256-column halves of a 512-wide one).  KS = 2: 8 waves (two per SIMD, twice the weight bytes in flight
+// per CU -- the launch is bound by the latency of its L2 -> register weight stream, see the file header): wave (cg, kh) owns
+// columns 64cg .. of contraction half kh, the two halves are added through LDS in a fixed order (kh = 0 first); of a 512-wide
+// layer it owns the 256-column half kh over the whole contraction.  DEPTH = weight chunks in flight per wave.
+template <int KS>
+struct Lane {
+  int tid, lane, wv, cg, kh, col, xo;
+  __device__ __forceinline__ Lane() {
+    tid = threadIdx.x; lane = tid & 63;
+    wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cg = wv & 3; kh = KS == 2 ? wv >> 2 : 0;
+    col = cg * 64 + lane;
+    xo = (lane & 3) * FCC_XS;
+  }
+};
+
+// 256-wide layer, contraction of NCH chunks: complete sums in v[] of the waves with kh == 0 (one workgroup barrier inside
+// when KS == 2).  wp = this layer's image + col * 4; tile = activation tile.  The next layer's first chunks are requested
+// into nring from wn (already offset for this wave) while the last DEPTH chunks are consumed.
+template <int DEPTH, int KS, int NCH, int NCHN, int NGN>
+__device__ __forceinline__ void layer256(const Lane<KS>& L, Ring<DEPTH, 1>& ring, const float* __restrict__ wp, int cstride,
+                                         const float* tile, Ring<DEPTH, (NGN > 0 ? NGN : 1)>& nring,
+                                         const float* __restrict__ wn, int gstride_n, int cstride_n, float* part, float (&v)[8]) {
+  constexpr int NW = NCH / KS;                  // chunks per wave
+  Acc8 acc[1];
+  acc_zero(acc[0]);
+  gemm_run<DEPTH, NW, 1, NCHN, NGN>(ring, wp + (long)L.kh * NW * cstride, 0, cstride, tile + L.xo + L.kh * NW * 4, acc, nring, wn,
+                                    gstride_n, cstride_n);
+  acc_rows(acc[0], v);
+  if (KS == 2) {
+    if (L.kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) part[r * FCC_HID + L.col] = v[r];
+    }
+    __syncthreads();
+    if (L.kh == 0) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += part[r * FCC_HID + L.col];
+    }
+  }
+}
+
+// first chunks of a 256-wide layer's stream for this wave
+template <int DEPTH, int KS, int NCH>
+__device__ __forceinline__ void fill256(const Lane<KS>& L, Ring<DEPTH, 1>& ring, const float* __restrict__ wp, int cstride) {
+  ring_fill<DEPTH, 1, NCH / KS>(ring, wp + (long)L.kh * (NCH / KS) * cstride, 0, cstride);
+}
+
 // ---------------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(256) void k_fc_chain_fwd(const FwdArgs P) {
+template <int DEPTH, int KS>
+__global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   const dvae_fc_chain_fwd_args& a = P.a;
+  constexpr int NT = 256 * KS, NWV = 4 * KS;
+  constexpr int SD = 64 / NWV;                      // chunks per wave of a layer whose contraction is split over ALL waves
+  constexpr int G512 = KS == 2 ? 1 : 2;             // 256-column halves of a 512-wide layer per wave
   __shared__ __attribute__((aligned(16))) float tA[FCC_R * FCC_XS];
   __shared__ __attribute__((aligned(16))) float tB[FCC_R * FCC_XS];
-  __shared__ float red[4][FCC_R][64];
+  __shared__ float red[NWV][FCC_R][64];
   __shared__ float mlt[FCC_R][64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __shared__ float part[KS == 2 ? FCC_R * FCC_HID : 1];
+  const Lane<KS> L;
+  const int tid = L.tid, lane = L.lane, wv = L.wv, col = L.col, xo = L.xo;
+  const bool own = L.kh == 0;                       // this wave finishes the 256-wide layers (bias, activation, stores)
   const int row0 = blockIdx.x * FCC_R;
   const int D = a.D, D2 = 2 * a.D;
-  const int col = wv * 64 + lane;                   // this lane's output column in a 256-wide layer
-  const int xo = (lane & 3) * FCC_XS;
   constexpr int CS = FCC_HID * 4;                   // chunk stride of a 256-wide image
 
-  Ring<8, 1> r1, r2;
-  Ring<8, 1> dummy;
-  Ring<16, 1> dummy16;
-  ring_fill<8, 1, 128>(r1, a.w_e1 + col * 4, 0, CS);
-  load_rows<FCC_FLAT>(a.a_flat, row0, a.n_enc, tA, tid);
+  Ring<DEPTH, 1> r1, r2, dummy;
+  Ring<SD, 1> dummy_s;
+  fill256<DEPTH, KS, 128>(L, r1, a.w_e1 + col * 4, CS);
+  load_rows<FCC_FLAT, NT>(a.a_flat, row0, a.n_enc, tA, tid);
   const float be1 = a.b_e1[col], be2 = a.b_e2[col];
   __syncthreads();
 
   float v[8];
   // ---- encoder lin1: 512 -> 256, ReLU
-  {
-    Acc8 acc[1];
-    acc_zero(acc[0]);
-    gemm_run<8, 128, 1, 64, 1>(r1, a.w_e1 + col * 4, 0, CS, tA + xo, acc, r2, a.w_e2 + col * 4, 0, CS);
-    acc_rows(acc[0], v);
+  layer256<DEPTH, KS, 128, 64 / KS, 1>(L, r1, a.w_e1 + col * 4, CS, tA, r2, a.w_e2 + col * 4 + (long)L.kh * (64 / KS) * CS, 0, CS, part, v);
+  if (own) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       v[r] = fmaxf(v[r] + be1, 0.f);
@@ -205,15 +254,13 @@ __global__ __launch_bounds__(256) void k_fc_chain_fwd(const FwdArgs P) {
     }
   }
   __syncthreads();
-  // ---- encoder lin2: 256 -> 256, ReLU; meanwhile request this wave's slice of mu_logvar_gen (contraction split over the waves)
-  Ring<16, 1> rml;
-  {
-    Acc8 acc[1];
-    acc_zero(acc[0]);
-    gemm_run<8, 64, 1, 0, 0>(r2, a.w_e2 + col * 4, 0, CS, tB + xo, acc, dummy, nullptr, 0, 0);
-    const int cml = lane < D2 ? lane : D2 - 1;
-    ring_fill<16, 1, 16>(rml, a.w_ml + ((long)wv * 16 * D2 + cml) * 4, 0, D2 * 4);
-    acc_rows(acc[0], v);
+  // ---- encoder lin2: 256 -> 256, ReLU; meanwhile request this wave's slice of mu_logvar_gen (contraction split over ALL waves)
+  Ring<SD, 1> rml;
+  const int cml = lane < D2 ? lane : D2 - 1;
+  const float* wml = a.w_ml + ((long)wv * SD * D2 + cml) * 4;
+  layer256<DEPTH, KS, 64, 0, 0>(L, r2, a.w_e2 + col * 4, CS, tB, dummy, nullptr, 0, 0, part, v);
+  ring_fill<SD, 1, SD>(rml, wml, 0, D2 * 4);
+  if (own) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       v[r] = fmaxf(v[r] + be2, 0.f);
@@ -222,24 +269,26 @@ __global__ __launch_bounds__(256) void k_fc_chain_fwd(const FwdArgs P) {
     }
   }
   __syncthreads();
-  // ---- mu_logvar_gen: 256 -> 2D (no activation): wave w contracts k in [64w, 64w+64), partial sums through LDS
+  // ---- mu_logvar_gen: 256 -> 2D (no activation): wave w contracts k in [4 SD w, 4 SD (w+1)), partial sums through LDS
   {
     Acc8 acc[1];
     acc_zero(acc[0]);
-    const int cml = lane < D2 ? lane : D2 - 1;
-    gemm_run<16, 16, 1, 0, 0>(rml, a.w_ml + ((long)wv * 16 * D2 + cml) * 4, 0, D2 * 4, tA + xo + wv * 64, acc, dummy16, nullptr, 0, 0);
+    gemm_run<SD, SD, 1, 0, 0>(rml, wml, 0, D2 * 4, tA + xo + wv * SD * 4, acc, dummy_s, nullptr, 0, 0);
     acc_rows(acc[0], v);
 #pragma unroll
     for (int r = 0; r < 8; ++r) red[wv][r][lane] = v[r];
   }
-  // the decoder's first two weight streams do not depend on anything computed here: request them now
-  Ring<8, 1> rd2;
+  // the decoder's second weight stream does not depend on anything computed here: request it now
+  Ring<DEPTH, 1> rd2;
   const bool dec = row0 < a.n_dec;                  // workgroup-uniform
-  if (dec) ring_fill<8, 1, 64>(rd2, a.w_d2 + col * 4, 0, CS);
+  if (dec) fill256<DEPTH, KS, 64>(L, rd2, a.w_d2 + col * 4, CS);
   __syncthreads();
-  for (int t = tid; t < FCC_R * D2; t += 256) {
+  for (int t = tid; t < FCC_R * D2; t += NT) {
     const int r = t / D2, j = t % D2;
-    const float m = ((red[0][r][j] + red[1][r][j]) + (red[2][r][j] + red[3][r][j])) + a.b_ml[j];
+    float m = red[0][r][j];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) m += red[w][r][j];
+    m += a.b_ml[j];
     mlt[r][j] = m;
     if (row0 + r < a.n_enc) a.ml[(long)(row0 + r) * D2 + j] = m;
   }
@@ -248,7 +297,7 @@ __global__ __launch_bounds__(256) void k_fc_chain_fwd(const FwdArgs P) {
   {
     float* klt = &red[0][0][0];                     // [8][16]
     const int dp = (D + 3) & ~3;
-    for (int t = tid; t < FCC_R * 16; t += 256) {
+    for (int t = tid; t < FCC_R * 16; t += NT) {
       const int r = t >> 4, d = t & 15;
       float kl = 0.f;
       if (d < dp) {
@@ -278,7 +327,7 @@ __global__ __launch_bounds__(256) void k_fc_chain_fwd(const FwdArgs P) {
   if (!dec) return;
   const float bd1 = a.b_d1[col], bd2 = a.b_d2[col];
   // ---- decoder lin1: D -> 256, ReLU
-  {
+  if (own) {
     Acc8 acc;
     acc_zero(acc);
     gemm_small_c(a.w_d1 + col * 4, CS, (D + 3) >> 2, tB + xo, acc);
@@ -291,13 +340,11 @@ __global__ __launch_bounds__(256) void k_fc_chain_fwd(const FwdArgs P) {
     }
   }
   __syncthreads();
-  // ---- decoder lin2: 256 -> 256, ReLU
-  Ring<8, 2> rd3;
-  {
-    Acc8 acc[1];
-    acc_zero(acc[0]);
-    gemm_run<8, 64, 1, 64, 2>(rd2, a.w_d2 + col * 4, 0, CS, tA + xo, acc, rd3, a.w_d3 + col * 4, FCC_HID * 4, FCC_FLAT * 4);
-    acc_rows(acc[0], v);
+  // ---- decoder lin2: 256 -> 256, ReLU; its tail requests lin3's stream (512 wide: column half kh when KS == 2, both else)
+  Ring<DEPTH, G512> rd3;
+  const float* wd3 = a.w_d3 + (col + (KS == 2 ? L.kh * FCC_HID : 0)) * 4;
+  layer256<DEPTH, KS, 64, 64, G512>(L, rd2, a.w_d2 + col * 4, CS, tA, rd3, wd3, FCC_HID * 4, FCC_FLAT * 4, part, v);
+  if (own) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       v[r] = fmaxf(v[r] + bd2, 0.f);
@@ -306,56 +353,60 @@ __global__ __launch_bounds__(256) void k_fc_chain_fwd(const FwdArgs P) {
     }
   }
   __syncthreads();
-  // ---- decoder lin3: 256 -> 512, ReLU (columns col and 256 + col)
+  // ---- decoder lin3: 256 -> 512, ReLU
   {
-    Acc8 acc[2];
-    acc_zero(acc[0]); acc_zero(acc[1]);
-    const float b0 = a.b_d3[col], b1 = a.b_d3[FCC_HID + col];
-    gemm_run<8, 64, 2, 0, 0>(rd3, a.w_d3 + col * 4, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
+    Acc8 acc[G512];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < G512; ++g) acc_zero(acc[g]);
+    gemm_run<DEPTH, 64, G512, 0, 0>(rd3, wd3, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G512; ++g) {
+      const int c512 = col + (KS == 2 ? L.kh : g) * FCC_HID;
+      const float b = a.b_d3[c512];
       acc_rows(acc[g], v);
 #pragma unroll
       for (int r = 0; r < 8; ++r)
-        if (row0 + r < a.n_dec) a.d3[(long)(row0 + r) * FCC_FLAT + g * FCC_HID + col] = fmaxf(v[r] + (g ? b1 : b0), 0.f);
+        if (row0 + r < a.n_dec) a.d3[(long)(row0 + r) * FCC_FLAT + c512] = fmaxf(v[r] + b, 0.f);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-__global__ __launch_bounds__(256) void k_fc_chain_bwd(const BwdArgs P) {
+template <int DEPTH, int KS>
+__global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   const dvae_fc_chain_bwd_args& a = P.a;
+  constexpr int NT = 256 * KS, NWV = 4 * KS;
+  constexpr int SD = 64 / NWV;
+  constexpr int G512 = KS == 2 ? 1 : 2;
   __shared__ __attribute__((aligned(16))) float tA[FCC_R * FCC_XS];
   __shared__ __attribute__((aligned(16))) float tB[FCC_R * FCC_XS];
-  __shared__ float red[4][FCC_R][64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __shared__ float red[NWV][FCC_R][64];
+  __shared__ float part[KS == 2 ? FCC_R * FCC_HID : 1];
+  const Lane<KS> L;
+  const int tid = L.tid, lane = L.lane, wv = L.wv, col = L.col, xo = L.xo;
+  const bool own = L.kh == 0;
   const int row0 = blockIdx.x * FCC_R;
   const int n = a.n;
   const int D = a.D, D2 = 2 * a.D;
-  const int col = wv * 64 + lane;
-  const int xo = (lane & 3) * FCC_XS;
   constexpr int CS = FCC_HID * 4;
 
-  Ring<8, 1> r3, r2, re2;
-  Ring<8, 1> dummy;
-  Ring<16, 1> dummy16;
-  ring_fill<8, 1, 128>(r3, a.w_d3 + col * 4, 0, CS);
-  load_rows<FCC_FLAT>(a.gd3, row0, n, tA, tid);
+  Ring<DEPTH, 1> r3, r2, re2, dummy;
+  Ring<SD, 1> dummy_s;
+  fill256<DEPTH, KS, 128>(L, r3, a.w_d3 + col * 4, CS);
+  load_rows<FCC_FLAT, NT>(a.gd3, row0, n, tA, tid);
   float mk[8], v[8];
   // ReLU mask of a 256-wide layer = its saved post-activation output (zero rows beyond n: their gradients are not stored)
   auto load_mask = [&](const float* __restrict__ act) {
+    if (own) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) mk[r] = row0 + r < n ? act[(long)(row0 + r) * FCC_HID + col] : 0.f;
+      for (int r = 0; r < 8; ++r) mk[r] = row0 + r < n ? act[(long)(row0 + r) * FCC_HID + col] : 0.f;
+    }
   };
   load_mask(a.d2);
   __syncthreads();
   // ---- decoder lin3 input gradient: 512 -> 256, mask d2
-  {
-    Acc8 acc[1];
-    acc_zero(acc[0]);
-    gemm_run<8, 128, 1, 64, 1>(r3, a.w_d3 + col * 4, 0, CS, tA + xo, acc, r2, a.w_d2 + col * 4, 0, CS);
-    acc_rows(acc[0], v);
+  layer256<DEPTH, KS, 128, 64 / KS, 1>(L, r3, a.w_d3 + col * 4, CS, tA, r2, a.w_d2 + col * 4 + (long)L.kh * (64 / KS) * CS, 0, CS, part, v);
+  if (own) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       v[r] = mk[r] > 0.f ? v[r] : 0.f;
@@ -365,15 +416,13 @@ __global__ __launch_bounds__(256) void k_fc_chain_bwd(const BwdArgs P) {
   }
   load_mask(a.d1);
   __syncthreads();
-  // ---- decoder lin2 input gradient: 256 -> 256, mask d1; request this wave's slice of lin1's (256 -> D, split over the waves)
-  Ring<16, 1> r1;
-  {
-    Acc8 acc[1];
-    acc_zero(acc[0]);
-    gemm_run<8, 64, 1, 0, 0>(r2, a.w_d2 + col * 4, 0, CS, tB + xo, acc, dummy, nullptr, 0, 0);
-    const int c1 = lane < D ? lane : D - 1;
-    ring_fill<16, 1, 16>(r1, a.w_d1 + ((long)wv * 16 * D + c1) * 4, 0, D * 4);
-    acc_rows(acc[0], v);
+  // ---- decoder lin2 input gradient: 256 -> 256, mask d1; request this wave's slice of lin1's (256 -> D, split over ALL waves)
+  Ring<SD, 1> r1;
+  const int c1 = lane < D ? lane : D - 1;
+  const float* w1 = a.w_d1 + ((long)wv * SD * D + c1) * 4;
+  layer256<DEPTH, KS, 64, 0, 0>(L, r2, a.w_d2 + col * 4, CS, tB, dummy, nullptr, 0, 0, part, v);
+  ring_fill<SD, 1, SD>(r1, w1, 0, D * 4);
+  if (own) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       v[r] = mk[r] > 0.f ? v[r] : 0.f;
@@ -386,26 +435,27 @@ __global__ __launch_bounds__(256) void k_fc_chain_bwd(const BwdArgs P) {
   {
     Acc8 acc[1];
     acc_zero(acc[0]);
-    const int c1 = lane < D ? lane : D - 1;
-    gemm_run<16, 16, 1, 0, 0>(r1, a.w_d1 + ((long)wv * 16 * D + c1) * 4, 0, D * 4, tA + xo + wv * 64, acc, dummy16, nullptr, 0, 0);
+    gemm_run<SD, SD, 1, 0, 0>(r1, w1, 0, D * 4, tA + xo + wv * SD * 4, acc, dummy_s, nullptr, 0, 0);
     acc_rows(acc[0], v);
 #pragma unroll
     for (int r = 0; r < 8; ++r) red[wv][r][lane] = v[r];
   }
-  ring_fill<8, 1, 64>(re2, a.w_e2 + col * 4, 0, CS);      // encoder lin2's stream: independent of the latent glue below
+  fill256<DEPTH, KS, 64>(L, re2, a.w_e2 + col * 4, CS);   // encoder lin2's stream: independent of the latent glue below
   load_mask(a.h2);
   __syncthreads();
   // ---- reparameterisation + KL backward (k_reparam_kl_bwd's arithmetic) -> dml[8][2D] (interleaved) -> tB, zero padded
   {
     const float klw = a.scal[DVAE_S_KLW] * a.coef[DVAE_C_INV_B];
     const int dp2 = (D2 + 3) & ~3;
-    for (int t = tid; t < FCC_R * 32; t += 256) {
+    for (int t = tid; t < FCC_R * 32; t += NT) {
       const int r = t >> 5, d = t & 31;
       if (d < D) {
         float dm = 0.f, dl = 0.f;
         if (row0 + r < n) {
           const long o = (long)(row0 + r) * D + d;
-          float g = (red[0][r][d] + red[1][r][d]) + (red[2][r][d] + red[3][r][d]);
+          float g = red[0][r][d];
+#pragma unroll
+          for (int w = 1; w < NWV; ++w) g += red[w][r][d];
           if (a.dz) a.dz[o] = g;
           if (a.dz2) g += a.dz2[o];
           if (a.dz3) g += a.dz3[o];
@@ -429,7 +479,7 @@ __global__ __launch_bounds__(256) void k_fc_chain_bwd(const BwdArgs P) {
   }
   __syncthreads();
   // ---- mu_logvar_gen input gradient: 2D -> 256, mask h2
-  {
+  if (own) {
     Acc8 acc;
     acc_zero(acc);
     gemm_small_c(a.w_ml + col * 4, CS, (D2 + 3) >> 2, tB + xo, acc);
@@ -443,13 +493,12 @@ __global__ __launch_bounds__(256) void k_fc_chain_bwd(const BwdArgs P) {
   }
   load_mask(a.h1);
   __syncthreads();
-  // ---- encoder lin2 input gradient: 256 -> 256, mask h1
-  Ring<8, 2> re1;
-  {
-    Acc8 acc[1];
-    acc_zero(acc[0]);
-    gemm_run<8, 64, 1, 64, 2>(re2, a.w_e2 + col * 4, 0, CS, tA + xo, acc, re1, a.w_e1 + col * 4, FCC_HID * 4, FCC_FLAT * 4);
-    acc_rows(acc[0], v);
+  // ---- encoder lin2 input gradient: 256 -> 256, mask h1; its tail requests lin1's stream (512 wide)
+  Ring<DEPTH, G512> re1;
+  const int half = KS == 2 ? L.kh : 0;
+  const float* we1 = a.w_e1 + (col + half * FCC_HID) * 4;
+  layer256<DEPTH, KS, 64, 64, G512>(L, re2, a.w_e2 + col * 4, CS, tA, re1, we1, FCC_HID * 4, FCC_FLAT * 4, part, v);
+  if (own) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       v[r] = mk[r] > 0.f ? v[r] : 0.f;
@@ -457,33 +506,59 @@ __global__ __launch_bounds__(256) void k_fc_chain_bwd(const BwdArgs P) {
       if (row0 + r < n) a.gh1[(long)(row0 + r) * FCC_HID + col] = v[r];
     }
   }
-  // masks of the 512-wide output: the conv stack's flattened activation (encoders.py:80), columns col and 256 + col
-  float mk2[2][8];
+  // masks of the 512-wide output: the conv stack's flattened activation (encoders.py:80)
+  float mk2[G512][8];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < G512; ++g)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) mk2[g][r] = row0 + r < n ? a.a_flat[(long)(row0 + r) * FCC_FLAT + g * FCC_HID + col] : 0.f;
+    for (int r = 0; r < 8; ++r)
+      mk2[g][r] = row0 + r < n ? a.a_flat[(long)(row0 + r) * FCC_FLAT + (KS == 2 ? half : g) * FCC_HID + col] : 0.f;
   __syncthreads();
   // ---- encoder lin1 input gradient: 256 -> 512, mask a_flat
   {
-    Acc8 acc[2];
-    acc_zero(acc[0]); acc_zero(acc[1]);
-    gemm_run<8, 64, 2, 0, 0>(re1, a.w_e1 + col * 4, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
+    Acc8 acc[G512];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < G512; ++g) acc_zero(acc[g]);
+    gemm_run<DEPTH, 64, G512, 0, 0>(re1, we1, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G512; ++g) {
+      const int c512 = col + (KS == 2 ? half : g) * FCC_HID;
       acc_rows(acc[g], v);
 #pragma unroll
       for (int r = 0; r < 8; ++r)
-        if (row0 + r < n) a.ga_flat[(long)(row0 + r) * FCC_FLAT + g * FCC_HID + col] = mk2[g][r] > 0.f ? v[r] : 0.f;
+        if (row0 + r < n) a.ga_flat[(long)(row0 + r) * FCC_FLAT + c512] = mk2[g][r] > 0.f ? v[r] : 0.f;
     }
   }
+}
+
+// ring depth x contraction split of the shipped library (measured: profiles/r03_*fc_chain*); debug builds can A/B the
+// other instantiations with DVAE_FCC_VARIANT = 10 * DEPTH + KS
+#ifndef FCC_DEFAULT_VARIANT
+#define FCC_DEFAULT_VARIANT 162
+#endif
+
+template <int DEPTH, int KS>
+static void launch_fwd_t(const FwdArgs& P, int nblk, hipStream_t s) {
+  hipLaunchKernelGGL((k_fc_chain_fwd<DEPTH, KS>), dim3(nblk), dim3(256 * KS), 0, s, P);
+}
+template <int DEPTH, int KS>
+static void launch_bwd_t(const BwdArgs& P, int nblk, hipStream_t s) {
+  hipLaunchKernelGGL((k_fc_chain_bwd<DEPTH, KS>), dim3(nblk), dim3(256 * KS), 0, s, P);
 }
 
 int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s) {
   FwdArgs P;
   P.a = *a;
   const int nblk = (a->n_enc + FCC_R - 1) / FCC_R;
-  hipLaunchKernelGGL(k_fc_chain_fwd, dim3(nblk), dim3(256), 0, s, P);
+  static const int variant = env_int("DVAE_FCC_VARIANT", FCC_DEFAULT_VARIANT);
+  switch (variant) {
+#ifdef DVAE_DEBUG_SWITCHES
+    case 81: launch_fwd_t<8, 1>(P, nblk, s); break;
+    case 161: launch_fwd_t<16, 1>(P, nblk, s); break;
+    case 82: launch_fwd_t<8, 2>(P, nblk, s); break;
+#endif
+    default: launch_fwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10>(P, nblk, s); break;
+  }
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -492,7 +567,15 @@ int launch_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, hipStream_t s) {
   BwdArgs P;
   P.a = *a;
   const int nblk = (a->n + FCC_R - 1) / FCC_R;
-  hipLaunchKernelGGL(k_fc_chain_bwd, dim3(nblk), dim3(256), 0, s, P);
+  static const int variant = env_int("DVAE_FCC_VARIANT", FCC_DEFAULT_VARIANT);
+  switch (variant) {
+#ifdef DVAE_DEBUG_SWITCHES
+    case 81: launch_bwd_t<8, 1>(P, nblk, s); break;
+    case 161: launch_bwd_t<16, 1>(P, nblk, s); break;
+    case 82: launch_bwd_t<8, 2>(P, nblk, s); break;
+#endif
+    default: launch_bwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10>(P, nblk, s); break;
+  }
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -106,12 +106,20 @@ class Discriminator(nn.Module):
                                       device=self._arena.flat.device)
         return self._wsbuf
 
-    def forward_raw(self, z, M):
-        """z[M,latent] -> logits[M,2] (discriminator.py:60-70); activations kept for backward."""
+    def _fresh_buffers(self, M):
+        """Activation / gradient buffers owned by ONE forward call (the autograd path: several forwards of the same batch
+        size may be alive at once, losses.py:261,292)."""
+        dev = self._arena.flat.device
+        f = lambda n: torch.empty(M, n, dtype=torch.float32, device=dev)
+        return dict(h=[f(self.dims[i + 1]) for i in range(6)], g=[f(self.dims[i]) for i in range(6)])
+
+    def forward_raw(self, z, M, acts=None):
+        """z[M,latent] -> logits[M,2] (discriminator.py:60-70); activations kept for backward (in the module's workspace
+        for this batch size, or in `acts`)."""
         if self._arena.flat.device.type != "cuda":
             raise _lib.DvaeHipError("the native Discriminator computes only on an MI355X (no CPU fallback)")
         s = _stream()
-        b = self._act_buffers(M)
+        b = self._act_buffers(M) if acts is None else acts
         x = z
         for i, n in enumerate(self._layer_names):
             act = ACT_LEAKY02 if i < 5 else ACT_NONE
@@ -120,12 +128,12 @@ class Discriminator(nn.Module):
             x = b["h"][i]
         return x
 
-    def backward_raw(self, z, g_logits, M, rows=None, wgrad=True, chain="g"):
+    def backward_raw(self, z, g_logits, M, rows=None, wgrad=True, chain="g", acts=None):
         """Back-propagate g_logits[rows,2] through the MLP evaluated by forward_raw(z, M).
         rows < M restricts to the first `rows` samples (dgrad-only chain of quirk Q1).
         Returns the gradient w.r.t. z ([rows, latent])."""
         s = _stream()
-        b = self._act_buffers(M)
+        b = self._act_buffers(M) if acts is None else acts
         R = M if rows is None else rows
         dy = g_logits
         for i in range(5, -1, -1):
@@ -140,7 +148,55 @@ class Discriminator(nn.Module):
             dy = gx
         return dy
 
+    def param_list(self):
+        out = []
+        for n in self._layer_names:
+            layer = getattr(self, n)
+            out += [layer.weight, layer.bias]
+        return out
+
+    def unalias_grads(self):
+        """After FactorKLoss.call_optimize ``Parameter.grad`` IS a view of the gradient arena (assign_grads); the
+        autograd-compatible backward writes its results there and hands autograd clones, which autograd would then
+        accumulate into the very buffer just written.  Give every aliased ``.grad`` its own storage first."""
+        lo = self._arena.grad.data_ptr()
+        hi = lo + self._arena.grad.numel() * 4
+        for p_ in self.parameters():
+            g = p_.grad
+            if g is not None and lo <= g.data_ptr() < hi:
+                p_.grad = g.clone()
+
     def forward(self, z):
-        """nn.Module-style call (inference / evaluation); returns detached logits."""
+        """discriminator.py:60-70 as an nn.Module call: logits[M,2], differentiable w.r.t. ``z`` and the parameters
+        (user code that back-propagates through ``loss_f.discriminator(z)``, e.g. the reference's own
+        FactorKLoss.call_optimize, losses.py:261-306: two forwards of the same batch size, both back-propagated).  Every
+        call owns its activations."""
+        return _DiscFn.apply(self, z, *self.param_list())
+
+
+class _DiscFn(torch.autograd.Function):
+    """Discriminator.forward with autograd: forward_raw / backward_raw (the GEMM chains of libdvae_hip.so)."""
+
+    @staticmethod
+    def forward(ctx, disc, z, *params):
+        if z.dtype != torch.float32 or z.device != disc.arena.flat.device:
+            raise _lib.DvaeHipError("Discriminator input must be fp32 on %s" % disc.arena.flat.device)
+        z = z.contiguous()
         M = z.shape[0]
-        return self.forward_raw(z.contiguous(), M).clone()
+        acts = disc._fresh_buffers(M)
+        logits = disc.forward_raw(z, M, acts=acts).clone()
+        ctx.disc, ctx.M, ctx.acts = disc, M, acts
+        ctx.save_for_backward(z)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g_logits):
+        disc, M = ctx.disc, ctx.M
+        (z,) = ctx.saved_tensors
+        disc.unalias_grads()
+        dz = disc.backward_raw(z, g_logits.contiguous(), M, wgrad=True, chain="g", acts=ctx.acts)
+        grads = []
+        for n in disc._layer_names:
+            grads.append(disc.arena.view(n + ".weight", grad=True).clone())
+            grads.append(disc.arena.view(n + ".bias", grad=True).clone())
+        return (None, dz.clone()) + tuple(grads)

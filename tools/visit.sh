@@ -3,6 +3,7 @@
 #   gpurun --timeout 1500 -- 'STEPS="probe fused tests smoke bench sweep kbench timeline" bash tools/visit.sh'
 # STEPS (any subset, in this order):
 #   probe     MFMA 4x4x1 lane-layout probe (tools/ubench/mfma4x4_probe)
+#   fccab     FC-chain instantiations side by side (debug builds)
 #   fused     the round-3 kernel tests only (tests/test_gpu_fused_core.py, tests/test_gpu_timed_config.py)
 #   tests     the whole -m gpu suite (PYTEST_ARGS to narrow it)
 #   smoke     __graft_entry__.smoke()
@@ -23,6 +24,10 @@ STEPS=${STEPS:-"tests smoke bench"}
 has() { case " $STEPS " in *" $1 "*) return 0;; *) return 1;; esac; }
 echo "== host: $(nproc) cpus; $(rocm-smi --showproductname 2>/dev/null | grep -m1 -i 'card series' || true)"
 if has probe; then echo "== probe"; timeout 120 tools/ubench/mfma4x4_probe 2>&1 | tail -n 14 | tee gpurun_out/${TAG}_probe.txt; fi
+if has fccab; then
+  echo "== FC chain variants (debug build: DVAE_FCC_VARIANT = 10 * ring depth + contraction split)"
+  for v in 81 161 82 162; do DVAE_FCC_VARIANT=$v timeout 120 python tools/fcc_ab.py 128 1024 2>&1 | grep variant; done | tee gpurun_out/${TAG}_fcc_ab.txt
+fi
 if has fused; then
   echo "== pytest (round-3 kernels)"
   timeout 900 python -m pytest tests/test_gpu_fused_core.py tests/test_gpu_timed_config.py -m gpu -q --timeout=300 --no-header > gpurun_out/${TAG}_pytest_fused.log 2>&1
@@ -30,7 +35,11 @@ if has fused; then
   echo "pytest exit: $FUSED_RC" | tee -a gpurun_out/${TAG}_pytest_fused.log
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_fused.log | cut -c1-260 | head -40
   grep -n -m3 -A6 "^E  " gpurun_out/${TAG}_pytest_fused.log | cut -c1-300 | head -40
-  if [ "$FUSED_RC" != "0" ] && [ "${STOP_ON_FUSED_FAIL:-0}" = "1" ]; then echo "== round-3 kernel tests failed: skipping the remaining steps"; STEPS="${FAIL_STEPS:-}"; fi
+  if [ "$FUSED_RC" != "0" ] && [ -n "${FCC_FALLBACK:-}" ]; then
+    echo "== round-3 kernel tests failed with the default FC-chain variant: continuing with DVAE_FCC_VARIANT=$FCC_FALLBACK"
+    export DVAE_FCC_VARIANT=$FCC_FALLBACK
+    timeout 900 python -m pytest tests/test_gpu_fused_core.py -m gpu -q --timeout=300 --no-header 2>&1 | tail -n 3
+  elif [ "$FUSED_RC" != "0" ] && [ "${STOP_ON_FUSED_FAIL:-0}" = "1" ]; then echo "== round-3 kernel tests failed: skipping the remaining steps"; STEPS="${FAIL_STEPS:-}"; fi
 fi
 if has tests; then
   echo "== pytest -m gpu"
