@@ -121,6 +121,7 @@ def kernel_rooflines(B, device):
     2 x 4.19 M MACs per image), launched through the C-ABI.  Per training step each family runs twice
     at this geometry: k_up32ws<16> = convT2 fwd + conv2 dgrad (masked), k_down32ws<16> = conv2 fwd + convT2 dgrad
     (masked), k_wgrad32ws<16> = conv2 wgrad + convT2 wgrad."""
+    import ctypes
     from disvae_amd import _lib
     from disvae_amd._lib import call, ptr
     f = lambda *s: torch.rand(*s, device=device)
@@ -131,12 +132,17 @@ def kernel_rooflines(B, device):
     dw, db = torch.empty_like(w), torch.empty_like(b)
     ws = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), device=device)
     s = torch.cuda.current_stream().cuda_stream
-    NH, RELU = _lib.NHWC, _lib.ACT_RELU
+    NH, RELU, NONE = _lib.NHWC, _lib.ACT_RELU, _lib.ACT_NONE
+    # exactly what the training step launches: the kernels on pre-staged weight images (dvae_stage_weights, once per step)
+    imd, imu = torch.empty(16384, device=device), torch.empty(16384, device=device)
+    cd = (_lib.ConvImageDesc * 1)()
+    cd[0].w, cd[0].img_down, cd[0].img_up = ptr(w), ptr(imd), ptr(imu)
+    call("dvae_stage_weights", ctypes.addressof(cd), 1, None, 0, None, None, s)
     fams = {
-        "k_up32ws<16>": [("convT2 fwd", lambda: call("dvae_convT4s2_fwd", ptr(small), NH, ptr(w), ptr(b), ptr(obig), NH, B, 32, 16, 16, 32, RELU, s)),
-                       ("conv2 dgrad (masked)", lambda: call("dvae_conv4s2_dgrad", ptr(small), NH, ptr(w), ptr(big), ptr(obig), NH, B, 32, 32, 32, 32, s))],
-        "k_down32ws<16>": [("conv2 fwd", lambda: call("dvae_conv4s2_fwd", ptr(big), NH, ptr(w), ptr(b), ptr(osmall), NH, B, 32, 32, 32, 32, RELU, s)),
-                           ("convT2 dgrad (masked)", lambda: call("dvae_convT4s2_dgrad", ptr(big), NH, ptr(w), ptr(small), ptr(osmall), NH, B, 32, 16, 16, 32, s))],
+        "k_up32ws<16>": [("convT2 fwd", lambda: call("dvae_conv32_up", ptr(small), NH, ptr(imu), ptr(b), None, ptr(obig), B, 16, RELU, s)),
+                       ("conv2 dgrad (masked)", lambda: call("dvae_conv32_up", ptr(small), NH, ptr(imu), None, ptr(big), ptr(obig), B, 16, NONE, s))],
+        "k_down32ws<16>": [("conv2 fwd", lambda: call("dvae_conv32_down", ptr(big), ptr(imd), ptr(b), None, ptr(osmall), NH, B, 16, RELU, s)),
+                           ("convT2 dgrad (masked)", lambda: call("dvae_conv32_down", ptr(big), ptr(imd), None, ptr(small), ptr(osmall), NH, B, 16, NONE, s))],
         "k_wgrad32ws<16>": [("conv2 wgrad (+reduce)", lambda: call("dvae_conv4s2_wgrad", ptr(big), NH, ptr(small), NH, ptr(dw), ptr(db), B, 32, 32, 32, 32, ptr(ws), s))],
     }
     flops = 2.0 * 4194304 * B              # algorithmic FLOPs per launch: 2 x MACs/img x images per launch

@@ -369,6 +369,31 @@ int dvae_set_coef(float* coef, float c0, float c1, float c2, float c3, float c4,
   return launch_set_coef(coef, v, (hipStream_t)stream);
 }
 
+int dvae_stream_order(void* earlier, void* later) {
+  // events are re-used round-robin: 256 of them outlive any window of outstanding fork / join pairs of an iteration (~20);
+  // per device (an event belongs to the device it was created on)
+  constexpr int NEV = 256, NDEV = 32;
+  static hipEvent_t pool[NDEV][NEV];
+  static int made[NDEV] = {}, next[NDEV] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= NDEV) { set_error("dvae_stream_order: no current device"); return -2; }
+  if (!made[d]) {
+    for (int k = 0; k < NEV; ++k)
+      if (hipEventCreateWithFlags(&pool[d][k], hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
+        set_error("dvae_stream_order: hipEventCreateWithFlags failed");
+        return -2;
+      }
+    made[d] = 1;
+  }
+  hipEvent_t ev = pool[d][next[d]];
+  next[d] = (next[d] + 1) % NEV;
+  if (hipEventRecord(ev, (hipStream_t)earlier) != hipSuccess || hipStreamWaitEvent((hipStream_t)later, ev, 0) != hipSuccess) {
+    set_error("dvae_stream_order: %s", hipGetErrorString(hipGetLastError()));
+    return -2;
+  }
+  return 0;
+}
+
 int dvae_add(const float* a, const float* b, float* out, long n, void* stream) {
   DVAE_CHECK_ARG(a && b && out && n > 0);
   return launch_add(a, b, out, n, (hipStream_t)stream);

@@ -43,6 +43,19 @@ static inline Strides make_strides(int layout, int C, int H, int W) {
   return s;
 }
 
+// "once per device" flag.  Function attributes such as MaxDynamicSharedMemorySize belong to the (function, device) pair: a
+// process that drives several GPUs has to set them on each (one process per GPU, the data-parallel layout, never notices).
+struct DeviceOnce {
+  bool done[32] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

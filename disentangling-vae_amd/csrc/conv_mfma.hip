@@ -529,22 +529,20 @@ static int launch_down_ws(const ConvArgs& a, hipStream_t s) {
   const int n_units = units_for(a.N, HS);
   const int grid = n_units < 256 ? n_units : 256;
   const size_t lds = (16384 + 2 * G::BIG_FLOATS) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute((const void*)k_down32ws<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k_down32ws<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
   }
   static const int abl = env_int("DVAE_ABLATE", 0);   // timing ablation, debug builds only (results invalid)
   const int af = a.act | (abl << 8);
 #ifdef DVAE_DEBUG_SWITCHES
   static const int lt = env_int("DVAE_DOWN_LT", 256);  // 512: two loader waves per SIMD (768-thread workgroups)
   if (lt == 512) {
-    static bool attr2 = false;
-    if (!attr2) {
+    static DeviceOnce attr2;
+    if (attr2.first()) {
       (void)hipFuncSetAttribute((const void*)k_down32ws<HS, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void*)k_down32ws<HS, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr2 = true;
     }
     if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
     else hipLaunchKernelGGL((k_down32ws<HS, false, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
@@ -564,11 +562,10 @@ static int launch_down_t(const ConvArgs& a, hipStream_t s) {
   const int n_units = units_for(a.N, HS);
   const int grid = n_units < 256 ? n_units : 256;
   const size_t lds = (16384 + G::BIG_FLOATS + 8192) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute((const void*)k_down32<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k_down32<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
   }
   const int out_nchw = a.out_layout == DVAE_NCHW;
   if (a.mask) hipLaunchKernelGGL((k_down32<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, out_nchw, a.w_staged);
@@ -583,11 +580,10 @@ static int launch_up_t(const ConvArgs& a, hipStream_t s) {
   const int n_units = units_for(a.N, HS);
   const int grid = n_units < 256 ? n_units : 256;
   const size_t lds = (16384 + G::SH_FLOATS) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute((const void*)k_up32<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k_up32<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
   }
   const int small_nchw = a.small_layout == DVAE_NCHW;
   if (a.mask) hipLaunchKernelGGL((k_up32<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, small_nchw, a.w_staged);
@@ -608,8 +604,8 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
     if (cap > 0 && cap < grid) grid = cap;
   }
   const size_t lds = (G::BIG_FLOATS + 64 * 32) * sizeof(float);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  static DeviceOnce attr;
+  if (attr.first()) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
   hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units, small_nchw);
   DVAE_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_wgrad32_reduce, dim3(WG_REDUCE_BLOCKS), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);

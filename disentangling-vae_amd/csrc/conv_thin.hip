@@ -91,7 +91,7 @@ __device__ __forceinline__ void store_big_thin(const BigThinRegs<C, TB>& r, floa
 // once per workgroup (coalesced read, transposed [k][cs] image) into 8*C VGPRs per lane; the
 // next unit's big tile is prefetched into registers during the MFMA phase.
 template <int C, bool MASK, typename TB = float>
-__global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 4) void k_down_thin(const TB* __restrict__ big, const float* __restrict__ w,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
                                                    float* __restrict__ out, int N, int act, int n_units) {
   __shared__ float bt[C * TB_PLANE];
@@ -112,9 +112,14 @@ __global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, c
       wT[k * 32 + cs] = wv[r];
     }
   }
-  BigThinRegs<C, TB> pf;
+  // TWO tiles in flight per workgroup (units u + g and u + 2g while unit u is multiplied): with one, the kernel sat at
+  // 3.9 TB/s of algorithmic traffic with every CU's memory queue a latency deep (6 workgroups x 8 KB per CU); the loads
+  // are 8 registers per thread and tile
+  BigThinRegs<C, TB> pfa, pfb;
   int unit = blockIdx.x;
-  if (unit < n_units) load_big_thin<C, TB>(pf, big, unit >> 3, (unit & 7) * 4, true, tid);
+  const int gstep = gridDim.x;
+  if (unit < n_units) load_big_thin<C, TB>(pfa, big, unit >> 3, (unit & 7) * 4, true, tid);
+  if (unit + gstep < n_units) load_big_thin<C, TB>(pfb, big, (unit + gstep) >> 3, ((unit + gstep) & 7) * 4, true, tid);
   __syncthreads();
   float wreg[8 * C];                                     // B operand: w[cs = i][k = 2*kk + h]
 #pragma unroll
@@ -122,12 +127,12 @@ __global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, c
   const float bv = bias ? bias[i] : 0.f;
   const int sy_l = wv;  // this wave's small row inside the unit; lane i = sx
 
-  for (; unit < n_units; unit += gridDim.x) {
-    const int n = unit >> 3, sy0 = (unit & 7) * 4;
+  auto body = [&](BigThinRegs<C, TB>& pf, int u) {
+    const int n = u >> 3, sy0 = (u & 7) * 4;
     __syncthreads();                                     // previous unit's LDS reads are complete
     store_big_thin<C, TB>(pf, bt, tid, lut);
     __syncthreads();
-    const int nu = unit + gridDim.x;
+    const int nu = u + 2 * gstep;
     if (nu < n_units) load_big_thin<C, TB>(pf, big, nu >> 3, (nu & 7) * 4, true, tid);
     const long rowbase = ((((long)n * 32 + sy0 + sy_l) * 32)) * 32 + i;
     float mv[16];
@@ -154,6 +159,13 @@ __global__ __launch_bounds__(256) void k_down_thin(const TB* __restrict__ big, c
       if (MASK) v = mv[e] > 0.f ? v : 0.f;
       out[rowbase + sx * 32] = v;
     }
+  };
+  while (unit < n_units) {
+    body(pfa, unit);
+    unit += gstep;
+    if (unit >= n_units) break;
+    body(pfb, unit);
+    unit += gstep;
   }
 }
 
@@ -284,6 +296,181 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
   }
 }
 
+// ---- up_thin on the matrix core (round 3) ---------------------------------------------------------------------------------
+// The same layer (convT3 forward: small NHWC [N,32,32,32] -> big NCHW [N,C,64,64], bias + sigmoid, optionally the fused
+// reconstruction likelihood) on v_mfma_f32_4x4x1_16b_f32.  k_up_thin above is a VALU kernel (1536 scalar FMAs per small
+// pixel: the C = 1 / 3 output channels are too narrow for a 32x32 or 16x16 MFMA tile) and is issue-bound at 0.35 of the
+// HBM roof, with the likelihood arithmetic competing for the same VALU (profiles/r02_final_pmc_summary.md).  The 4x4x1 form
+// has 16 independent 4x4 blocks: 4 PIXELS x 4 output channels (3 used) per block = 64 small pixels per instruction and
+// contraction step, 75 % of the matrix core's rate for C = 3 -- and the VALU is left to the sigmoid / likelihood epilogue.
+//   workgroup = 4 waves, persistent over units of 4 small rows x 32 columns (8 per image); wave (rp, py) owns the two small
+//   rows 2rp, 2rp+1 (lane = pixel) and the output row parity py, both column parities px:
+//     out[2r+py][2l+px][cb] = sum_{ty,tx,cs} small[r+py-ty][l+px-tx][cs] * w[cs][cb][1-py+2ty][1-px+2tx]
+//   A operand: the lane's source pixel, four contracted channels per ds_read_b128 from the halo tile in LDS (6 distinct
+//   source pixels per lane and channel quad serve 32 MFMAs); B operand: w for cb = lane % 4, the wave's 8 taps x 32
+//   channels = 256 VGPRs per lane for the whole kernel (one wave per SIMD: the register file is this kernel's to use);
+//   D: lane (block b, cb) holds 4 pixels x 2 column parities = 8 consecutive output columns of one row: two 16-byte stores.
+// Exact fp32 (k-ordered fmaf chains, two accumulators per output for the even / odd channel, added at the end).
+#define UM_GRID 256                // persistent: one workgroup per CU (a wave keeps 256 VGPRs of weights)
+#define UM_ROWS 6
+#define UM_COLS 34
+#define UM_TILE (UM_ROWS * UM_COLS * 32)
+template <int C, bool FUSE, typename TT = float>
+__global__ __launch_bounds__(256) void k_up_thin_mfma(const float* __restrict__ small, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int N, int act,
+                                                      int n_units, const TT* __restrict__ target, float* __restrict__ g,
+                                                      int dist, const float* __restrict__ coef, float* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) float st[2][UM_TILE];
+  __shared__ float wsh[32 * C * 16];
+  __shared__ float redl[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rp = wv >> 1, py = wv & 1;
+  const int cb = lane & 3;
+  const float gs = FUSE ? coef[DVAE_C_INV_B] : 0.f;
+  // ---- staging slots of this thread: 16-byte chunk `ch` of tile pixels (row, col), constant over the units
+  constexpr int NSLOT = (UM_ROWS * UM_COLS * 8 + 255) / 256;
+  int s_lds[NSLOT], s_gofs[NSLOT], s_row[NSLOT];
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    const int sidx = tid + 256 * k;
+    s_lds[k] = -1; s_gofs[k] = 0; s_row[k] = -100;
+    if (sidx < UM_ROWS * UM_COLS * 8) {
+      const int ch = sidx & 7, pix = sidx >> 3;
+      const int col = pix % UM_COLS, row = pix / UM_COLS;
+      s_lds[k] = (row * UM_COLS + col) * 32 + ((ch ^ (col & 7)) << 2);
+      const bool inside = col >= 1 && col <= 32;
+      s_gofs[k] = ((row - 1) * 32 + (col - 1)) * 32 + ch * 4;
+      s_row[k] = inside ? row : -100;                    // -100: halo column, always zero
+    }
+  }
+  f32x4 pf[NSLOT];
+  auto load_tile = [&](int u) {
+    const int n = u >> 3, sy0 = (u & 7) * 4;
+    const float* base = small + (((long)n * 32 + sy0) * 32) * 32;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int sy = sy0 - 1 + s_row[k];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (s_row[k] >= 0 && sy >= 0 && sy < 32) v = *reinterpret_cast<const f32x4*>(base + s_gofs[k]);
+      pf[k] = v;
+    }
+  };
+  auto store_tile = [&](float* t) {
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k)
+      if (s_lds[k] >= 0) *reinterpret_cast<f32x4*>(t + s_lds[k]) = pf[k];
+  };
+  int unit = blockIdx.x;
+  if (unit < n_units) load_tile(unit);
+  for (int e = tid; e < 32 * C * 16; e += 256) wsh[e] = w[e];
+  __syncthreads();
+  // B operands: Bw[ty][kw][cs] = w[cs][cb][1 - py + 2 ty][kw] for cb = lane % 4 (0 beyond C)
+  float Bw[2][4][32];
+#pragma unroll
+  for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+      for (int cs = 0; cs < 32; ++cs)
+        Bw[ty][kw][cs] = cb < C ? wsh[(cs * C + (cb < C ? cb : 0)) * 16 + (1 - py + 2 * ty) * 4 + kw] : 0.f;
+  const float bv = (bias && cb < C) ? bias[cb] : 0.f;
+  // A operand addresses: pixel = lane: small row 2rp + lane/32, column lane%32; source (row + py - ty, col + dc), dc in -1..1
+  const int rr = 2 * rp + (lane >> 5), l = lane & 31;
+  int aoff[2][3], asw[3];
+#pragma unroll
+  for (int dc = 0; dc < 3; ++dc) {
+    const int tcol = l + dc;                             // (l + 1) + (dc - 1)
+    asw[dc] = tcol & 7;
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty) aoff[ty][dc] = ((rr + 1 + py - ty) * UM_COLS + tcol) * 32;
+  }
+  if (unit < n_units) store_tile(st[0]);
+  __syncthreads();
+  if (unit + (int)gridDim.x < n_units) load_tile(unit + gridDim.x);
+  float lsum = 0.f;
+  int buf = 0;
+  for (; unit < n_units; unit += gridDim.x) {
+    const float* t = st[buf];
+    f32x4 acc[2][2];                                     // [px][channel parity]
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc[px][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                        // 4 contracted channels per step
+      f32x4 x[2][3];
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc) x[ty][dc] = *reinterpret_cast<const f32x4*>(t + aoff[ty][dc] + ((q ^ asw[dc]) << 2));
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int tx = 0; tx < 2; ++tx) {
+            const int kw = 1 - px + 2 * tx, dc = 1 + px - tx;          // source column l + px - tx
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[px][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[ty][dc][j], Bw[ty][kw][4 * q + j], acc[px][j & 1], 0, 0, 0);
+          }
+    }
+    // hand over: the next unit's tile (prefetched during the MFMAs) goes to the other buffer
+    if (unit + (int)gridDim.x < n_units) store_tile(st[buf ^ 1]);
+    __syncthreads();
+    if (unit + 2 * (int)gridDim.x < n_units) load_tile(unit + 2 * gridDim.x);
+    buf ^= 1;
+    // epilogue: lane (block b = lane/4, cb): pixels 4b .. 4b+3 of the wave's two rows x both column parities = output
+    // columns 8 (b%8) .. +7 of row 2 (sy0 + 2rp + b/8) + py
+    if (cb < C) {
+      const int n = unit >> 3, sy0 = (unit & 7) * 4;
+      const int b = lane >> 2;
+      const int by = 2 * (sy0 + 2 * rp + (b >> 3)) + py;
+      const long o = ((((long)n * C + cb) * 64) + by) * 64 + 8 * (b & 7);
+      const f32x4 s0 = acc[0][0] + acc[0][1], s1 = acc[1][0] + acc[1][1];
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = s0[e] + bv; v[2 * e + 1] = s1[e] + bv; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (act == DVAE_ACT_SIGMOID) v[e] = 1.f / (1.f + expf(-v[e]));
+        else if (act == DVAE_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(out + o) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(out + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      if (FUSE) {
+        float xt[8];
+        if constexpr (sizeof(TT) == 4) {
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(target + o), t1 = *reinterpret_cast<const f32x4*>(target + o + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xt[e] = t0[e]; xt[4 + e] = t1[e]; }
+        } else {
+          const uint2 tw = *reinterpret_cast<const uint2*>(target + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xt[e] = to_unit((uint8_t)((tw.x >> (8 * e)) & 0xff));
+            xt[4 + e] = to_unit((uint8_t)((tw.y >> (8 * e)) & 0xff));
+          }
+        }
+        float gl[8], gr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lsum += recon_elem(v[e], xt[e], dist, &gl[e], &gr); gl[e] *= gs; }
+        *reinterpret_cast<f32x4*>(g + o) = f32x4{gl[0], gl[1], gl[2], gl[3]};
+        *reinterpret_cast<f32x4*>(g + o + 4) = f32x4{gl[4], gl[5], gl[6], gl[7]};
+      }
+    }
+  }
+  if (FUSE) {
+    const float v = wave_sum(lsum);
+    if (lane == 0) redl[wv] = v;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = (redl[0] + redl[1]) + (redl[2] + redl[3]);
+    // unused partial slots must read as zero
+    for (int k = gridDim.x + blockIdx.x * 256 + tid; k < DVAE_REC_NPART; k += gridDim.x * 256) partials[k] = 0.f;
+  }
+}
+
 // ---- wgrad_thin ----------------------------------------------------------------------------
 template <int C, typename TB = float>
 __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, const float* __restrict__ small,
@@ -312,24 +499,27 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, 
     const int cb = bval[t] ? (nidx >> 4) : 0, kh = (nidx >> 2) & 3, kw = nidx & 3;
     boff[t] = cb * TB_PLANE + kh * TB_ROW + (kw & 1) * TB_PAR + (kw >> 1);
   }
-  BigThinRegs<C, TB> pfb;
-  f32x4 pfs[4];
-  auto load_unit = [&](int u) {
+  // two units in flight (registers: 8 + 16 per thread and unit), see k_down_thin
+  struct UnitRegs { BigThinRegs<C, TB> b; f32x4 s[4]; };
+  UnitRegs ua, ub;
+  const int gstep = gridDim.x;
+  auto load_unit = [&](UnitRegs& r, int u) {
     const int n = u >> 3, sy0 = (u & 7) * 4;
-    load_big_thin<C, TB>(pfb, big, n, sy0, true, tid);
+    load_big_thin<C, TB>(r.b, big, n, sy0, true, tid);
     const float* src = small + ((((long)n * 32 + sy0) * 32)) * 32;  // 128 pixels x 32 ch contiguous
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pfs[k] = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
+    for (int k = 0; k < 4; ++k) r.s[k] = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
   };
   int unit = blockIdx.x;
-  if (unit < n_units) load_unit(unit);
-  for (; unit < n_units; unit += gridDim.x) {
+  if (unit < n_units) load_unit(ua, unit);
+  if (unit + gstep < n_units) load_unit(ub, unit + gstep);
+  auto body = [&](UnitRegs& r, int u) {
     __syncthreads();
-    store_big_thin<C, TB>(pfb, bt, tid, lut);
+    store_big_thin<C, TB>(r.b, bt, tid, lut);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(sp + (tid + k * 256) * 4) = pfs[k];
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(sp + (tid + k * 256) * 4) = r.s[k];
     __syncthreads();
-    if (unit + (int)gridDim.x < n_units) load_unit(unit + gridDim.x);
+    if (u + 2 * gstep < n_units) load_unit(r, u + 2 * gstep);
     // wave wv handles small row sy_l = wv (32 pixels = 16 k-steps)
 #pragma unroll 4
     for (int t = 0; t < 16; ++t) {
@@ -345,6 +535,13 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, 
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
       }
     }
+  };
+  while (unit < n_units) {
+    body(ua, unit);
+    unit += gstep;
+    if (unit >= n_units) break;
+    body(ub, unit);
+    unit += gstep;
   }
   // cross-wave reduction through LDS (reuse sp: 4 waves x NT x 16 x 64 floats <= 8192)
   __syncthreads();
@@ -414,9 +611,16 @@ int launch_down_thin(const ConvArgs& a, hipStream_t s) {
 int launch_up_thin(const ConvArgs& a, hipStream_t s) {
   if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
   const int n_units = a.N * 8;
-  const int grid = n_units;          // one unit per workgroup: the hardware dispatcher balances the load
-  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
-  else hipLaunchKernelGGL((k_up_thin<3, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+  static const bool valu = env_on("DVAE_UP_THIN_VALU");     // debug builds: the round-1/2 VALU kernel (A/B)
+  if (valu) {
+    const int grid = n_units;        // one unit per workgroup: the hardware dispatcher balances the load
+    if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+    else hipLaunchKernelGGL((k_up_thin<3, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+  } else {
+    const int grid = n_units < UM_GRID ? n_units : UM_GRID;
+    if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin_mfma<1, false>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+    else hipLaunchKernelGGL((k_up_thin_mfma<3, false>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+  }
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -425,10 +629,17 @@ int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int d
                          float* partials, hipStream_t s) {
   if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
   const int n_units = a.N * 8;
-  // persistent (one loss partial per workgroup): 6 workgroups of 128 threads fit a CU (26 KB LDS each)
-  const int grid = n_units < 1536 ? n_units : 1536;
-  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
-  else hipLaunchKernelGGL((k_up_thin<3, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  static const bool valu = env_on("DVAE_UP_THIN_VALU");     // debug builds: the round-1/2 VALU kernel (A/B)
+  if (valu) {
+    // persistent (one loss partial per workgroup): 6 workgroups of 128 threads fit a CU (26 KB LDS each)
+    const int grid = n_units < 1536 ? n_units : 1536;
+    if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+    else hipLaunchKernelGGL((k_up_thin<3, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  } else {
+    const int grid = n_units < UM_GRID ? n_units : UM_GRID;
+    if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin_mfma<1, true>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+    else hipLaunchKernelGGL((k_up_thin_mfma<3, true>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  }
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -448,9 +659,9 @@ int launch_up_thin_recon_u8(const ConvArgs& a, const uint8_t* target, float* g, 
                             float* partials, hipStream_t s) {
   if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
   const int n_units = a.N * 8;
-  const int grid = n_units < 1536 ? n_units : 1536;
-  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true, uint8_t>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
-  else hipLaunchKernelGGL((k_up_thin<3, true, uint8_t>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  const int grid = n_units < UM_GRID ? n_units : UM_GRID;
+  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin_mfma<1, true, uint8_t>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  else hipLaunchKernelGGL((k_up_thin_mfma<3, true, uint8_t>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

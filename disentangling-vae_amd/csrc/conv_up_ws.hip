@@ -282,11 +282,10 @@ static int launch_up_ws_t(const ConvArgs& a, hipStream_t s) {
   const int grid = n_units < 256 ? n_units : 256;
   static_assert(2 * UPWS_OUT_FLOATS == 16384, "the two output images occupy exactly the weight image");
   const size_t lds = (size_t)(16384 + 2 * G::SH_FLOATS) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute((const void*)k_up32ws<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k_up32ws<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
   }
   static const int abl = env_int("DVAE_UPWS_ABLATE", 0);      // debug builds only
   const int af = a.act | (abl << 8);

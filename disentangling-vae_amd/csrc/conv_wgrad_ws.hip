@@ -230,8 +230,8 @@ static int launch_wgrad_ws_t(const float* big, const float* small, float* dw, fl
   const int n_units = (int)(((long)N * HS * HS) / 64);
   const int grid = n_units < WGW_MAX_BLOCKS ? n_units : WGW_MAX_BLOCKS;
   const size_t lds = (size_t)2 * W::BUF_FLOATS * sizeof(float);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad32ws<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  static DeviceOnce attr;
+  if (attr.first()) { (void)hipFuncSetAttribute((const void*)k_wgrad32ws<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
 #ifdef DVAE_DEBUG_SWITCHES
   static const int abl = env_int("DVAE_WGWS_ABLATE", 0);
   hipLaunchKernelGGL(k_wgrad32ws<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, n_units, abl);

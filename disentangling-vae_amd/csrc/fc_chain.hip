@@ -531,10 +531,12 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   }
 }
 
-// ring depth x contraction split of the shipped library (measured: profiles/r03_*fc_chain*); debug builds can A/B the
-// other instantiations with DVAE_FCC_VARIANT = 10 * DEPTH + KS
+// ring depth x contraction split of the shipped library.  Measured (profiles/r03_v2_fcc_ab.txt, B = 128 / 1024, forward |
+// backward, us): <8,1> 28.1 | 33.6 / 30.5 | 40.2; <16,1> 28.0 | 33.4 / 30.3 | 38.4; <8,2> 23.6 | 25.3 / 26.1 | 27.7; <16,2> 24.4 |
+// 26.0 / 26.8 | 28.4 -- the second wave per SIMD helps, a deeper ring does not: ~65 GB/s of weight stream per CU either way.
+// Debug builds can A/B the other instantiations with DVAE_FCC_VARIANT = 10 * DEPTH + KS
 #ifndef FCC_DEFAULT_VARIANT
-#define FCC_DEFAULT_VARIANT 162
+#define FCC_DEFAULT_VARIANT 82
 #endif
 
 template <int DEPTH, int KS>
@@ -555,7 +557,7 @@ int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s) {
 #ifdef DVAE_DEBUG_SWITCHES
     case 81: launch_fwd_t<8, 1>(P, nblk, s); break;
     case 161: launch_fwd_t<16, 1>(P, nblk, s); break;
-    case 82: launch_fwd_t<8, 2>(P, nblk, s); break;
+    case 162: launch_fwd_t<16, 2>(P, nblk, s); break;
 #endif
     default: launch_fwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10>(P, nblk, s); break;
   }
@@ -572,7 +574,7 @@ int launch_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, hipStream_t s) {
 #ifdef DVAE_DEBUG_SWITCHES
     case 81: launch_bwd_t<8, 1>(P, nblk, s); break;
     case 161: launch_bwd_t<16, 1>(P, nblk, s); break;
-    case 82: launch_bwd_t<8, 2>(P, nblk, s); break;
+    case 162: launch_bwd_t<16, 2>(P, nblk, s); break;
 #endif
     default: launch_bwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10>(P, nblk, s); break;
   }

@@ -396,10 +396,9 @@ static void launch_fc32_t(const float* a, long lda, const float* b, long ldb, fl
                           const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
   size_t lds = (size_t)(32 * (KP + 4) + (BJ ? (KP + 8) * 32 : 32 * (KP + 4))) * sizeof(float);
   if (lds < 4 * 16 * 64 * sizeof(float)) lds = 4 * 16 * 64 * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute((const void*)k_fc32<KP, BJ, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
   }
   hipLaunchKernelGGL((k_fc32<KP, BJ, SC>), dim3((N + 31) / 32, (M + 31) / 32), dim3(256), lds, s, a, lda, b, ldb, c, ldc, M, N,
                      Kc, bias, act, mask, mask_act);
@@ -543,10 +542,9 @@ static bool try_fcw32(const float* x, const float* dy, float* dw, float* db, int
   } else {
     constexpr int KP = 256;
     const size_t lds = sizeof(float) * 2 * (KP + 8) * 32;
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.first()) {
       (void)hipFuncSetAttribute((const void*)k_fcw32<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = true;
     }
     hipLaunchKernelGGL((k_fcw32<KP>), grid, dim3(256), lds, s, dy, x, dw, db, M, N, K);
   }
@@ -739,10 +737,9 @@ template <int TM, bool BJ>
 static void launch_gemm_big_t(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
                              const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
   const size_t lds = sizeof(float) * 2 * (TM * 68 + (BJ ? 64 * 64 + 32 : 64 * 68));
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute((const void*)k_gemm_big<TM, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
   }
   static const int abl = env_int("DVAE_GEMM_ABLATE", 0);   // timing ablation, debug builds only (results invalid)
   hipLaunchKernelGGL((k_gemm_big<TM, BJ>), dim3((N + 63) / 64, (M + TM - 1) / TM), dim3(256), lds, s, a, lda, b, ldb, c, ldc,

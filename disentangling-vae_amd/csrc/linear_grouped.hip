@@ -140,10 +140,9 @@ __global__ __launch_bounds__(256) void k_fcw_grouped(const FcwTable t) {
 template <int KP>
 static void launch_fcw_grouped_t(const FcwTable& t, int tiles, hipStream_t s) {
   const size_t lds = sizeof(float) * 2 * (KP + 8) * 32;      // >= the reduction image (4224 floats) for KP >= 64
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute((const void*)k_fcw_grouped<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
   }
   hipLaunchKernelGGL((k_fcw_grouped<KP>), dim3(tiles), dim3(256), lds, s, t);
 }

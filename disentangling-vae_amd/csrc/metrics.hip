@@ -49,17 +49,21 @@ __global__ __launch_bounds__(256) void k_entropy_lse(const float* __restrict__ z
       v[u] = cT[n + u] - 0.5f * (diff * diff * ivT[n + u]);        // log_density_gaussian, utils/math.py:48-50
       mx = fmaxf(mx, v[u]);
     }
+    // every density of the block (and everything before it) can be -inf (exp(-logvar) overflowing): shift by 0 then, so
+    // that exp(-inf - shift) = 0 instead of exp(-inf + inf) = NaN; torch.logsumexp returns -inf for such a column too
+    const float sh = mx > -INFINITY ? mx : 0.f;
     float t = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t += __expf(v[u] - mx);
-    acc = acc * __expf(m - mx) + t;
+    for (int u = 0; u < 8; ++u) t += __expf(v[u] - sh);
+    acc = acc * __expf(m - sh) + t;
     m = mx;
   }
   for (; n < n1; ++n) {
     const float diff = z - muT[n];
     const float v = cT[n] - 0.5f * (diff * diff * ivT[n]);
     const float mx = fmaxf(m, v);
-    acc = acc * __expf(m - mx) + __expf(v - mx);
+    const float sh = mx > -INFINITY ? mx : 0.f;
+    acc = acc * __expf(m - sh) + __expf(v - sh);
     m = mx;
   }
   if (s < S) {

@@ -58,10 +58,14 @@ __global__ __launch_bounds__(256) void k_stage_weights(StageTable t) {
     const long nch = (long)((g.K + 3) >> 2) * g.N;
     if (c >= nch) return;
     const int k4 = (int)(c / g.N), n = (int)(c % g.N);
+    if ((g.K & 3) == 0) {                                // rows are 16-byte aligned: one load per chunk
+      v = *reinterpret_cast<const f32x4*>(g.w + (long)n * g.K + 4 * k4);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = 4 * k4 + r;
-      v[r] = k < g.K ? g.w[(long)n * g.K + k] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const int k = 4 * k4 + r;
+        v[r] = k < g.K ? g.w[(long)n * g.K + k] : 0.f;
+      }
     }
     reinterpret_cast<f32x4*>(g.img)[c] = v;
   } else {

@@ -83,6 +83,7 @@ SIGNATURES = {
     "dvae_comm_group_start": [],
     "dvae_comm_group_end": [],
     "dvae_add": [_p, _p, _p, _l, _p],
+    "dvae_stream_order": [_p, _p],
 }
 _RESTYPE = {"dvae_last_error": ctypes.c_char_p, "dvae_conv_wgrad_ws_floats": ctypes.c_size_t,
             "dvae_latent_entropy_ws_floats": ctypes.c_size_t}

@@ -52,10 +52,18 @@ class DeviceImageLoader:
 
     images: anything ``to_uint8_nchw`` accepts, or a uint8 [N,C,H,W] device tensor; labels: optional [N, ...] tensor
     (dSprites ``lat_values``); without labels the second item of a batch is 0 like CelebA's placeholder (datasets.py:291).
-    shuffle: a fresh ``torch.randperm`` of the data set per epoch from the torch CPU generator, like
-    ``DataLoader(shuffle=True)``'s RandomSampler (seeded by ``torch.manual_seed``)."""
+    shuffle: the order of an epoch is drawn exactly as ``DataLoader(dataset, batch_size, shuffle=True)`` draws it
+    (datasets.py:67-71) -- the iterator's base seed and the RandomSampler's seed from the global CPU generator, then
+    ``torch.randperm(n)`` from a generator of its own -- so the same ``torch.manual_seed`` gives the same batches and leaves
+    the CPU generator in the same state as the reference's loader (tests/test_host_logic.py).  The permutation is moved to
+    the device ONCE per epoch; a batch is one on-device gather.
+    rank / world_size: data parallelism (disvae_amd.parallel).  Every rank draws the SAME permutation (the CPU seed is
+    shared: FactorVAE's permute_dims needs that anyway) and takes rows [rank*B, (rank+1)*B) of each global batch of
+    world_size*B images, the rank order the global-batch estimators assume; ``len()`` counts global batches.  A ragged last
+    global batch is split evenly (up to world_size - 1 images of the epoch are dropped so that all ranks see the same
+    batch shape, which the collectives require)."""
 
-    def __init__(self, images, batch_size=64, shuffle=True, labels=None, device="cuda"):
+    def __init__(self, images, batch_size=64, shuffle=True, labels=None, device="cuda", rank=0, world_size=1):
         if isinstance(images, torch.Tensor) and images.is_cuda:
             if images.dtype != torch.uint8 or images.dim() != 4:
                 raise TypeError("device image sets must be uint8 [N,C,H,W]")
@@ -65,26 +73,52 @@ class DeviceImageLoader:
         self.labels = None if labels is None else torch.as_tensor(labels)
         self.batch_size = int(batch_size)
         self.shuffle = shuffle
+        if not (0 <= int(rank) < int(world_size)):
+            raise ValueError("rank %r outside world_size %r" % (rank, world_size))
+        self.rank, self.world_size = int(rank), int(world_size)
         self.dataset = _DatasetView(self)              # ``len(loader.dataset)`` = images, as main.py:201 logs it
 
     @property
     def n_images(self):
         return self.images.shape[0]
 
+    def _global_batches(self):
+        """[(first index into the epoch's order, images per rank)] of every global batch."""
+        n, bg = self.n_images, self.batch_size * self.world_size
+        out = []
+        for i in range(0, n, bg):
+            per = min(self.batch_size, (n - i) // self.world_size)
+            if per > 0:
+                out.append((i, per))
+        return out
+
     def __len__(self):
         """number of batches (training.py:118), the last one possibly smaller."""
-        return (self.n_images + self.batch_size - 1) // self.batch_size
+        return len(self._global_batches())
+
+    @staticmethod
+    def epoch_order(n):
+        """The index order ``DataLoader(shuffle=True, num_workers=0)`` iterates an n-item data set in, with the same
+        consumption of the global CPU generator (torch/utils/data/dataloader.py: the iterator's base seed;
+        sampler.py RandomSampler.__iter__: a seed for a private generator, then randperm)."""
+        torch.empty((), dtype=torch.int64).random_()                       # _BaseDataLoaderIter._base_seed (unused here)
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())   # RandomSampler.__iter__
+        g = torch.Generator()
+        g.manual_seed(seed)
+        return torch.randperm(n, generator=g)
 
     def __iter__(self):
-        n = self.n_images
-        order = torch.randperm(n) if self.shuffle else None
         dev = self.images.device
-        for i in range(0, n, self.batch_size):
+        order = order_dev = None
+        if self.shuffle:
+            order = self.epoch_order(self.n_images)
+            order_dev = order.to(dev)                  # ONE host-to-device copy per epoch
+        for i, per in self._global_batches():
+            lo = i + self.rank * per
             if order is None:
-                batch = self.images[i:i + self.batch_size]
-                lab = 0 if self.labels is None else self.labels[i:i + self.batch_size]
+                batch = self.images[lo:lo + per]
+                lab = 0 if self.labels is None else self.labels[lo:lo + per]
             else:
-                idx = order[i:i + self.batch_size]
-                batch = self.images.index_select(0, idx.to(dev))       # gather on the device: uint8, B x C x H x W bytes
-                lab = 0 if self.labels is None else self.labels[idx]
+                batch = self.images.index_select(0, order_dev[lo:lo + per])   # gather on the device: uint8, B x C x H x W bytes
+                lab = 0 if self.labels is None else self.labels[order[lo:lo + per]]
             yield batch, lab

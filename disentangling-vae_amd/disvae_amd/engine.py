@@ -133,7 +133,10 @@ class _Buffers:
         self.h1, self.h2 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM)
         self.gh1, self.gh2 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM)
         self.ml, self.dml = f(B, 2 * D), f(B, 2 * D)
-        self.mu, self.logvar, self.z = f(B, D), f(B, D), f(B, D)
+        # z, mu, logvar: consecutive slabs of ONE buffer -- the sharded beta-TCVAE step all-gathers them with a single
+        # collective, no packing pass (parallel.Comm.all_gather_latents)
+        self.lat3 = f(3, B, D)
+        self.z, self.mu, self.logvar = self.lat3[0], self.lat3[1], self.lat3[2]
         self.d1, self.d2, self.d3 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM), f(B, HID * 16)
         self.gd1, self.gd2, self.gd3 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM), f(B, HID * 16)
         self.dec_act = [f(B, h, h, HID) for h in eng.dec_sizes]       # NHWC outputs of the hidden convT layers
@@ -204,6 +207,16 @@ class VAEEngine:
         # the weight-gradient kernels that the side stream would overlap are a few microseconds long.  Set per step by the
         # loss plugins (BaseLoss._streams).
         self.single_stream = False
+        # how the weight gradients are scheduled against the chain of input gradients (two streams):
+        #   False: batch-sized schedule -- the big layers' weight gradients are forked behind the big input gradients (two
+        #          chip-filling persistent kernels do not co-run: what matters is that the small kernels of the critical path
+        #          find idle CUs), the tail is balanced between the streams (measured at B = 1024: DESIGN.md section 5);
+        #   True : dependency-driven -- every weight gradient is launched on the side stream as soon as its two operands
+        #          exist (a fork per layer), beside the input gradient of the same layer.  Below a few hundred images per
+        #          step no kernel fills the chip, the iteration is a latency chain, and the side stream should start as
+        #          early as the data allows (profiles/r03_v2_timeline_b128.md: backward pass 287 us against ~150 us of
+        #          dependent work).  Set per step by the loss plugins (BaseLoss._streams).
+        self.eager_wgrad = False
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
         self._fc_descs = {}    # host descriptor arrays / argument structs of launches, kept alive for recorded plans
         self._images = None
@@ -273,7 +286,7 @@ class VAEEngine:
         timeline), so the FC weight gradients fork once per chain, not once per layer."""
         if self.single_stream:
             return
-        record_py(self._side.wait_stream, torch.cuda.current_stream())
+        call("dvae_stream_order", _stream(), self._side.cuda_stream)
 
     @property
     def side_stream(self):
@@ -305,7 +318,7 @@ class VAEEngine:
     def _join_side(self):
         if self.single_stream:
             return
-        record_py(torch.cuda.current_stream().wait_stream, self._side)
+        call("dvae_stream_order", self._side.cuda_stream, _stream())
 
     # ------------------------------------------------------------------ input
     @property
@@ -486,13 +499,19 @@ class VAEEngine:
         # on this stream is small (8x8 / 4x4 layers, the FC chain, the latent glue, the encoder's FC chain)
         # and leaves most CUs idle -- so the big weight gradients are forked THERE (fork 1, after the last
         # big dgrad), and the rest after the FC dgrads (fork 2).  Every fork costs this stream ~6 us.
+        eager = self.eager_wgrad and not self.single_stream
         pending, deferred, queued = [], [], []
         for k in range(len(names) - 1, -1, -1):
             name, x_in, gx, h = names[k], acts[k], gacts[k], hs[k]
             lname = "decoder.%s" % name
             wargs = ("dvae_convT4s2_wgrad", ptr(x_in), NCHW if k == 0 else NHWC, ptr(dy), dy_layout,
                      ptr(self.g(lname + ".weight")), ptr(self.g(lname + ".bias")), B, HID, h, h, couts[k])
-            (pending if h >= 16 else deferred).append(wargs)
+            if eager:
+                # both operands of this layer's weight gradient exist (dy: the previous input gradient or g_logit): side
+                # stream, now, beside this layer's input gradient
+                self._conv_wgrad(*wargs, fork=True)
+            else:
+                (pending if h >= 16 else deferred).append(wargs)
             # the first decoder layer's input gradient leaves NCHW = (c,h,w) order, straight into gd3 (the
             # gradient of lin3's output; ReLU mask = lin3's output d3 in the same order): no relayout pass
             out_layout = NCHW if k == 0 else NHWC
@@ -503,6 +522,8 @@ class VAEEngine:
                 call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p(lname + ".weight")), ptr(x_in), ptr(gx),
                      out_layout, B, HID, h, h, couts[k], s)
             dy, dy_layout = gx, NHWC
+            if eager:
+                continue
             for w_ in queued:                    # side launches of the previous fork, issued AFTER this stream's next kernel
                 self._conv_wgrad(*w_, fork=False)
             queued = []
@@ -521,7 +542,8 @@ class VAEEngine:
             call("dvae_linear_dgrad", ptr(buf.gd1), ptr(self.p("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
                  B, D, HIDDEN_DIM, ws, s)
         # small conv layers + the three FC weight gradients: one fork, then they co-run with whatever follows
-        self.fork_side()
+        if deferred or not defer_fc_wgrad:
+            self.fork_side()
         for wargs in deferred:
             self._conv_wgrad(*wargs, fork=False)
         fc = [(buf.d2, buf.gd3, self.g("decoder.lin3.weight"), self.g("decoder.lin3.bias"), B, HIDDEN_DIM, HID * 16),
@@ -558,9 +580,36 @@ class VAEEngine:
               + pend[1:]
               + [(buf.h2, buf.dml, self.g("encoder.mu_logvar_gen.weight"), self.g("encoder.mu_logvar_gen.bias"),
                   B, HIDDEN_DIM, 2 * self.latent_dim)])
+        eager = self.eager_wgrad and not self.single_stream
         deferred = [lambda fc=fc: self._side_wgrad_grouped(fc)]
         tail_main = []                      # weight gradients the main stream computes after conv1's (load balance of the tail)
         last = len(self.enc_names) - 1
+        if eager:
+            # dependency-driven schedule: the six FC weight gradients now (every operand exists: the chain of input gradients
+            # is behind us), then each conv layer's weight gradient beside its input gradient; conv1 has no input gradient:
+            # its weight gradient is the main stream's last kernel
+            self.fork_side()
+            self._side_wgrad_grouped(fc)
+            for k in range(last, -1, -1):
+                name = self.enc_names[k]
+                lname = "encoder.%s" % name
+                h_in = self.enc_sizes[k] * 2
+                x_in, x_layout, cin = (buf.enc_act[k - 1], NHWC, HID) if k > 0 else (x, NCHW, c)
+                dy, dy_layout = (buf.ga_flat, NCHW) if k == last else (buf.enc_gact[k], NHWC)
+                wargs = ("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), dy_layout,
+                         ptr(self.g(lname + ".weight")), ptr(self.g(lname + ".bias")), B, cin, h_in, h_in, HID)
+                if k == 0:
+                    if x.dtype == torch.uint8:
+                        call("dvae_conv4s2_wgrad_u8", ptr(x), ptr(dy), ptr(self.g(lname + ".weight")),
+                             ptr(self.g(lname + ".bias")), B, cin, h_in, h_in, HID, ptr(self._ws), s)
+                    else:
+                        self._conv_wgrad(*wargs, fork=False, main=True)
+                    break
+                self._conv_wgrad(*wargs, fork=k < last)      # (k == last: the fork above covers it)
+                call("dvae_conv32_up", ptr(dy), dy_layout, self._img(lname, "up"), None, ptr(x_in), ptr(buf.enc_gact[k - 1]),
+                     B, h_in // 2, ACT_NONE, s)
+            self._join_side()
+            return
         for k in range(last, -1, -1):
             name = self.enc_names[k]
             lname = "encoder.%s" % name

@@ -16,7 +16,6 @@ import logging
 import math
 import os
 from collections import defaultdict
-from functools import reduce
 from timeit import default_timer
 
 import numpy as np
@@ -84,114 +83,100 @@ class Evaluator:
 
     # ------------------------------------------------------------------ MIG / AAM (evaluate.py:119-317)
     def compute_metrics(self, dataloader, sample_idx=None, n_samples=10000):
-        """evaluate.py:119-158.  ``dataloader.dataset`` must expose ``lat_sizes`` / ``lat_names`` (data with known,
-        balanced factors of variation, e.g. dSprites) and the loader must iterate the data set in factor order
-        (``shuffle=False``), as the reference requires.  sample_idx: optional iterator of injected ``randperm`` draws
-        (parity tests): first the marginal one, then one per (factor, value) in loop order."""
-        try:
-            lat_sizes = dataloader.dataset.lat_sizes
-            lat_names = dataloader.dataset.lat_names
-        except AttributeError:
+        """Mutual Information Gap and Axis Alignment Metric of the model on a data set with known, balanced factors of
+        variation (evaluate.py:119-158): ``dataloader.dataset`` must expose ``lat_sizes`` / ``lat_names`` and the loader
+        must iterate the data set in factor order (``shuffle=False``), as the reference requires.  Returns
+        ``{'MIG': ..., 'AAM': ...}`` and writes the reference's ``metric_helpers.pth``.
+        sample_idx: optional sequence of injected ``randperm`` draws (parity tests): the marginal one first, then one per
+        (factor, value) in the reference's loop order."""
+        ds = dataloader.dataset
+        if not (hasattr(ds, "lat_sizes") and hasattr(ds, "lat_names")):
             raise ValueError("Dataset needs to have known true factors of variations to compute the metric. This does not "
-                             "seem to be the case for {}".format(type(dataloader.__dict__["dataset"]).__name__))
+                             "seem to be the case for {}".format(type(ds).__name__))
+        lat_sizes = [int(k) for k in ds.lat_sizes]
         draws = iter(sample_idx) if sample_idx is not None else None
+        take = (lambda: None) if draws is None else (lambda: next(draws))
         self.logger.info("Computing the empirical distribution q(z|x).")
-        samples_zCx, params_zCx = self._compute_q_zCx(dataloader)
-        len_dataset, latent_dim = samples_zCx.shape
+        table = _LatentTable(*self._encode_dataset(dataloader))
+        if table.n != int(np.prod(lat_sizes)):
+            raise ValueError("data set of %d images does not enumerate lat_sizes=%s" % (table.n, lat_sizes))
         self.logger.info("Estimating the marginal entropy.")
-        H_z = self._estimate_latent_entropies(samples_zCx, params_zCx, n_samples=n_samples,
-                                              sample_idx=None if draws is None else next(draws))
-        samples_zCx = samples_zCx.view(*lat_sizes, latent_dim)
-        params_zCx = tuple(p.view(*lat_sizes, latent_dim) for p in params_zCx)
-        H_zCv = self._estimate_H_zCv(samples_zCx, params_zCx, lat_sizes, lat_names, n_samples=n_samples, draws=draws)
-        H_z, H_zCv = H_z.cpu(), H_zCv.cpu()
-        # I[z_j;v_k] = -H[z_j|v_k] + H[z_j]   (evaluate.py:147-149)
-        mut_info = -H_zCv + H_z
-        sorted_mut_info = torch.sort(mut_info, dim=1, descending=True)[0].clamp(min=0)
-        metric_helpers = {'marginal_entropies': H_z, 'cond_entropies': H_zCv}
-        mig = self._mutual_information_gap(sorted_mut_info, lat_sizes, storer=metric_helpers)
-        aam = self._axis_aligned_metric(sorted_mut_info, storer=metric_helpers)
-        metrics = {'MIG': mig.item(), 'AAM': aam.item()}
+        H_z = self._entropies(table, None, n_samples, take())                      # H[z_j]                 [D]
+        H_zCv = torch.zeros(len(lat_sizes), table.dim, device=self.device)         # H[z_j | v_k]           [K, D]
+        for k, (size, name) in enumerate(zip(lat_sizes, ds.lat_names)):
+            for value in range(size):
+                self.logger.info("Estimating conditional entropies for the {}th value of {}.".format(value, name))
+                rows = table.rows_where(lat_sizes, k, value)
+                H_zCv[k] += self._entropies(table, rows, n_samples, take()) / size
+        scores = disentanglement_scores(H_z.cpu(), H_zCv.cpu(), lat_sizes)
         os.makedirs(self.save_dir, exist_ok=True)
-        torch.save(metric_helpers, os.path.join(self.save_dir, METRIC_HELPERS_FILE))
-        return metrics
+        torch.save(scores, os.path.join(self.save_dir, METRIC_HELPERS_FILE))        # same keys as evaluate.py:151-156
+        return {'MIG': scores["mig"].item(), 'AAM': scores["aam"].item()}
 
-    def _mutual_information_gap(self, sorted_mut_info, lat_sizes, storer=None):
-        """evaluate.py:160-180 (balanced factors: H(v_k) = log |V_k|)."""
-        delta_mut_info = sorted_mut_info[:, 0] - sorted_mut_info[:, 1]
-        H_v = torch.from_numpy(np.asarray(lat_sizes)).float().log()
-        mig_k = delta_mut_info / H_v
-        mig = mig_k.mean()
-        if storer is not None:
-            storer["mig_k"] = mig_k
-            storer["mig"] = mig
-        return mig
-
-    def _axis_aligned_metric(self, sorted_mut_info, storer=None):
-        """evaluate.py:182-194."""
-        numerator = (sorted_mut_info[:, 0] - sorted_mut_info[:, 1:].sum(dim=1)).clamp(min=0)
-        aam_k = numerator / sorted_mut_info[:, 0]
-        aam_k[torch.isnan(aam_k)] = 0
-        aam = aam_k.mean()
-        if storer is not None:
-            storer["aam_k"] = aam_k
-            storer["aam"] = aam
-        return aam
-
-    def _compute_q_zCx(self, dataloader):
-        """evaluate.py:196-231: (mean, logvar) of q(z|x) for every x, through the native encoder; the model is in eval
-        mode here (Evaluator.__call__), so the "sample" of q(z|x) is its mean (vae.py:69-71)."""
-        len_dataset = len(dataloader.dataset)
-        latent_dim = self.model.latent_dim
-        mean = torch.zeros(len_dataset, latent_dim, device=self.device)
-        logvar = torch.zeros(len_dataset, latent_dim, device=self.device)
-        n = 0
+    def _encode_dataset(self, dataloader):
+        """(mean, logvar) of q(z|x) for every image of the data set, [N, D] each on the device, through the native encoder
+        (evaluate.py:196-231; in eval mode -- Evaluator.__call__ -- the reference's "sample" of q(z|x) is its mean,
+        vae.py:69-71, so the table of means doubles as the table of samples)."""
+        chunks = []
         with torch.no_grad():
             for x, _label in dataloader:
-                batch_size = x.size(0)
-                mean[n:n + batch_size], logvar[n:n + batch_size] = self.model.encoder(x.to(self.device))
-                n += batch_size
-        samples_zCx = self.model.reparameterize(mean, logvar)
-        return samples_zCx, (mean, logvar)
+                chunks.append(self.model.encoder(x.to(self.device)))
+        return torch.cat([m for m, _ in chunks]), torch.cat([lv for _, lv in chunks])
 
-    def _estimate_latent_entropies(self, samples_zCx, params_zCX, n_samples=10000, sample_idx=None):
-        """evaluate.py:233-297 on the device: H(z_j) = E_z[-log q(z_j)], q(z_j) = 1/N sum_n q(z_j|x_n).
-        The reference re-views the gathered [n_samples, D] samples as [D, n_samples] (:262, a reshape): the gathered
-        buffer is handed to the kernel as that [D, S] image, which reproduces it exactly."""
-        len_dataset, latent_dim = samples_zCx.shape
-        device = samples_zCx.device
-        if sample_idx is None:
-            sample_idx = torch.randperm(len_dataset, device=device)[:n_samples]                     # :259
-        sample_idx = sample_idx.to(device)[:n_samples]
-        if sample_idx.numel() != n_samples:
-            raise RuntimeError("shape '[{}, {}]' is invalid for input of size {}".format(      # what .view raises at :262
-                latent_dim, n_samples, sample_idx.numel() * latent_dim))
-        z_ds = samples_zCx.index_select(0, sample_idx).contiguous()                                 # memory = the [D, S] view
-        mean, logvar = params_zCX[0].contiguous(), params_zCX[1].contiguous()
-        n_ws = _lib.lib().dvae_latent_entropy_ws_floats(len_dataset, latent_dim, n_samples)
+    def _entropies(self, table, rows, n_samples, draw):
+        """H[z_j] = E_z[-log q(z_j)] with q(z_j) = 1/N sum_n q(z_j | x_n) over the `rows` of the table (None: all of it),
+        estimated on n_samples of its own samples (evaluate.py:233-297), as one dvae_latent_entropy launch sequence.
+        draw: the ``randperm(N)[:n_samples]`` of evaluate.py:259, or None to draw it here.  The reference re-views the
+        gathered [n_samples, D] block as [D, n_samples] (:262, a reshape, not a transpose): the gathered block is handed to
+        the kernel as that [D, S] image, which reproduces it exactly."""
+        mean, logvar = table.select(rows)
+        n, dim = mean.shape
+        if draw is None:
+            draw = torch.randperm(n, device=mean.device)
+        draw = draw.to(mean.device)[:n_samples]
+        if draw.numel() != n_samples:              # the reference's .view(latent_dim, n_samples) fails the same way
+            raise RuntimeError("shape '[{}, {}]' is invalid for input of size {}".format(dim, n_samples, draw.numel() * dim))
+        z_ds = mean.index_select(0, draw).contiguous()
+        need = _lib.lib().dvae_latent_entropy_ws_floats(n, dim, n_samples)
         ws = getattr(self, "_metric_ws", None)
-        if ws is None or ws.numel() < n_ws or ws.device != device:
-            ws = self._metric_ws = torch.empty(n_ws, dtype=torch.float32, device=device)
-        H_z = torch.empty(latent_dim, dtype=torch.float32, device=device)
-        call("dvae_latent_entropy", ptr(z_ds), ptr(mean), ptr(logvar), len_dataset, latent_dim, n_samples, ptr(ws), ptr(H_z),
-             _stream())
-        return H_z
+        if ws is None or ws.numel() < need or ws.device != mean.device:
+            ws = self._metric_ws = torch.empty(need, dtype=torch.float32, device=mean.device)
+        H = torch.empty(dim, dtype=torch.float32, device=mean.device)
+        call("dvae_latent_entropy", ptr(z_ds), ptr(mean), ptr(logvar), n, dim, n_samples, ptr(ws), ptr(H), _stream())
+        return H
 
-    def _estimate_H_zCv(self, samples_zCx, params_zCx, lat_sizes, lat_names, n_samples=10000, draws=None):
-        """evaluate.py:299-317: conditional entropies H[z|v], averaged over the values of every factor."""
-        latent_dim = samples_zCx.size(-1)
-        len_dataset = reduce((lambda x, y: x * y), [int(k) for k in lat_sizes])
-        H_zCv = torch.zeros(len(lat_sizes), latent_dim, device=self.device)
-        for i_fac_var, (lat_size, lat_name) in enumerate(zip(lat_sizes, lat_names)):
-            lat_size = int(lat_size)
-            idcs = [slice(None)] * len(lat_sizes)
-            for i in range(lat_size):
-                self.logger.info("Estimating conditional entropies for the {}th value of {}.".format(i, lat_name))
-                idcs[i_fac_var] = i
-                sl = tuple(idcs)
-                samples_zxCv = samples_zCx[sl].contiguous().view(len_dataset // lat_size, latent_dim)
-                params_zxCv = tuple(p[sl].contiguous().view(len_dataset // lat_size, latent_dim) for p in params_zCx)
-                H_zCv[i_fac_var] += self._estimate_latent_entropies(
-                    samples_zxCv, params_zxCv, n_samples=n_samples,
-                    sample_idx=None if draws is None else next(draws)) / lat_size
-        return H_zCv
+
+class _LatentTable:
+    """q(z|x) of a whole data set: mean / logvar [N, D] on the device, rows in the data set's factor order."""
+
+    def __init__(self, mean, logvar):
+        self.mean, self.logvar = mean.contiguous(), logvar.contiguous()
+        self.n, self.dim = self.mean.shape
+        self._index = None
+
+    def rows_where(self, lat_sizes, factor, value):
+        """Row numbers of the images whose `factor`-th factor of variation takes its `value`-th value, in data-set order
+        (= the order of the reference's ``samples_zCx[..., value, ...]`` slice flattened, evaluate.py:311-314)."""
+        if self._index is None:
+            self._index = torch.arange(self.n, device=self.mean.device).view(*lat_sizes)
+        return self._index.select(factor, value).reshape(-1)
+
+    def select(self, rows):
+        if rows is None:
+            return self.mean, self.logvar
+        return self.mean.index_select(0, rows), self.logvar.index_select(0, rows)
+
+
+def disentanglement_scores(H_z, H_zCv, lat_sizes):
+    """MIG (evaluate.py:160-180) and AAM (:182-194) from the marginal entropies H_z [D] and the conditional entropies
+    H_zCv [K, D] of K balanced factors of variation (H[v_k] = log |V_k|).  I[z_j; v_k] = H[z_j] - H[z_j | v_k], negative
+    estimates count as 0; per factor: MIG_k = (largest - second largest information) / H[v_k], AAM_k = max(0, largest -
+    all the others) / largest (0 where no latent carries information).  Returns the reference's metric_helpers dict."""
+    info = (H_z.unsqueeze(0) - H_zCv).clamp(min=0)                 # [K, D]
+    ranked = torch.sort(info, dim=1, descending=True)[0]
+    best, runner_up = ranked[:, 0], ranked[:, 1] if ranked.shape[1] > 1 else torch.zeros_like(ranked[:, 0])
+    mig_k = (best - runner_up) / torch.tensor([float(k) for k in lat_sizes]).log()
+    others = ranked[:, 1:].sum(dim=1)
+    aam_k = torch.where(best > 0, (best - others).clamp(min=0) / best, torch.zeros_like(best))
+    return {"marginal_entropies": H_z, "cond_entropies": H_zCv, "mig_k": mig_k, "mig": mig_k.mean(),
+            "aam_k": aam_k, "aam": aam_k.mean()}

@@ -149,10 +149,15 @@ class BaseLoss(abc.ABC):
     # one HIP stream instead of two below this many input elements per step (engine.single_stream); DVAE_STREAMS=1|2 forces
     SINGLE_STREAM_ELEMS = int(knob("DVAE_SINGLE_STREAM_ELEMS", 64 * 3 * 64 * 64))   # measured: profiles/r02_run10_streams.txt
 
+    # dependency-driven weight-gradient schedule (engine.eager_wgrad) up to this many input elements per step; above, the
+    # batch-sized schedule (measured cross-over: profiles/r03_*sweep*)
+    EAGER_WGRAD_ELEMS = int(knob("DVAE_EAGER_WGRAD_ELEMS", 384 * 3 * 64 * 64))
+
     def _streams(self, model, data):
         mode = knob("DVAE_STREAMS", "auto")
         single = mode == "1" or (mode == "auto" and data.numel() <= self.SINGLE_STREAM_ELEMS)
         model.engine.single_stream = bool(single) and self._world()[0] == 1
+        model.engine.eager_wgrad = data.numel() <= int(knob("DVAE_EAGER_WGRAD_ELEMS", self.EAGER_WGRAD_ELEMS))
         return model.engine.single_stream
 
     def _replay_mode(self, is_train, data):
@@ -167,7 +172,7 @@ class BaseLoss(abc.ABC):
         batch pointer, the stream, and the few Python-side switches passed as scalars."""
         return (id(model), data.shape, data.data_ptr(), injected, _stream(), model.arena.flat.data_ptr(),
                 model.arena.grad.data_ptr(), _lib.ALLOC_GEN[0], self.rec_dist, getattr(self, "is_mss", None),
-                model.engine.single_stream)
+                model.engine.single_stream, model.engine.eager_wgrad)
 
     @abc.abstractmethod
     def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):

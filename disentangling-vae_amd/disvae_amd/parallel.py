@@ -4,8 +4,9 @@ The reference is single-process; this is new.  What is exchanged 
   * every loss      : sum-all-reduce of the flat gradient arena in two spans (decoder half as soon as the decoder's
                       gradients are final, encoder half at the end; 2.0 MB together) and one of the 32-float packed
                       loss sums;
-  * btcvae          : all-gather of (z, mu, logvar) so every rank evaluates its ROW block of the global B x B estimator
-                      (reference parity at the global batch), and a reduce-scatter of the [B_global, D] column gradients;
+  * btcvae          : ONE all-gather of the packed (z, mu, logvar) so every rank evaluates its ROW block of the global
+                      B x B estimator (reference parity at the global batch), and ONE reduce-scatter of the packed
+                      [B_global, D] column gradients (dmu, dlogvar);
   * factor          : all-gather of the second half-batch latents (permute_dims permutes across the GLOBAL half batch;
                       every rank applies the same, shared-seed, CPU-generated permutations and keeps its slice); the
                       16 MB discriminator gradient arena is all-reduced as soon as the discriminator's backward pass has
@@ -58,11 +59,11 @@ class Comm:
 
     def all_gather_into(self, out, t):
         """out[world * n] <- concatenation of every rank's t[n] in rank order."""
-        dist.all_gather_into_tensor(out, t, group=self.group)
+        dist.all_gather_into_tensor(out.view(-1), t.reshape(-1), group=self.group)
 
     def reduce_scatter_into(self, out, t):
         """out[n] <- this rank's chunk of the element-wise sum over ranks of t[world * n]."""
-        dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=self.group)
+        dist.reduce_scatter_tensor(out.view(-1), t.reshape(-1), op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast(self, t, src=0):
         dist.broadcast(t, src=src, group=self.group)
@@ -92,24 +93,35 @@ class Comm:
         return out
 
     def all_gather_latents(self, z, mu, logvar):
-        """(z, mu, logvar) local [B, D] -> global [world*B, D] each (three collectives issued as one group)."""
-        self.group_start()
-        out = tuple(self.all_gather_rows(t, n) for t, n in ((z, "z_all"), (mu, "mu_all"), (logvar, "lv_all")))
-        self.group_end()
-        return out
+        """(z, mu, logvar) local [B, D] -> global [world*B, D] each, in rank order: ONE collective.  The engine keeps the
+        three tensors as consecutive slabs of one [3, B, D] buffer, which is sent as it is (anything else is packed first);
+        one copy kernel re-orders the received [world, 3, B, D] into three contiguous [world*B, D] tensors."""
+        B, D = z.shape
+        n = B * D * z.element_size()
+        if (z.is_contiguous() and mu.is_contiguous() and logvar.is_contiguous()
+                and mu.data_ptr() == z.data_ptr() + n and logvar.data_ptr() == z.data_ptr() + 2 * n
+                and z.untyped_storage().data_ptr() == logvar.untyped_storage().data_ptr()):
+            send = z.as_strided((3, B, D), (B * D, D, 1))
+        else:
+            send = self._buf("lat_send", (3, B, D), z)
+            torch.stack((z, mu, logvar), out=send)
+        recv = self._buf("lat_recv", (self.world_size, 3, B, D), z)
+        self.all_gather_into(recv, send)
+        glob = self._buf("lat_glob", (3, self.world_size * B, D), z)
+        glob.view(3, self.world_size, B, D).copy_(recv.permute(1, 0, 2, 3))
+        return glob[0], glob[1], glob[2]
 
     def reduce_scatter_cols(self, dmu_all, dlv_all):
-        """Column gradients [B_global, D] summed over ranks -> this rank's rows [B, D] (rows of rank r are contiguous)."""
-        B = dmu_all.shape[0] // self.world_size
-        outs = []
-        self.group_start()
-        for t, n in ((dmu_all, "dmu_loc"), (dlv_all, "dlv_loc")):
-            t = t.contiguous()
-            out = self._buf(n, (B,) + tuple(t.shape[1:]), t)
-            self.reduce_scatter_into(out, t)
-            outs.append(out)
-        self.group_end()
-        return outs[0], outs[1]
+        """Column gradients [B_global, D] summed over ranks -> this rank's rows [B, D] (rows of rank r are contiguous):
+        ONE collective on the pair packed as [world, 2, B, D]."""
+        W = self.world_size
+        B = dmu_all.shape[0] // W
+        D = dmu_all.shape[1]
+        send = self._buf("cols_send", (W, 2, B, D), dmu_all)
+        torch.stack((dmu_all.reshape(W, B, D), dlv_all.reshape(W, B, D)), dim=1, out=send)
+        out = self._buf("cols_loc", (2, B, D), dmu_all)
+        self.reduce_scatter_into(out, send)
+        return out[0], out[1]
 
     def close(self):
         pass

@@ -317,6 +317,14 @@ int dvae_set_coef(float* coef, float c0, float c1, float c2, float c3, float c4,
 /* out[i] = a[i] + b[i] (n elements), helper for merging latent gradients (quirk Q1).       */
 int dvae_add(const float* a, const float* b, float* out, long n, void* stream);
 
+/* ---- stream ordering (new; the reference is one stream of ATen ops) -----------------------------------------------
+ * Work enqueued on `later` after this call runs after everything enqueued on `earlier` before it (both hipStream_t of the
+ * current device).  The native training step issues its weight-gradient kernels on a second stream beside the chain of
+ * input gradients (training.py:157 is ONE autograd pass: only the data dependencies between its kernels matter); this is
+ * its fork / join primitive: an event recorded with a DEVICE-scope release (hipEventReleaseToDevice: no system-scope cache
+ * flush, the two streams share the device) from a small internal pool, then hipStreamWaitEvent.  Capturable.            */
+int dvae_stream_order(void* earlier, void* later);
+
 /* ---- RCCL collectives over xGMI (data parallelism over the GPUs of one node; new, the reference is single-process) ----
  * One communicator per process (= per GPU).  Every collective is ENQUEUED on `stream` (ordered with the kernels around
  * it, no host synchronisation) in fp32 with sum reduction.  librccl is dlopen()ed on first use ($DVAE_RCCL_LIB, the

@@ -8,8 +8,8 @@ from disvae_amd.parallel import Comm
 
 class HostStagedComm(Comm):
     def _stage(self, fn, out, t):
-        ho, ht = out.cpu(), t.cpu()
-        fn(ho, ht)
+        ho, ht = out.cpu().contiguous(), t.cpu().contiguous()
+        fn(ho.view(-1), ht.view(-1))          # gloo's *_tensor collectives take flat buffers
         out.copy_(ho)
 
     def all_gather_into(self, out, t):

@@ -41,10 +41,14 @@ def test_discriminator_forward_is_differentiable(M, D):
     ref.backward()
     check(d_z, _ref_forward(sd, z1r), rtol=1e-5, atol_rel=2e-6, what="D(z)")
     check(loss, ref, rtol=1e-5, what="loss through D")
-    check(z1d.grad, z1r.grad, rtol=1e-4, atol_rel=2e-5, what="dL/dz1")
-    check(zpd.grad, zpr.grad, rtol=1e-4, atol_rel=2e-5, what="dL/dz_perm")
+    # gradients: LeakyReLU' jumps from 0.2 to 1 at 0, so a hidden unit whose pre-activation is within fp32 rounding of zero
+    # takes the other slope than in fp64 and moves ITS sample's dL/dz by up to ~1e-3 of the tensor's scale (M x 5000 units:
+    # a handful at M = 128, none at M = 9 / 37, which therefore keep the tight bound)
+    tol = dict(rtol=1e-4, atol_rel=2e-5) if M < 100 else dict(rtol=1e-3, atol_rel=2e-3)
+    check(z1d.grad, z1r.grad, what="dL/dz1", **tol)
+    check(zpd.grad, zpr.grad, what="dL/dz_perm", **tol)
     for k, p in disc.named_parameters():
-        check(p.grad, sd[k].grad, rtol=1e-4, atol_rel=2e-5, what="dL/d" + k)
+        check(p.grad, sd[k].grad, what="dL/d" + k, **tol)
     # a second backward accumulates (zero_grad(set_to_none=False) semantics of torch.optim)
     before = {k: p.grad.clone() for k, p in disc.named_parameters()}
     total(disc(z1d), disc(zpd), zeros.to(DEV), ones.to(DEV)).backward()

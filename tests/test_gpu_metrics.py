@@ -36,6 +36,24 @@ def test_entropy_kernel_vs_reference_golden():
         np.testing.assert_allclose(H.cpu().numpy(), g[key], rtol=1e-5, err_msg=key)
 
 
+def test_entropy_of_a_column_without_any_finite_density_is_inf_not_nan():
+    """exp(-logvar) overflows for logvar < -88.7: every log-density of such a latent is -inf, torch.logsumexp returns -inf
+    and the entropy estimate is +inf (evaluate.py:273-289); the kernel's running-max rescale must not turn that into NaN."""
+    N, D, S = 40, 2, 5
+    gen = torch.Generator().manual_seed(7)
+    mean = torch.randn(N, D, generator=gen)
+    logvar = torch.randn(N, D, generator=gen) * 0.3
+    logvar[:, 0] = -200.0
+    z = torch.randn(S, D, generator=gen) + 3.0           # S x D block = the [D, S] image the kernel reads
+    H, _ = _entropy(z, mean, logvar, S)
+    zv = z.reshape(D, S)
+    ld = -0.5 * (math.log(2 * math.pi) + logvar[:, 1:2]) - 0.5 * (zv[1].view(1, S) - mean[:, 1:2]) ** 2 * torch.exp(-logvar[:, 1:2])
+    ref1 = (math.log(N) - torch.logsumexp(ld.double(), 0)).mean()
+    got = H.cpu()
+    assert torch.isinf(got[0]) and got[0] > 0, got
+    np.testing.assert_allclose(got[1].item(), ref1.item(), rtol=1e-5)
+
+
 @pytest.mark.parametrize("N,D,S", [(5003, 10, 777), (17, 3, 5), (40000, 16, 300)])
 def test_entropy_kernel_vs_oracle(N, D, S):
     gen = torch.Generator().manual_seed(N)

@@ -240,3 +240,34 @@ def test_bench_reads_hbm_traffic_from_the_newest_pmc_summary(tmp_path, monkeypat
     (prof / "r03_run1_pmc_summary.md").write_text(head + "| k_up32ws<16, true> | 1 | 170.0 | 130.0 | 0.5 |\n")
     assert bench.pmc_traffic("k_up32ws<16")[1] == os.path.join("profiles", "r03_run1_pmc_summary.md")
     assert bench.pmc_traffic("k_no_such_kernel") == (None, None)
+
+
+def test_device_image_loader_draws_batches_like_the_reference_dataloader():
+    """DeviceImageLoader(shuffle=True) == DataLoader(dataset, batch_size, shuffle=True) (utils/datasets.py:67-71) for the
+    same torch.manual_seed: same images per batch, same ragged last batch, same state of the CPU generator afterwards;
+    under data parallelism the ranks partition each global batch in rank order and agree on the number of batches."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from disvae_amd.data import DeviceImageLoader
+    n, B = 37, 8
+    imgs = (torch.arange(n, dtype=torch.uint8).view(n, 1, 1, 1) * torch.ones(1, 1, 4, 4, dtype=torch.uint8)).contiguous()
+    labels = torch.arange(n)
+    for epoch_seed in (0, 1234):
+        torch.manual_seed(epoch_seed)
+        ref = [(x[:, 0, 0, 0].tolist(), y.tolist()) for x, y in DataLoader(TensorDataset(imgs, labels), batch_size=B, shuffle=True)]
+        ref_next = torch.rand(3)
+        torch.manual_seed(epoch_seed)
+        got = [(x[:, 0, 0, 0].tolist(), y.tolist()) for x, y in DeviceImageLoader(imgs, batch_size=B, labels=labels, device="cpu")]
+        assert got == ref and torch.equal(torch.rand(3), ref_next)
+    # two ranks: every global batch of 2 x 4 images is the reference's batch of 8, split in rank order
+    shards = []
+    for rank in range(2):
+        torch.manual_seed(1234)
+        ld = DeviceImageLoader(imgs, batch_size=4, labels=labels, device="cpu", rank=rank, world_size=2)
+        shards.append([x[:, 0, 0, 0].tolist() for x, _ in ld])
+        assert len(ld) == len(shards[-1]) == 5
+    for k in range(4):
+        assert shards[0][k] + shards[1][k] == ref[k][0]
+    assert shards[0][4] + shards[1][4] == ref[4][0][:2] + ref[4][0][2:4]       # 5 leftover images: 2 + 2, one dropped
+    # no shuffle: slices in order
+    ld = DeviceImageLoader(imgs, batch_size=10, shuffle=False, device="cpu")
+    assert [x.shape[0] for x, _ in ld] == [10, 10, 10, 7]

@@ -9,6 +9,7 @@
 #   smoke     __graft_entry__.smoke()
 #   bench     python bench.py (BENCH_ARGS; default run = headline + drop-in + the other three configs + CPU baseline)
 #   sweep     short bench lines at B = 64 / 128 / 256 / 1024 (btcvae 3ch) and the dsprites / factor configs
+#   absweep   A/B of the host-side schedule knobs (DVAE_DEBUG=1) over the batch size
 #   kbench    every kernel alone at B = 1024 and B = 128
 #   prof      rocprofv3 --kernel-trace --stats of the default workload + summary + timeline
 #   timeline  the B = 128 step as a timeline (rocprofv3 kernel trace)
@@ -77,6 +78,23 @@ if has sweep; then
   for c in factor_celeba btcvae_dsprites factor_dsprites; do
     timeout 200 python bench.py --config $c --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --no-parity-check --no-drop-in 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$c', d['value'], d['ms_per_step'])" | tee -a gpurun_out/${TAG}_sweep.txt
   done
+fi
+if has absweep; then
+  echo "== schedule A/B (DVAE_DEBUG=1 knobs): weight-gradient schedule (eager = dependency-driven, batch = batch-sized), streams"
+  line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'])"; }
+  BA="--steps 100 --warmup 20 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
+  for b in 128 256 512 1024; do
+    DVAE_DEBUG=1 DVAE_EAGER_WGRAD_ELEMS=0 timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "B=$b batch-sized"
+    DVAE_DEBUG=1 DVAE_EAGER_WGRAD_ELEMS=999999999 timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "B=$b eager"
+  done | tee gpurun_out/${TAG}_absweep.txt
+  for b in 64 128; do
+    DVAE_DEBUG=1 DVAE_STREAMS=1 timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "B=$b one stream"
+    DVAE_DEBUG=1 DVAE_STREAMS=2 timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "B=$b two streams"
+  done | tee -a gpurun_out/${TAG}_absweep.txt
+  for c in btcvae_dsprites factor_dsprites; do
+    DVAE_DEBUG=1 DVAE_EAGER_WGRAD_ELEMS=0 timeout 200 python bench.py --config $c --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --no-parity-check --no-drop-in 2>&1 | tail -n 1 | line "$c batch-sized"
+    DVAE_DEBUG=1 DVAE_EAGER_WGRAD_ELEMS=999999999 timeout 200 python bench.py --config $c --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --no-parity-check --no-drop-in 2>&1 | tail -n 1 | line "$c eager"
+  done | tee -a gpurun_out/${TAG}_absweep.txt
 fi
 if has kbench; then
   echo "== kbench"
