@@ -310,7 +310,7 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
 //   source pixels per lane and channel quad serve 32 MFMAs); B operand: w for cb = lane % 4, the wave's 8 taps x 32
 //   channels = 256 VGPRs per lane for the whole kernel (one wave per SIMD: the register file is this kernel's to use);
 //   D: lane (block b, cb) holds 4 pixels x 2 column parities = 8 consecutive output columns of one row: two 16-byte stores.
-// Exact fp32 (k-ordered fmaf chains, two accumulators per output for the even / odd channel, added at the end).
+// Exact fp32 (k-ordered fmaf chains, four accumulators per output -- contracted channel mod 4 -- added at the end).
 #define UM_GRID 256                // persistent: one workgroup per CU (a wave keeps 256 VGPRs of weights)
 #define UM_ROWS 6
 #define UM_COLS 34
@@ -392,18 +392,43 @@ __global__ __launch_bounds__(256) void k_up_thin_mfma(const float* __restrict__ 
   int buf = 0;
   for (; unit < n_units; unit += gridDim.x) {
     const float* t = st[buf];
-    f32x4 acc[2][2];                                     // [px][channel parity]
+    // lane (block b = lane/4, cb): pixels 4b .. 4b+3 of the wave's two rows x both column parities = output columns
+    // 8 (b%8) .. +7 of row 2 (sy0 + 2rp + b/8) + py of channel cb
+    const int b_ = lane >> 2;
+    const long o = ((((long)(unit >> 3) * C + (cb < C ? cb : 0)) * 64) + 2 * ((unit & 7) * 4 + 2 * rp + (b_ >> 3)) + py) * 64 + 8 * (b_ & 7);
+    // the likelihood target of this unit: requested now, consumed after the MFMA phase
+    f32x4 tg0 = {0.f, 0.f, 0.f, 0.f}, tg1 = {0.f, 0.f, 0.f, 0.f};
+    uint2 tgb = {0u, 0u};
+    if (FUSE && cb < C) {
+      if constexpr (sizeof(TT) == 4) {
+        tg0 = *reinterpret_cast<const f32x4*>(target + o);
+        tg1 = *reinterpret_cast<const f32x4*>(target + o + 4);
+      } else {
+        tgb = *reinterpret_cast<const uint2*>(target + o);
+      }
+    }
+    f32x4 acc[2][4];                                     // [px][channel % 4]: an accumulator is re-used every 8th MFMA
 #pragma unroll
     for (int px = 0; px < 2; ++px)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) acc[px][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {                        // 4 contracted channels per step
-      f32x4 x[2][3];
+      for (int q = 0; q < 4; ++q) acc[px][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 8 steps of 4 contracted channels: 6 operand reads (2 source rows x 3 source columns) + 32 MFMAs each.  The reads of
+    // step q+1 are issued before the MFMAs of step q (register ping-pong, order pinned by sched_group_barrier): with one
+    // wave per SIMD nothing else hides the LDS latency
+    f32x4 x[2][2][3];
+    auto rd = [&](int q, int slot) {
 #pragma unroll
       for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
-        for (int dc = 0; dc < 3; ++dc) x[ty][dc] = *reinterpret_cast<const f32x4*>(t + aoff[ty][dc] + ((q ^ asw[dc]) << 2));
+        for (int dc = 0; dc < 3; ++dc)
+          x[slot][ty][dc] = *reinterpret_cast<const f32x4*>(t + aoff[ty][dc] + ((q ^ asw[dc]) << 2));
+    };
+    rd(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cur = q & 1;
+      if (q + 1 < 8) rd(q + 1, cur ^ 1);
 #pragma unroll
       for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
@@ -413,22 +438,19 @@ __global__ __launch_bounds__(256) void k_up_thin_mfma(const float* __restrict__ 
             const int kw = 1 - px + 2 * tx, dc = 1 + px - tx;          // source column l + px - tx
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc[px][j & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[ty][dc][j], Bw[ty][kw][4 * q + j], acc[px][j & 1], 0, 0, 0);
+              acc[px][j] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[cur][ty][dc][j], Bw[ty][kw][4 * q + j], acc[px][j], 0, 0, 0);
           }
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // 6 DS reads (next step)
+      __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);   // 32 MFMAs (this step)
     }
     // hand over: the next unit's tile (prefetched during the MFMAs) goes to the other buffer
     if (unit + (int)gridDim.x < n_units) store_tile(st[buf ^ 1]);
     __syncthreads();
     if (unit + 2 * (int)gridDim.x < n_units) load_tile(unit + 2 * gridDim.x);
     buf ^= 1;
-    // epilogue: lane (block b = lane/4, cb): pixels 4b .. 4b+3 of the wave's two rows x both column parities = output
-    // columns 8 (b%8) .. +7 of row 2 (sy0 + 2rp + b/8) + py
+    // epilogue
     if (cb < C) {
-      const int n = unit >> 3, sy0 = (unit & 7) * 4;
-      const int b = lane >> 2;
-      const int by = 2 * (sy0 + 2 * rp + (b >> 3)) + py;
-      const long o = ((((long)n * C + cb) * 64) + by) * 64 + 8 * (b & 7);
-      const f32x4 s0 = acc[0][0] + acc[0][1], s1 = acc[1][0] + acc[1][1];
+      const f32x4 s0 = (acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]), s1 = (acc[1][0] + acc[1][1]) + (acc[1][2] + acc[1][3]);
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[2 * e] = s0[e] + bv; v[2 * e + 1] = s1[e] + bv; }
@@ -442,15 +464,13 @@ __global__ __launch_bounds__(256) void k_up_thin_mfma(const float* __restrict__ 
       if (FUSE) {
         float xt[8];
         if constexpr (sizeof(TT) == 4) {
-          const f32x4 t0 = *reinterpret_cast<const f32x4*>(target + o), t1 = *reinterpret_cast<const f32x4*>(target + o + 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { xt[e] = t0[e]; xt[4 + e] = t1[e]; }
+          for (int e = 0; e < 4; ++e) { xt[e] = tg0[e]; xt[4 + e] = tg1[e]; }
         } else {
-          const uint2 tw = *reinterpret_cast<const uint2*>(target + o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            xt[e] = to_unit((uint8_t)((tw.x >> (8 * e)) & 0xff));
-            xt[4 + e] = to_unit((uint8_t)((tw.y >> (8 * e)) & 0xff));
+            xt[e] = to_unit((uint8_t)((tgb.x >> (8 * e)) & 0xff));
+            xt[4 + e] = to_unit((uint8_t)((tgb.y >> (8 * e)) & 0xff));
           }
         }
         float gl[8], gr;
@@ -499,27 +519,24 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, 
     const int cb = bval[t] ? (nidx >> 4) : 0, kh = (nidx >> 2) & 3, kw = nidx & 3;
     boff[t] = cb * TB_PLANE + kh * TB_ROW + (kw & 1) * TB_PAR + (kw >> 1);
   }
-  // two units in flight (registers: 8 + 16 per thread and unit), see k_down_thin
-  struct UnitRegs { BigThinRegs<C, TB> b; f32x4 s[4]; };
-  UnitRegs ua, ub;
-  const int gstep = gridDim.x;
-  auto load_unit = [&](UnitRegs& r, int u) {
+  BigThinRegs<C, TB> pfb;
+  f32x4 pfs[4];
+  auto load_unit = [&](int u) {
     const int n = u >> 3, sy0 = (u & 7) * 4;
-    load_big_thin<C, TB>(r.b, big, n, sy0, true, tid);
+    load_big_thin<C, TB>(pfb, big, n, sy0, true, tid);
     const float* src = small + ((((long)n * 32 + sy0) * 32)) * 32;  // 128 pixels x 32 ch contiguous
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r.s[k] = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
+    for (int k = 0; k < 4; ++k) pfs[k] = *reinterpret_cast<const f32x4*>(src + (tid + k * 256) * 4);
   };
   int unit = blockIdx.x;
-  if (unit < n_units) load_unit(ua, unit);
-  if (unit + gstep < n_units) load_unit(ub, unit + gstep);
-  auto body = [&](UnitRegs& r, int u) {
+  if (unit < n_units) load_unit(unit);
+  for (; unit < n_units; unit += gridDim.x) {
     __syncthreads();
-    store_big_thin<C, TB>(r.b, bt, tid, lut);
+    store_big_thin<C, TB>(pfb, bt, tid, lut);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(sp + (tid + k * 256) * 4) = r.s[k];
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(sp + (tid + k * 256) * 4) = pfs[k];
     __syncthreads();
-    if (u + 2 * gstep < n_units) load_unit(r, u + 2 * gstep);
+    if (unit + (int)gridDim.x < n_units) load_unit(unit + gridDim.x);
     // wave wv handles small row sy_l = wv (32 pixels = 16 k-steps)
 #pragma unroll 4
     for (int t = 0; t < 16; ++t) {
@@ -535,13 +552,6 @@ __global__ __launch_bounds__(256) void k_wgrad_thin(const TB* __restrict__ big, 
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
       }
     }
-  };
-  while (unit < n_units) {
-    body(ua, unit);
-    unit += gstep;
-    if (unit >= n_units) break;
-    body(ub, unit);
-    unit += gstep;
   }
   // cross-wave reduction through LDS (reuse sp: 4 waves x NT x 16 x 64 floats <= 8192)
   __syncthreads();

@@ -3,8 +3,8 @@
 bench.py steps the model with ``torch.optim.Adam(model.flat_parameters(), lr, fused=True)`` (the parameter arena as equal
 8192-element chunks) where a drop-in user writes ``optim.Adam(model.parameters(), lr)`` (main.py:208).  Here:
   * both optimizer constructions, from the same state, on the same batches and injected noise, at the bench batch, for
-    3 steps: after every step the parameters equal each other and torch's CPU Adam fed with the engine's gradients (atol
-    3e-8: a few ulp of a 0.05-sized weight; the three implementations differ in operation order only).  The parameters are
+    3 steps: after every step the parameters equal each other and torch's CPU Adam fed with the engine's gradients to <= 1
+    ulp (the three implementations differ in operation order only).  The parameters are
     re-synchronised after each comparison: Adam turns an ulp-level difference of a near-zero gradient entry into an
     O(lr) difference of the update, so un-synchronised trajectories measure that amplification, not the optimizers;
   * the 10-step training trajectory of SURVEY.md 8c at the bench batch sizes (btcvae 64x64x3 B = 1024, factor 64x64x1
@@ -65,11 +65,14 @@ def test_flat_fused_adam_equals_adam_over_the_state_dict_views():
         for pc, pb in zip(cpu, mb.parameters()):
             pc.grad = pb.grad.detach().cpu().clone()
         oc.step()
-        da = (ma.arena.flat - mb.arena.flat).abs().max().item()
-        assert da <= 3e-8, "step %d: flat fused Adam vs Adam over the views: max |diff| %.3e" % (step, da)
+        # <= 1 ulp of the parameter (2^-23 relative; the largest weights, decoder.lin1's, are ~0.8: 6e-8 absolute) or 2e-6
+        # of an update (lr = 5e-4 -> 1e-9), whichever is larger
+        ulp = lambda a, b: ((a - b).abs() / (b.abs() * 2.0 ** -23 + 1e-9)).max().item()
+        da = ulp(ma.arena.flat, mb.arena.flat)
+        assert da <= 1.0, "step %d: flat fused Adam vs Adam over the views: %.2f ulp" % (step, da)
         for pc, (k, pb) in zip(cpu, mb.named_parameters()):
-            d = (pc.detach() - pb.detach().cpu()).abs().max().item()
-            assert d <= 3e-8, "step %d %s: GPU Adam vs torch CPU Adam on the same gradients: %.3e" % (step, k, d)
+            d = ulp(pb.detach().cpu(), pc.detach())
+            assert d <= 1.0, "step %d %s: GPU Adam vs torch CPU Adam on the same gradients: %.2f ulp" % (step, k, d)
         # the alignment padding of the arena stays zero under the flat optimizer (zero gradient -> zero update)
         used = torch.zeros_like(ma.arena.flat, dtype=torch.bool)
         for k, (off, n) in ma.arena.offsets.items():

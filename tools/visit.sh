@@ -4,7 +4,7 @@
 # STEPS (any subset, in this order):
 #   probe     MFMA 4x4x1 lane-layout probe (tools/ubench/mfma4x4_probe)
 #   fccab     FC-chain instantiations side by side (debug builds)
-#   fused     the round-3 kernel tests only (tests/test_gpu_fused_core.py, tests/test_gpu_timed_config.py)
+#   fused     the round-3 kernel tests only (tests/test_gpu_fused_core.py + FUSED_EXTRA)
 #   tests     the whole -m gpu suite (PYTEST_ARGS to narrow it)
 #   smoke     __graft_entry__.smoke()
 #   bench     python bench.py (BENCH_ARGS; default run = headline + drop-in + the other three configs + CPU baseline)
@@ -31,7 +31,7 @@ if has fccab; then
 fi
 if has fused; then
   echo "== pytest (round-3 kernels)"
-  timeout 900 python -m pytest tests/test_gpu_fused_core.py tests/test_gpu_timed_config.py -m gpu -q --timeout=300 --no-header > gpurun_out/${TAG}_pytest_fused.log 2>&1
+  timeout 900 python -m pytest tests/test_gpu_fused_core.py ${FUSED_EXTRA:-} -m gpu -q --timeout=300 --no-header > gpurun_out/${TAG}_pytest_fused.log 2>&1
   FUSED_RC=$?
   echo "pytest exit: $FUSED_RC" | tee -a gpurun_out/${TAG}_pytest_fused.log
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_fused.log | cut -c1-260 | head -40
