@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
 #pragma unroll
       for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) lse_merge(md[d], sd[d], red[w2][2 + 2 * d], red[w2][3 + 2 * d]);
     }
-    float* rs = rowstats + (long)il * 16;
+    float* rs = rowstats + (long)il * DVAE_ROWSTATS;
     float log_pz = 0.f, log_qzCx = 0.f, log_prod = 0.f;
 #pragma unroll
     for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict
   const float invB = 1.f / (float)Bg;
   const float cP = (beta - alpha) * invB, cQ = (gam - beta) * invB;
   const float* muT = tmp; const float* cT = tmp + (long)D * Bg; const float* ivT = tmp + (long)2 * D * Bg;
-  const float* rs = rowstats + (long)il * 16;
+  const float* rs = rowstats + (long)il * DVAE_ROWSTATS;
   const float lqz = rs[1];
   float zi[DM], lse[DM], g[DM];
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_cols(const float* __restrict
   }
   for (int il = lane; il < Bl; il += 64) {
     const int i = row0 + il;
-    const float* rs = rowstats + (long)il * 16;
+    const float* rs = rowstats + (long)il * DVAE_ROWSTATS;
     const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
     float ld[DM], r[DM], diff[DM];
     float S = 0.f;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void loss_pack_body(const float* __restrict__ rec_par
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (rowstats) {
     for (int i = tid; i < Bl; i += 256) {
-      const float* rs = rowstats + (long)i * 16;
+      const float* rs = rowstats + (long)i * DVAE_ROWSTATS;
       s0 += rs[0]; s1 += rs[1]; s2 += rs[2]; s3 += rs[3];
     }
   }
@@ -587,7 +587,7 @@ int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, 
                       const float* log_w, float* tmp, float* rowstats, hipStream_t s) {
   // latent_dim 10 (every reference experiment) has fully unrolled kernels; any other D <= 12 (rowstats holds
   // 4 + D floats per row) runs the same code with the dimension as a run-time bound
-  if (D < 1 || D > 12) return 1;
+  if (D < 1 || D > DVAE_BTCVAE_MAX_D) return 1;
   const long n = (long)Bg * D;
   hipLaunchKernelGGL(k_btcvae_prep, dim3((n + 255) / 256), dim3(256), 0, s, mu, lv, Bg, D, tmp);
   DVAE_CHECK_LAUNCH();
@@ -600,7 +600,7 @@ int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, 
 int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const float* rowstats, int Bg, int D, int row0,
                       int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz, float* dmu,
                       float* dlv, hipStream_t s) {
-  if (D < 1 || D > 12) return 1;
+  if (D < 1 || D > DVAE_BTCVAE_MAX_D) return 1;
   if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
                                   is_mss, log_w, coef, dz, D);
   else hipLaunchKernelGGL(k_btcvae_bwd_rows<0>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,

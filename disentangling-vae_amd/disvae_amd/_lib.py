@@ -19,7 +19,8 @@ C_INV_B, C_ANNEAL, C_BETA, C_ALPHA, C_GAMMA, C_CAP, NCOEF = 0, 1, 2, 3, 4, 5, 8
 REC_NPART = 2048
 NPACK = 32
 MAX_LATENT_DIM = 16          # DVAE_MAX_D
-BTCVAE_MAX_LATENT_DIM = 12   # DVAE_BTCVAE_MAX_D
+BTCVAE_MAX_LATENT_DIM = 16   # DVAE_BTCVAE_MAX_D
+ROWSTATS = 32                # DVAE_ROWSTATS
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

@@ -287,7 +287,7 @@ class _BtcvaeFn(torch.autograd.Function):
         z, mu, logvar = z.contiguous(), mu.contiguous(), logvar.contiguous()
         B, D = z.shape
         scratch.set_log_w(B, n_data)
-        rowstats = torch.empty(B, 16, dtype=torch.float32, device=z.device)
+        rowstats = torch.empty(B, _lib.ROWSTATS, dtype=torch.float32, device=z.device)
         tmp = torch.empty(3 * D, B, dtype=torch.float32, device=z.device)
         call("dvae_btcvae_fwd", ptr(z), ptr(mu), ptr(logvar), B, D, 0, B, int(is_mss), ptr(scratch.log_w),
              ptr(tmp), ptr(rowstats), _stream())
@@ -444,7 +444,7 @@ class _SingleOptimizerLoss(BaseLoss):
                 zg, mug, lvg = buf.z, buf.mu, buf.logvar
                 if ew > 1:
                     zg, mug, lvg = self.comm.all_gather_latents(buf.z, buf.mu, buf.logvar)
-                rowstats = sc.latent("rowstats", B, 16)
+                rowstats = sc.latent("rowstats", B, _lib.ROWSTATS)
                 tc_tmp = sc.latent("tc_tmp", 3 * D, Be)
                 call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Be, D, er * B, B, int(self.is_mss), ptr(sc.log_w),
                      ptr(tc_tmp), ptr(rowstats), ss)
@@ -581,8 +581,8 @@ class BtcvaeLoss(_SingleOptimizerLoss):
     @staticmethod
     def _check_latent_dim(D):
         if D > _lib.BTCVAE_MAX_LATENT_DIM:
-            raise ValueError("btcvae: latent_dim={} > {}: the fused B x B estimator kernels keep 4 + latent_dim row "
-                             "statistics in 16 floats".format(D, _lib.BTCVAE_MAX_LATENT_DIM))
+            raise ValueError("btcvae: latent_dim={} > {}: the fused B x B estimator kernels keep their per-dimension state "
+                             "in registers".format(D, _lib.BTCVAE_MAX_LATENT_DIM))
 
     def _store(self, storer, vals, D):
         storer['recon_loss'].append(vals[_lib.S_REC])

@@ -28,10 +28,11 @@ extern "C" {
 #define DVAE_VERSION 103
 
 /* latent dimensions the fused kernels cover (the reference's --latent-dim is 10 in every experiment of
- * hyperparam.ini): reparameterisation / KL / scalar slots up to 16, the beta-TCVAE estimator up to 12
- * (rowstats keeps 4 + D floats per row in 16).  D = 10 has fully unrolled kernels.                  */
+ * hyperparam.ini): reparameterisation / KL / scalar slots, the FC chain and the beta-TCVAE estimator up to 16.
+ * D = 10 has fully unrolled kernels.                                                                  */
 #define DVAE_MAX_D 16
-#define DVAE_BTCVAE_MAX_D 12
+#define DVAE_BTCVAE_MAX_D 16
+#define DVAE_ROWSTATS 32        /* floats per row of the estimator's row statistics: 4 + D used */
 
 enum { DVAE_NCHW = 0, DVAE_NHWC = 1 };
 enum { DVAE_ACT_NONE = 0, DVAE_ACT_RELU = 1, DVAE_ACT_LEAKY02 = 2, DVAE_ACT_SIGMOID = 3 };
@@ -258,7 +259,7 @@ int dvae_convT4s2_sigmoid_recon_fwd(const float* x, int x_layout, const float* w
  * z,mu,logvar: [Bg,D] (the whole -- global -- batch); this call evaluates rows
  * [row0,row0+Bl).  log_w = {log(1/N), log(strat), log(1/M)} in fp32 as the reference
  * computes them (math.py:66-73), ignored when is_mss == 0.
- * rowstats[Bl,16]: log_pz, log_qz, log_prod_qzi, log_q_zCx, lse_d[0..D-1]  (1 <= D <= DVAE_BTCVAE_MAX_D).
+ * rowstats[Bl,DVAE_ROWSTATS]: log_pz, log_qz, log_prod_qzi, log_q_zCx, lse_d[0..D-1]  (1 <= D <= DVAE_BTCVAE_MAX_D).
  * tmp[3*Bg*D]: scratch filled by fwd with the transposed per-column constants (mu, -0.5(log
  * 2pi + logvar), exp(-logvar)) and re-read by bwd: pass the same buffer to both.             */
 int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg, int D, int row0,

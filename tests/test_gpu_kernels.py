@@ -259,7 +259,7 @@ def test_btcvae_kat_reference_values():
     z = mu + torch.exp(0.5 * lv) * eps
     lw = torch.zeros(4); lw[:3] = log_importance_weights(B, 100)
     for mss in (1, 0):
-        rs = torch.empty(B, 16, device=DEV)
+        rs = torch.empty(B, _lib.ROWSTATS, device=DEV)
         tmp = torch.empty(3 * D, B, device=DEV)
         call("dvae_btcvae_fwd", ptr(dev(z)), ptr(dev(mu)), ptr(dev(lv)), B, D, 0, B, mss, ptr(dev(lw)), ptr(tmp), ptr(rs), stream())
         for k, nm in enumerate(["log_pz", "log_qz", "log_prod_qzi", "log_q_zCx"]):
@@ -268,7 +268,7 @@ def test_btcvae_kat_reference_values():
 
 @pytest.mark.parametrize("B,n_data,mss,D", [(4, 100, True, 10), (4, 100, False, 10), (8, 737280, True, 10), (64, 202599, True, 10),
                                             (256, 737280, True, 10), (1024, 202599, True, 10), (100, 5000, True, 10),
-                                            (70, 5000, True, 1), (300, 202599, True, 6), (256, 737280, True, 12)])
+                                            (70, 5000, True, 1), (300, 202599, True, 6), (256, 737280, True, 12), (130, 5000, True, 16)])
 def test_btcvae_fwd_bwd(B, n_data, mss, D):
     g = torch.Generator().manual_seed(B)
     mu = torch.randn(B, D, generator=g)
@@ -277,7 +277,7 @@ def test_btcvae_fwd_bwd(B, n_data, mss, D):
     z = mu + torch.exp(0.5 * lv) * eps
     from disvae_amd.utils.math import log_importance_weights
     lw = torch.zeros(4); lw[:3] = log_importance_weights(B, n_data)
-    rs = torch.empty(B, 16, device=DEV)
+    rs = torch.empty(B, _lib.ROWSTATS, device=DEV)
     tmp = torch.empty(3 * D, B, device=DEV)
     zd, mud, lvd, lwd = dev(z), dev(mu), dev(lv), dev(lw)
     call("dvae_btcvae_fwd", ptr(zd), ptr(mud), ptr(lvd), B, D, 0, B, int(mss), ptr(lwd), ptr(tmp), ptr(rs), stream())
@@ -289,7 +289,7 @@ def test_btcvae_fwd_bwd(B, n_data, mss, D):
         check(rs[:, k], ref32[k], rtol=1e-5, atol_rel=1e-5, what="fp32 col %d" % k)
     # row-sharded evaluation gives the same rows (data-parallel path)
     half = B // 2
-    rs2 = torch.empty(B - half, 16, device=DEV)
+    rs2 = torch.empty(B - half, _lib.ROWSTATS, device=DEV)
     call("dvae_btcvae_fwd", ptr(zd), ptr(mud), ptr(lvd), B, D, half, B - half, int(mss), ptr(lwd), ptr(tmp), ptr(rs2), stream())
     assert torch.equal(rs2.cpu()[:, :4 + D], rs[half:].cpu()[:, :4 + D])      # 4 sums + D per-dimension logsumexps
     # backward of alpha*mi + beta*tc + anneal*gamma*dw
@@ -353,7 +353,7 @@ def test_loss_epilogue_equals_pack_then_finalize(kind, B):
     coef[_lib.C_ALPHA], coef[_lib.C_GAMMA], coef[_lib.C_CAP] = 1.0, 2.0, 7.0
     coefd = dev(coef)
     partials = dev(_rand(_lib.REC_NPART, seed=3).abs())
-    rowstats = dev(_rand(B, 16, seed=4)) if kind == _lib.LOSS_BTCVAE else None
+    rowstats = dev(_rand(B, _lib.ROWSTATS, seed=4)) if kind == _lib.LOSS_BTCVAE else None
     disc = dev(_rand(4, seed=5)) if kind == _lib.LOSS_FACTOR else None
     f = lambda *s: torch.empty(*s, device=DEV)
     mu, lv, z = f(B, D), f(B, D), f(B, D)

@@ -419,10 +419,10 @@ def test_replay_device_rng_trains(loss, mode, tmp_path):
     assert np.mean(losses[-5:]) < 0.95 * np.mean(losses[:5])
 
 
-@pytest.mark.parametrize("loss,D", [("btcvae", 4), ("btcvae", 12), ("betaH", 16), ("factor", 7)])
+@pytest.mark.parametrize("loss,D", [("btcvae", 4), ("btcvae", 12), ("btcvae", 16), ("betaH", 16), ("factor", 7)])
 def test_fused_step_other_latent_dims(loss, D):
     """--latent-dim other than 10 (main.py: any value; vae.py:30): the estimator / reparameterisation kernels take
-    the latent dimension at run time (1..12 for btcvae, 1..16 otherwise)."""
+    the latent dimension at run time (1..16)."""
     img, B, seed, n_data, lr = (1, 64, 64), 24, 99, 737280, 5e-4
     torch.manual_seed(seed)
     model = init_specific_model("Burgess", img, D)

@@ -203,9 +203,9 @@ def test_latent_dim_limits_are_reported_clearly():
         init_specific_model("Burgess", (1, 32, 32), 17)
     with pytest.raises(ValueError, match="latent_dim"):
         init_specific_model("Burgess", (1, 32, 32), 0)
-    with pytest.raises(ValueError, match="btcvae: latent_dim=13"):
-        BtcvaeLoss(1000)._check_latent_dim(13)
-    BtcvaeLoss(1000)._check_latent_dim(12)
+    with pytest.raises(ValueError, match="btcvae: latent_dim=17"):
+        BtcvaeLoss(1000)._check_latent_dim(17)
+    BtcvaeLoss(1000)._check_latent_dim(16)
 
 
 def test_unknown_replay_mode_is_reported(monkeypatch):

@@ -100,7 +100,7 @@ report("fc_chain_fwd  (7 launches before)", timeit(lambda: eng.fc_chain_fwd(buf,
 report("fc_chain_bwd  (7 launches before)", timeit(lambda: eng.fc_chain_bwd(buf, eps, None, None, None, None, scal, coefd, B)), fl, 1.6e6)
 D = 10
 z = torch.randn(B, D, device=dev); mu = torch.randn(B, D, device=dev); lv = torch.randn(B, D, device=dev) * 0.5
-lw = torch.tensor([-12.0, -7.0, -6.9, 0.0], device=dev); rs = torch.empty(B, 16, device=dev); tmp = torch.empty(3 * D, B, device=dev)
+lw = torch.tensor([-12.0, -7.0, -6.9, 0.0], device=dev); rs = torch.empty(B, _lib.ROWSTATS, device=dev); tmp = torch.empty(3 * D, B, device=dev)
 coef = torch.tensor([1.0 / B, 0.5, 6.4, 1.0, 1.0, 0, 0, 0], device=dev)
 dz, dm, dl = (torch.empty(B, D, device=dev) for _ in range(3))
 report("btcvae fwd B=%d" % B, timeit(lambda: call("dvae_btcvae_fwd", ptr(z), ptr(mu), ptr(lv), B, D, 0, B, 1, ptr(lw), ptr(tmp), ptr(rs), s)), 30.0 * B * B * D, 0)
