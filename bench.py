@@ -137,7 +137,7 @@ def kernel_rooflines(B, device):
     imd, imu = torch.empty(16384, device=device), torch.empty(16384, device=device)
     cd = (_lib.ConvImageDesc * 1)()
     cd[0].w, cd[0].img_down, cd[0].img_up = ptr(w), ptr(imd), ptr(imu)
-    call("dvae_stage_weights", ctypes.addressof(cd), 1, None, 0, None, None, s)
+    call("dvae_stage_weights", ctypes.addressof(cd), 1, None, 0, None, None, None, s)
     fams = {
         "k_up32ws<16>": [("convT2 fwd", lambda: call("dvae_conv32_up", ptr(small), NH, ptr(imu), ptr(b), None, ptr(obig), B, 16, RELU, s)),
                        ("conv2 dgrad (masked)", lambda: call("dvae_conv32_up", ptr(small), NH, ptr(imu), None, ptr(big), ptr(obig), B, 16, NONE, s))],

@@ -307,13 +307,26 @@ int dvae_kl_finish(float* kl_dim, int kl_blocks, const float* coef, int D, void*
 }
 
 // ---- per-step weight staging, the tuned 32-channel kernels on pre-staged weights, the FC chain ----------------------
-int dvae_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc, float* coef,
-                       const float* coef_vals, void* stream) {
+int dvae_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc,
+                       const dvae_thin_image_desc* thin, float* coef, const float* coef_vals, void* stream) {
   DVAE_CHECK_ARG(n_conv >= 0 && n_conv <= DVAE_STAGE_MAX_CONV && n_fc >= 0 && n_fc <= DVAE_STAGE_MAX_FC);
   DVAE_CHECK_ARG((n_conv == 0 || conv) && (n_fc == 0 || fc));
   for (int q = 0; q < n_conv; ++q) DVAE_CHECK_ARG(conv[q].w);
   for (int q = 0; q < n_fc; ++q) DVAE_CHECK_ARG(fc[q].w && fc[q].N > 0 && fc[q].K > 0);
-  return launch_stage_weights(conv, n_conv, fc, n_fc, coef, coef_vals, (hipStream_t)stream);
+  if (thin) DVAE_CHECK_ARG(thin->w && (thin->C == 1 || thin->C == 3));
+  return launch_stage_weights(conv, n_conv, fc, n_fc, thin, coef, coef_vals, (hipStream_t)stream);
+}
+
+int dvae_convT3_fwd_staged(const float* x, const float* img_pairs, const float* b, const void* target, int target_is_u8,
+                           float* recon, float* g, int dist, const float* coef, float* partials, int N, int C,
+                           void* stream) {
+  DVAE_CHECK_ARG(x && img_pairs && recon && N > 0 && (C == 1 || C == 3));
+  if (target) {
+    DVAE_CHECK_ARG(g && coef && partials);
+    DVAE_CHECK_ARG(dist == DVAE_REC_BERNOULLI || dist == DVAE_REC_GAUSSIAN || dist == DVAE_REC_LAPLACE);
+  }
+  return launch_up_thin_staged(x, img_pairs, b, target, target_is_u8, recon, g, dist, coef, partials, N, C, DVAE_ACT_SIGMOID,
+                               (hipStream_t)stream);
 }
 
 int dvae_conv32_down(const float* big, const float* img_down, const float* bias, const float* mask, float* out,

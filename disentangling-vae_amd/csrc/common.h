@@ -163,8 +163,12 @@ int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s);
 int launch_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, hipStream_t s);
 int reparam_kl_blocks(int B);
 int launch_kl_finish(float* kl_dim, int kl_blocks, const float* coef, int D, hipStream_t s);
-int launch_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc, float* coef,
-                         const float* coef_vals, hipStream_t s);
+int launch_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc,
+                         const dvae_thin_image_desc* thin, float* coef, const float* coef_vals, hipStream_t s);
+__host__ __device__ int thin_pair_source(int idx, int C, int* cb);       // conv_thin.hip: record entry -> (tap, channel)
+int launch_up_thin_staged(const float* small, const float* wrec, const float* bias, const void* target, int target_u8,
+                          float* out, float* g, int dist, const float* coef, float* partials, int N, int C, int act,
+                          hipStream_t s);
 
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                           const float* coef, int B, int D, hipStream_t s);

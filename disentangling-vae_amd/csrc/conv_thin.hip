@@ -296,200 +296,209 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
   }
 }
 
-// ---- up_thin on the matrix core (round 3) ---------------------------------------------------------------------------------
-// The same layer (convT3 forward: small NHWC [N,32,32,32] -> big NCHW [N,C,64,64], bias + sigmoid, optionally the fused
-// reconstruction likelihood) on v_mfma_f32_4x4x1_16b_f32.  k_up_thin above is a VALU kernel (1536 scalar FMAs per small
-// pixel: the C = 1 / 3 output channels are too narrow for a 32x32 or 16x16 MFMA tile) and is issue-bound at 0.35 of the
-// HBM roof, with the likelihood arithmetic competing for the same VALU (profiles/r02_final_pmc_summary.md).  The 4x4x1 form
-// has 16 independent 4x4 blocks: 4 PIXELS x 4 output channels (3 used) per block = 64 small pixels per instruction and
-// contraction step, 75 % of the matrix core's rate for C = 3 -- and the VALU is left to the sigmoid / likelihood epilogue.
-//   workgroup = 4 waves, persistent over units of 4 small rows x 32 columns (8 per image); wave (rp, py) owns the two small
-//   rows 2rp, 2rp+1 (lane = pixel) and the output row parity py, both column parities px:
-//     out[2r+py][2l+px][cb] = sum_{ty,tx,cs} small[r+py-ty][l+px-tx][cs] * w[cs][cb][1-py+2ty][1-px+2tx]
-//   A operand: the lane's source pixel, four contracted channels per ds_read_b128 from the halo tile in LDS (6 distinct
-//   source pixels per lane and channel quad serve 32 MFMAs); B operand: w for cb = lane % 4, the wave's 8 taps x 32
-//   channels = 256 VGPRs per lane for the whole kernel (one wave per SIMD: the register file is this kernel's to use);
-//   D: lane (block b, cb) holds 4 pixels x 2 column parities = 8 consecutive output columns of one row: two 16-byte stores.
-// Exact fp32 (k-ordered fmaf chains, four accumulators per output -- contracted channel mod 4 -- added at the end).
-#define UM_GRID 256                // persistent: one workgroup per CU (a wave keeps 256 VGPRs of weights)
-#define UM_ROWS 6
-#define UM_COLS 34
-#define UM_TILE (UM_ROWS * UM_COLS * 32)
+// ---- up_thin on packed fp32 FMAs (round 3) ---------------------------------------------------------------------------
+// Same layer, same decomposition (thread = one small pixel -> its 2 x 2 x C outputs, weights wave-uniform in SGPRs,
+// swizzled halo tile in LDS), but the 16 C multiply-adds per contracted channel are issued as v_pk_fma_f32: two fp32 FMAs
+// per lane and instruction with the activation broadcast to both halves by op_sel and the two weights an SGPR pair.  k_up_thin
+// is bound by VALU issue (48 v_fma_f32 per channel at C = 3 next to the likelihood's arithmetic: 0.35 of the HBM roof,
+// profiles/r02_final_pmc_summary.md); paired:
+//   * channels (cb0, cb1) of the same output and tap share the activation                         -> 16 packed FMAs,
+//   * the remaining channel plane (cb2; the only one for C = 1): two taps that read the SAME source pixel feed two different
+//     output classes -- the own pixel 4 taps (2 pairs), the 4 edge neighbours 2 taps each (4 pairs), the 4 corner
+//     neighbours one tap each (4 scalar FMAs)                                                    -> 6 packed + 4 scalar,
+// 26 instructions per channel instead of 48 (10 instead of 16 for C = 1).  The pairs' weights must sit in adjacent SGPRs, so
+// the layer's weights are read from a per-channel record in pair order (DVAE_THIN_PAIR_FLOATS(C) floats per contracted
+// channel) that dvae_stage_weights writes once per step.  Every output is still a fixed-order fmaf chain per accumulator;
+// the cb2 plane adds three partial accumulators (row pairs, column pairs, corners) at the end.
+//   record of channel cs, C = 3:  [2 (4 cls + t) + {0,1}] = w[cs][{0,1}][kh][kw] with cls = 2 py + px, t = 2 ty + tx,
+//                                  kh = 1 - py + 2 ty, kw = 1 - px + 2 tx;  then the 16 floats of plane cb2 (C = 1: only these,
+//                                  of plane cb0) in the tap order of THIN_PLANE_TAPS below.
+__device__ __constant__ const int THIN_PLANE_TAPS[16] = {5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15};
+// (kh*4+kw): H pairs (cls0,cls1)/(cls2,cls3) from the own pixel: (1,1),(1,2) | (2,1),(2,2); from the pixel above / below:
+// (3,1),(3,2) | (0,1),(0,2); V pairs (cls0,cls2) from the left: (1,3),(2,3); (cls1,cls3) from the right: (1,0),(2,0);
+// corners: (0,0) -> cls3, (0,3) -> cls2, (3,0) -> cls1, (3,3) -> cls0
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int C, bool FUSE, typename TT = float>
-__global__ __launch_bounds__(256) void k_up_thin_mfma(const float* __restrict__ small, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, float* __restrict__ out, int N, int act,
-                                                      int n_units, const TT* __restrict__ target, float* __restrict__ g,
-                                                      int dist, const float* __restrict__ coef, float* __restrict__ partials) {
-  __shared__ __attribute__((aligned(16))) float st[2][UM_TILE];
-  __shared__ float wsh[32 * C * 16];
-  __shared__ float redl[4];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rp = wv >> 1, py = wv & 1;
-  const int cb = lane & 3;
+__global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ small, const float* __restrict__ wrec,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                    int act, int n_units, const TT* __restrict__ target,
+                                                    float* __restrict__ g, int dist, const float* __restrict__ coef,
+                                                    float* __restrict__ partials) {
+  constexpr int REC = C == 3 ? 48 : 16;             // DVAE_THIN_PAIR_FLOATS(C)
+  constexpr int PB = C == 3 ? 32 : 0;               // offset of the single-plane part in a record
+  constexpr int CS = C - 1;                         // the plane handled by the tap-pair scheme
+  __shared__ __attribute__((aligned(16))) float st[UT_ROWS * UT_COLS * 32];
+  __shared__ float redl[2];
+  const int tid = threadIdx.x;
+  const int m = tid >> 5, l = tid & 31;
   const float gs = FUSE ? coef[DVAE_C_INV_B] : 0.f;
-  // ---- staging slots of this thread: 16-byte chunk `ch` of tile pixels (row, col), constant over the units
-  constexpr int NSLOT = (UM_ROWS * UM_COLS * 8 + 255) / 256;
-  int s_lds[NSLOT], s_gofs[NSLOT], s_row[NSLOT];
-#pragma unroll
-  for (int k = 0; k < NSLOT; ++k) {
-    const int sidx = tid + 256 * k;
-    s_lds[k] = -1; s_gofs[k] = 0; s_row[k] = -100;
-    if (sidx < UM_ROWS * UM_COLS * 8) {
-      const int ch = sidx & 7, pix = sidx >> 3;
-      const int col = pix % UM_COLS, row = pix / UM_COLS;
-      s_lds[k] = (row * UM_COLS + col) * 32 + ((ch ^ (col & 7)) << 2);
-      const bool inside = col >= 1 && col <= 32;
-      s_gofs[k] = ((row - 1) * 32 + (col - 1)) * 32 + ch * 4;
-      s_row[k] = inside ? row : -100;                    // -100: halo column, always zero
-    }
-  }
-  f32x4 pf[NSLOT];
-  auto load_tile = [&](int u) {
-    const int n = u >> 3, sy0 = (u & 7) * 4;
-    const float* base = small + (((long)n * 32 + sy0) * 32) * 32;
-#pragma unroll
-    for (int k = 0; k < NSLOT; ++k) {
-      const int sy = sy0 - 1 + s_row[k];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (s_row[k] >= 0 && sy >= 0 && sy < 32) v = *reinterpret_cast<const f32x4*>(base + s_gofs[k]);
-      pf[k] = v;
-    }
-  };
-  auto store_tile = [&](float* t) {
-#pragma unroll
-    for (int k = 0; k < NSLOT; ++k)
-      if (s_lds[k] >= 0) *reinterpret_cast<f32x4*>(t + s_lds[k]) = pf[k];
-  };
-  int unit = blockIdx.x;
-  if (unit < n_units) load_tile(unit);
-  for (int e = tid; e < 32 * C * 16; e += 256) wsh[e] = w[e];
-  __syncthreads();
-  // B operands: Bw[ty][kw][cs] = w[cs][cb][1 - py + 2 ty][kw] for cb = lane % 4 (0 beyond C)
-  float Bw[2][4][32];
-#pragma unroll
-  for (int ty = 0; ty < 2; ++ty)
-#pragma unroll
-    for (int kw = 0; kw < 4; ++kw)
-#pragma unroll
-      for (int cs = 0; cs < 32; ++cs)
-        Bw[ty][kw][cs] = cb < C ? wsh[(cs * C + (cb < C ? cb : 0)) * 16 + (1 - py + 2 * ty) * 4 + kw] : 0.f;
-  const float bv = (bias && cb < C) ? bias[cb] : 0.f;
-  // A operand addresses: pixel = lane: small row 2rp + lane/32, column lane%32; source (row + py - ty, col + dc), dc in -1..1
-  const int rr = 2 * rp + (lane >> 5), l = lane & 31;
-  int aoff[2][3], asw[3];
-#pragma unroll
-  for (int dc = 0; dc < 3; ++dc) {
-    const int tcol = l + dc;                             // (l + 1) + (dc - 1)
-    asw[dc] = tcol & 7;
-#pragma unroll
-    for (int ty = 0; ty < 2; ++ty) aoff[ty][dc] = ((rr + 1 + py - ty) * UM_COLS + tcol) * 32;
-  }
-  if (unit < n_units) store_tile(st[0]);
-  __syncthreads();
-  if (unit + (int)gridDim.x < n_units) load_tile(unit + gridDim.x);
   float lsum = 0.f;
-  int buf = 0;
-  for (; unit < n_units; unit += gridDim.x) {
-    const float* t = st[buf];
-    // lane (block b = lane/4, cb): pixels 4b .. 4b+3 of the wave's two rows x both column parities = output columns
-    // 8 (b%8) .. +7 of row 2 (sy0 + 2rp + b/8) + py of channel cb
-    const int b_ = lane >> 2;
-    const long o = ((((long)(unit >> 3) * C + (cb < C ? cb : 0)) * 64) + 2 * ((unit & 7) * 4 + 2 * rp + (b_ >> 3)) + py) * 64 + 8 * (b_ & 7);
-    // the likelihood target of this unit: requested now, consumed after the MFMA phase
-    f32x4 tg0 = {0.f, 0.f, 0.f, 0.f}, tg1 = {0.f, 0.f, 0.f, 0.f};
-    uint2 tgb = {0u, 0u};
-    if (FUSE && cb < C) {
-      if constexpr (sizeof(TT) == 4) {
-        tg0 = *reinterpret_cast<const f32x4*>(target + o);
-        tg1 = *reinterpret_cast<const f32x4*>(target + o + 4);
-      } else {
-        tgb = *reinterpret_cast<const uint2*>(target + o);
-      }
-    }
-    f32x4 acc[2][4];                                     // [px][channel % 4]: an accumulator is re-used every 8th MFMA
-#pragma unroll
-    for (int px = 0; px < 2; ++px)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[px][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 8 steps of 4 contracted channels: 6 operand reads (2 source rows x 3 source columns) + 32 MFMAs each.  The reads of
-    // step q+1 are issued before the MFMAs of step q (register ping-pong, order pinned by sched_group_barrier): with one
-    // wave per SIMD nothing else hides the LDS latency
-    f32x4 x[2][2][3];
-    auto rd = [&](int q, int slot) {
-#pragma unroll
-      for (int ty = 0; ty < 2; ++ty)
-#pragma unroll
-        for (int dc = 0; dc < 3; ++dc)
-          x[slot][ty][dc] = *reinterpret_cast<const f32x4*>(t + aoff[ty][dc] + ((q ^ asw[dc]) << 2));
-    };
-    rd(0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int cur = q & 1;
-      if (q + 1 < 8) rd(q + 1, cur ^ 1);
-#pragma unroll
-      for (int ty = 0; ty < 2; ++ty)
-#pragma unroll
-        for (int px = 0; px < 2; ++px)
-#pragma unroll
-          for (int tx = 0; tx < 2; ++tx) {
-            const int kw = 1 - px + 2 * tx, dc = 1 + px - tx;          // source column l + px - tx
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[px][j] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[cur][ty][dc][j], Bw[ty][kw][4 * q + j], acc[px][j], 0, 0, 0);
-          }
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // 6 DS reads (next step)
-      __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);   // 32 MFMAs (this step)
-    }
-    // hand over: the next unit's tile (prefetched during the MFMAs) goes to the other buffer
-    if (unit + (int)gridDim.x < n_units) store_tile(st[buf ^ 1]);
+  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const int n = unit >> 3, sy0 = (unit & 7) * 4;
     __syncthreads();
-    if (unit + 2 * (int)gridDim.x < n_units) load_tile(unit + 2 * gridDim.x);
-    buf ^= 1;
-    // epilogue
-    if (cb < C) {
-      const f32x4 s0 = (acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]), s1 = (acc[1][0] + acc[1][1]) + (acc[1][2] + acc[1][3]);
-      float v[8];
+    {
+      // 16 columns per pass, 8 chunks of 16 bytes per pixel; all loads first (unconditional, clamped
+      // address), then the swizzled LDS stores
+      const int chunk = tid & 7, cg = tid >> 3;
+      f32x4 tv[UT_ROWS * 3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[2 * e] = s0[e] + bv; v[2 * e + 1] = s1[e] + bv; }
+      for (int row = 0; row < UT_ROWS; ++row) {
+        const int sy = sy0 - 1 + row;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (act == DVAE_ACT_SIGMOID) v[e] = 1.f / (1.f + expf(-v[e]));
-        else if (act == DVAE_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        for (int cp = 0; cp < 3; ++cp) {
+          const int col = cp * 16 + cg;
+          const int sx = col - 1;
+          const bool ok = n < N && col < UT_COLS && sy >= 0 && sy < 32 && sx >= 0 && sx < 32;
+          const long off = ok ? (((((long)n * 32 + sy) * 32) + sx) * 32 + chunk * 4) : 0;
+          f32x4 v = *reinterpret_cast<const f32x4*>(small + off);
+          if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          tv[row * 3 + cp] = v;
+        }
       }
-      *reinterpret_cast<f32x4*>(out + o) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(out + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      if (FUSE) {
-        float xt[8];
-        if constexpr (sizeof(TT) == 4) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { xt[e] = tg0[e]; xt[4 + e] = tg1[e]; }
-        } else {
+      for (int row = 0; row < UT_ROWS; ++row)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            xt[e] = to_unit((uint8_t)((tgb.x >> (8 * e)) & 0xff));
-            xt[4 + e] = to_unit((uint8_t)((tgb.y >> (8 * e)) & 0xff));
+        for (int cp = 0; cp < 3; ++cp) {
+          const int col = cp * 16 + cg;
+          if (col < UT_COLS)
+            *reinterpret_cast<f32x4*>(st + (row * UT_COLS + col) * 32 + ((chunk ^ ((col >> 1) & 7)) << 2)) = tv[row * 3 + cp];
+        }
+    }
+    __syncthreads();
+    f32x2 accA[4];                                   // (cb0, cb1) of class cls                     (C = 3)
+    f32x2 h01 = {0.f, 0.f}, h23 = {0.f, 0.f};        // plane CS: classes (0,1) / (2,3), sources in the own column
+    f32x2 v02 = {0.f, 0.f}, v13 = {0.f, 0.f};        // plane CS: classes (0,2) / (1,3), sources left / right
+    float sc[4] = {0.f, 0.f, 0.f, 0.f};              // plane CS: corner sources
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accA[c] = f32x2{0.f, 0.f};
+
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {   // 4 contracted channels per iteration
+      f32x4 x[3][3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int row = m + dy, col = l + dx;  // (m + (dy-1)) + 1
+          x[dy][dx] = *reinterpret_cast<const f32x4*>(st + (row * UT_COLS + col) * 32 + ((q ^ ((col >> 1) & 7)) << 2));
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* wp = wrec + (q * 4 + j) * REC;              // wave-uniform -> scalar loads, pairs in adjacent SGPRs
+        const f32x2* wp2 = reinterpret_cast<const f32x2*>(wp);
+        if (C == 3) {
+#pragma unroll
+          for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int ty = t >> 1, tx = t & 1;
+              const float xs = x[py - ty + 1][px - tx + 1][j];
+              accA[cls] = __builtin_elementwise_fma(f32x2{xs, xs}, wp2[cls * 4 + t], accA[cls]);
+            }
           }
         }
-        float gl[8], gr;
+        const f32x2* wb2 = reinterpret_cast<const f32x2*>(wp + PB);
+        const float xc = x[1][1][j], xu = x[0][1][j], xd = x[2][1][j], xl = x[1][0][j], xr = x[1][2][j];
+        h01 = __builtin_elementwise_fma(f32x2{xc, xc}, wb2[0], h01);
+        h23 = __builtin_elementwise_fma(f32x2{xc, xc}, wb2[1], h23);
+        h01 = __builtin_elementwise_fma(f32x2{xu, xu}, wb2[2], h01);
+        h23 = __builtin_elementwise_fma(f32x2{xd, xd}, wb2[3], h23);
+        v02 = __builtin_elementwise_fma(f32x2{xl, xl}, wb2[4], v02);
+        v13 = __builtin_elementwise_fma(f32x2{xr, xr}, wb2[5], v13);
+        sc[3] = fmaf(x[2][2][j], wp[PB + 12], sc[3]);
+        sc[2] = fmaf(x[2][0][j], wp[PB + 13], sc[2]);
+        sc[1] = fmaf(x[0][2][j], wp[PB + 14], sc[1]);
+        sc[0] = fmaf(x[0][0][j], wp[PB + 15], sc[0]);
+      }
+    }
+    float acc[4][C];
+    {
+      const float hh[4] = {h01[0], h01[1], h23[0], h23[1]}, vv[4] = {v02[0], v13[0], v02[1], v13[1]};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { lsum += recon_elem(v[e], xt[e], dist, &gl[e], &gr); gl[e] *= gs; }
-        *reinterpret_cast<f32x4*>(g + o) = f32x4{gl[0], gl[1], gl[2], gl[3]};
-        *reinterpret_cast<f32x4*>(g + o + 4) = f32x4{gl[4], gl[5], gl[6], gl[7]};
+      for (int cls = 0; cls < 4; ++cls) {
+        if (C == 3) { acc[cls][0] = accA[cls][0]; acc[cls][1] = accA[cls][1]; }
+        acc[cls][CS] = (hh[cls] + vv[cls]) + sc[cls];
+      }
+    }
+    if (n < N) {
+      const int sy = sy0 + m;
+#pragma unroll
+      for (int cb = 0; cb < C; ++cb) {
+        const float bv = bias ? bias[cb] : 0.f;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          float v0 = acc[py * 2 + 0][cb] + bv, v1 = acc[py * 2 + 1][cb] + bv;
+          if (act == DVAE_ACT_SIGMOID) { v0 = 1.f / (1.f + expf(-v0)); v1 = 1.f / (1.f + expf(-v1)); }
+          else if (act == DVAE_ACT_RELU) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+          const long o = ((((long)n * C + cb) * 64) + 2 * sy + py) * 64 + 2 * l;
+          *reinterpret_cast<float2*>(out + o) = make_float2(v0, v1);
+          if (FUSE) {
+            float xt0, xt1;
+            if constexpr (sizeof(TT) == 4) {
+              const float2 xt = *reinterpret_cast<const float2*>(target + o);
+              xt0 = xt.x; xt1 = xt.y;
+            } else {
+              const uchar2 xt = *reinterpret_cast<const uchar2*>(target + o);
+              xt0 = to_unit(xt.x); xt1 = to_unit(xt.y);
+            }
+            float gl0, gl1, gr;
+            lsum += recon_elem(v0, xt0, dist, &gl0, &gr);
+            lsum += recon_elem(v1, xt1, dist, &gl1, &gr);
+            *reinterpret_cast<float2*>(g + o) = make_float2(gs * gl0, gs * gl1);
+          }
+        }
       }
     }
   }
   if (FUSE) {
     const float v = wave_sum(lsum);
-    if (lane == 0) redl[wv] = v;
+    if ((tid & 63) == 0) redl[tid >> 6] = v;
     __syncthreads();
-    if (tid == 0) partials[blockIdx.x] = (redl[0] + redl[1]) + (redl[2] + redl[3]);
+    if (tid == 0) partials[blockIdx.x] = redl[0] + redl[1];
     // unused partial slots must read as zero
-    for (int k = gridDim.x + blockIdx.x * 256 + tid; k < DVAE_REC_NPART; k += gridDim.x * 256) partials[k] = 0.f;
+    for (int k = gridDim.x + blockIdx.x * 128 + tid; k < DVAE_REC_NPART; k += gridDim.x * 128) partials[k] = 0.f;
   }
 }
+
+// float index of record entry `idx` of contracted channel cs in w[cs][cb][16] (the staging kernel's gather)
+__host__ __device__ int thin_pair_source(int idx, int C, int* cb) {
+  const int taps[16] = {5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15};
+  if (C == 3 && idx < 32) {
+    const int a = idx >> 1, cls = a >> 2, t = a & 3;
+    const int py = cls >> 1, px = cls & 1, ty = t >> 1, tx = t & 1;
+    *cb = idx & 1;
+    return (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+  }
+  *cb = C - 1;
+  return taps[C == 3 ? idx - 32 : idx];
+}
+
+// convT3 forward on the staged pair records; target == NULL: no likelihood.  Returns 1 if the shape is not covered.
+int launch_up_thin_staged(const float* small, const float* wrec, const float* bias, const void* target, int target_u8,
+                          float* out, float* g, int dist, const float* coef, float* partials, int N, int C, int act,
+                          hipStream_t s) {
+  if (C != 1 && C != 3) return 1;
+  const int n_units = N * 8;
+  const int grid = n_units < 1536 ? n_units : 1536;
+#define UP_PK(CC, FF, TT_) hipLaunchKernelGGL((k_up_thin_pk<CC, FF, TT_>), dim3(grid), dim3(128), 0, s, small, wrec, bias, out, N, act, \
+                                             n_units, (const TT_*)target, g, dist, coef, partials)
+  if (!target) { if (C == 1) UP_PK(1, false, float); else UP_PK(3, false, float); }
+  else if (target_u8) { if (C == 1) UP_PK(1, true, uint8_t); else UP_PK(3, true, uint8_t); }
+  else { if (C == 1) UP_PK(1, true, float); else UP_PK(3, true, float); }
+#undef UP_PK
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+// (Round 3 measured a v_mfma_f32_4x4x1_16b_f32 formulation of this layer -- 16 blocks of 4 pixels x 4 output channels, the
+// wave's 256 weights in registers, operand reads one step ahead: parity green, but 103.6 us without / 144.9 us with the
+// likelihood at B = 1024 against 73 / 98 us here (profiles/r03_v4_kbench.txt).  The 4x4x1 form issues in 16 cycles, not 8:
+// 32 FLOP/clk/SIMD, half the rate of the 16x16x4 / 32x32x2 forms, and 3 of its 4 columns carry data -- 4096 matrix-core
+// cycles per 128 output pixels x 2 waves, no better than the VALU's 6144 x 2 waves spread over more resident waves.  Not
+// shipped; git history: k_up_thin_mfma.)
 
 // ---- wgrad_thin ----------------------------------------------------------------------------
 template <int C, typename TB = float>
@@ -621,16 +630,9 @@ int launch_down_thin(const ConvArgs& a, hipStream_t s) {
 int launch_up_thin(const ConvArgs& a, hipStream_t s) {
   if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
   const int n_units = a.N * 8;
-  static const bool valu = env_on("DVAE_UP_THIN_VALU");     // debug builds: the round-1/2 VALU kernel (A/B)
-  if (valu) {
-    const int grid = n_units;        // one unit per workgroup: the hardware dispatcher balances the load
-    if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
-    else hipLaunchKernelGGL((k_up_thin<3, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
-  } else {
-    const int grid = n_units < UM_GRID ? n_units : UM_GRID;
-    if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin_mfma<1, false>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
-    else hipLaunchKernelGGL((k_up_thin_mfma<3, false>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
-  }
+  const int grid = n_units;          // one unit per workgroup: the hardware dispatcher balances the load
+  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+  else hipLaunchKernelGGL((k_up_thin<3, false>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, a.act, n_units, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -639,17 +641,10 @@ int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int d
                          float* partials, hipStream_t s) {
   if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
   const int n_units = a.N * 8;
-  static const bool valu = env_on("DVAE_UP_THIN_VALU");     // debug builds: the round-1/2 VALU kernel (A/B)
-  if (valu) {
-    // persistent (one loss partial per workgroup): 6 workgroups of 128 threads fit a CU (26 KB LDS each)
-    const int grid = n_units < 1536 ? n_units : 1536;
-    if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
-    else hipLaunchKernelGGL((k_up_thin<3, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
-  } else {
-    const int grid = n_units < UM_GRID ? n_units : UM_GRID;
-    if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin_mfma<1, true>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
-    else hipLaunchKernelGGL((k_up_thin_mfma<3, true>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
-  }
+  // persistent (one loss partial per workgroup): 6 workgroups of 128 threads fit a CU (26 KB LDS each)
+  const int grid = n_units < 1536 ? n_units : 1536;
+  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  else hipLaunchKernelGGL((k_up_thin<3, true>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -669,9 +664,9 @@ int launch_up_thin_recon_u8(const ConvArgs& a, const uint8_t* target, float* g, 
                             float* partials, hipStream_t s) {
   if (!thin_applicable(a) || a.small_layout != DVAE_NHWC || a.out_layout != DVAE_NCHW || a.mask) return 1;
   const int n_units = a.N * 8;
-  const int grid = n_units < UM_GRID ? n_units : UM_GRID;
-  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin_mfma<1, true, uint8_t>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
-  else hipLaunchKernelGGL((k_up_thin_mfma<3, true, uint8_t>), dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  const int grid = n_units < 1536 ? n_units : 1536;
+  if (a.Cb == 1) hipLaunchKernelGGL((k_up_thin<1, true, uint8_t>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
+  else hipLaunchKernelGGL((k_up_thin<3, true, uint8_t>), dim3(grid), dim3(128), 0, s, a.small, a.w, a.bias, a.out, a.N, DVAE_ACT_SIGMOID, n_units, target, g, dist, coef, partials);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -228,7 +228,11 @@ static int launch_wgrad_ws_t(const float* big, const float* small, float* dw, fl
                              float* ws, hipStream_t s) {
   using W = WGeo<HS>;
   const int n_units = (int)(((long)N * HS * HS) / 64);
-  const int grid = n_units < WGW_MAX_BLOCKS ? n_units : WGW_MAX_BLOCKS;
+  int grid = n_units < WGW_MAX_BLOCKS ? n_units : WGW_MAX_BLOCKS;
+  {
+    static const int cap = env_int("DVAE_WGRAD_GRID", WGW_MAX_BLOCKS);   // debug builds: A/B of the persistent grid size
+    if (cap > 0 && cap < grid) grid = cap;
+  }
   const size_t lds = (size_t)2 * W::BUF_FLOATS * sizeof(float);
   static DeviceOnce attr;
   if (attr.first()) { (void)hipFuncSetAttribute((const void*)k_wgrad32ws<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }

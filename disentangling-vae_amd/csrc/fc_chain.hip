@@ -11,13 +11,15 @@
 // chain with the activations in LDS; nothing but the weights is read from memory between the first and the last layer, and
 // the weight streams do not depend on the data, so they are prefetched across layer boundaries (8 chunks in flight per
 // wave).  A layer is  y[8][O] = x[8][C] W  on v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks per instruction =
-// 4 batch rows x 64 output columns per wave, one contraction step; two row groups share the B operand.  The same 64
-// FLOP/clk/SIMD as the large MFMA shapes but with M = 4, so 8 rows waste nothing (a 16x16x4 tile would idle half of the
-// matrix core, a 32x32x2 tile three quarters).  B operand: the lane's output column, four contraction steps per 16-byte
-// load from the k-chunked images of dvae_stage_weights ([C/4][O][4]: a wave's load = 1 KB contiguous).  A operand: one
-// broadcast ds_read_b128 per row group and 4 steps.  Per 4 steps a wave issues 1 global load, 2 LDS reads and 8 MFMAs
-// (64 matrix-core cycles per KB of weights): the launch is bound by the CU's L2 -> register bandwidth (1.6 MB of weights
-// per workgroup per direction), ~10-15 us at any batch size up to 2048 rows (256 workgroups).
+// 4 batch rows x 64 output columns per wave, one contraction step; two row groups share the B operand.  The 4x4x1 form
+// issues in 16 cycles (measured: profiles/r03_v2_fcc_ab.txt, r03_v4_kbench.txt) = 32 FLOP/clk/SIMD, half the rate of the
+// 16x16x4 / 32x32x2 forms -- but with M = 4 nothing is wasted on 8 rows, where a 16x16x4 tile idles half of the matrix
+// core (same net rate) and a 32x32x2 tile three quarters.  B operand: the lane's output column, four contraction steps per
+// 16-byte load from the k-chunked images of dvae_stage_weights ([C/4][O][4]: a wave's load = 1 KB contiguous).  A operand:
+// one broadcast ds_read_b128 per row group and 4 steps.  Bounds per workgroup and direction: 12.8 k MFMAs on 4 SIMDs =
+// 51 k cycles = 21 us of matrix core, and 1.6 MB of weights at the ~65-90 GB/s one CU draws from L2 = 18-24 us: the launch
+// takes 24-28 us at any batch size up to 2048 rows (256 workgroups), against 50 / 67 us for the 7 + 7 launches it replaces
+// at 128 rows.  Fewer rows per workgroup would only move the bound from the matrix core to the weight stream.
 // Exact fp32 (k-ordered fmaf chains per accumulator; two accumulators per output, even / odd steps, summed at the end).
 #include "common.h"
 

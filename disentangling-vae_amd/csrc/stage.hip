@@ -8,6 +8,8 @@
 //   * the six fully-connected layers (encoders.py:63-67, decoders.py:53-55): k-chunked images [K/4][N][4] (forward, contract
 //     over K) and [N/4][K][4] (input gradient, contract over N) -- the operand streams of the fused FC-chain kernels
 //     (fc_chain.hip): one coalesced 16-byte load per lane = four contraction steps of the lane's output column;
+//   * the last decoder layer (decoders.py:65): its weights as per-channel records of operand PAIRS for the packed-FMA
+//     forward kernel (k_up_thin_pk, conv_thin.hip);
 //   * optionally the eight loss coefficients of the step (dvae_set_coef folded in: one launch less).
 // Output-driven: every thread produces ONE 16-byte chunk of one image (coalesced stores, gathered 4-byte reads of
 // parameters that sit in L2); 1.0 M floats per step, ~3 us.
@@ -15,8 +17,8 @@
 
 namespace dvae {
 
-#define STG_MAX_SEG 28        // 2 images x (DVAE_STAGE_MAX_CONV + DVAE_STAGE_MAX_FC)
-enum { SEG_CONV_DOWN = 0, SEG_CONV_UP = 1, SEG_FC_FWD = 2, SEG_FC_BWD = 3 };
+#define STG_MAX_SEG 29        // 2 images x (DVAE_STAGE_MAX_CONV + DVAE_STAGE_MAX_FC) + the thin layer's pair records
+enum { SEG_CONV_DOWN = 0, SEG_CONV_UP = 1, SEG_FC_FWD = 2, SEG_FC_BWD = 3, SEG_THIN_PAIRS = 4 };
 
 struct StageSeg {
   const float* w;
@@ -68,6 +70,18 @@ __global__ __launch_bounds__(256) void k_stage_weights(StageTable t) {
       }
     }
     reinterpret_cast<f32x4*>(g.img)[c] = v;
+  } else if (g.kind == SEG_THIN_PAIRS) {
+    // per contracted channel cs a record of REC floats in the pair order of k_up_thin_pk (conv_thin.hip); g.N = C
+    const int REC = DVAE_THIN_PAIR_FLOATS(g.N);
+    if (c >= 32 * REC / 4) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = (int)c * 4 + r, cs = o / REC, idx = o % REC;
+      int cb;
+      const int tap = thin_pair_source(idx, g.N, &cb);
+      v[r] = g.w[(cs * g.N + cb) * 16 + tap];
+    }
+    reinterpret_cast<f32x4*>(g.img)[c] = v;
   } else {
     // [ceil(N/4)][K][4]: chunk (n4, k) = w[4*n4 .. 4*n4+3][k] (zero beyond N)
     const long nch = (long)((g.N + 3) >> 2) * g.K;
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(256) void k_stage_weights(StageTable t) {
 }
 
 int launch_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc,
-                         float* coef, const float* coef_vals, hipStream_t s) {
+                         const dvae_thin_image_desc* thin, float* coef, const float* coef_vals, hipStream_t s) {
   StageTable t;
   memset(&t, 0, sizeof(t));
   int n = 0, wg = 0;
@@ -101,6 +115,7 @@ int launch_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dva
     add(fc[q].w, fc[q].img_fwd, SEG_FC_FWD, fc[q].N, fc[q].K, (long)((fc[q].K + 3) / 4) * fc[q].N);
     add(fc[q].w, fc[q].img_bwd, SEG_FC_BWD, fc[q].N, fc[q].K, (long)((fc[q].N + 3) / 4) * fc[q].K);
   }
+  if (thin) add(thin->w, thin->img_pairs, SEG_THIN_PAIRS, thin->C, 32, 32 * DVAE_THIN_PAIR_FLOATS(thin->C) / 4);
   t.n = n;
   t.coef_dst = (coef && coef_vals) ? coef : nullptr;
   if (t.coef_dst) for (int i = 0; i < 8; ++i) t.coef[i] = coef_vals[i];

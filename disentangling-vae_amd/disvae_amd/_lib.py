@@ -38,7 +38,8 @@ SIGNATURES = {
     "dvae_convT4s2_wgrad": [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "dvae_convT4s2_sigmoid_recon_fwd": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "dvae_conv_wgrad_ws_floats": [],
-    "dvae_stage_weights": [_p, _i, _p, _i, _p, _p, _p],
+    "dvae_stage_weights": [_p, _i, _p, _i, _p, _p, _p, _p],
+    "dvae_convT3_fwd_staged": [_p, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p],
     "dvae_conv32_down": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dvae_conv32_up": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "dvae_fc_chain_fwd": [_p, _p],
@@ -104,6 +105,16 @@ class ConvImageDesc(ctypes.Structure):
 class FcImageDesc(ctypes.Structure):
     """dvae_fc_image_desc (include/dvae_hip.h)."""
     _fields_ = [("w", _p), ("img_fwd", _p), ("img_bwd", _p), ("N", _i), ("K", _i)]
+
+
+class ThinImageDesc(ctypes.Structure):
+    """dvae_thin_image_desc (include/dvae_hip.h)."""
+    _fields_ = [("w", _p), ("img_pairs", _p), ("C", _i)]
+
+
+def thin_pair_floats(C):
+    """DVAE_THIN_PAIR_FLOATS(C)."""
+    return 48 if C == 3 else 16
 
 
 class FcChainFwdArgs(ctypes.Structure):

@@ -170,6 +170,12 @@ class _Images:
             off += (K + 3) // 4 * N * 4
             sizes[(name, "bwd")] = off
             off += (N + 3) // 4 * K * 4
+        # the last decoder layer (C = 1 / 3 output channels at 64x64): operand-pair records of the packed-FMA forward kernel
+        c = eng.img_size[0]
+        self.thin_C = c if (eng.is64 and c in (1, 3)) else 0
+        if self.thin_C:
+            sizes[("decoder.convT3", "pairs")] = off
+            off += 32 * _lib.thin_pair_floats(c)
         self.buf = torch.empty(off, dtype=torch.float32, device=arena.flat.device)
         base = self.buf.data_ptr()
         self.ptrs = {k: base + 4 * o for k, o in sizes.items()}
@@ -181,6 +187,11 @@ class _Images:
             N, K = arena.shapes[name + ".weight"]
             d.w, d.img_fwd, d.img_bwd, d.N, d.K = (ptr(arena.view(name + ".weight")), self.ptrs[(name, "fwd")],
                                                    self.ptrs[(name, "bwd")], N, K)
+        self.thin_desc = None
+        if self.thin_C:
+            self.thin_desc = _lib.ThinImageDesc()
+            self.thin_desc.w, self.thin_desc.img_pairs, self.thin_desc.C = (ptr(arena.view("decoder.convT3.weight")),
+                                                                            self.ptrs[("decoder.convT3", "pairs")], self.thin_C)
         self.coef_vals = (ctypes.c_float * 8)()
 
 
@@ -264,7 +275,7 @@ class VAEEngine:
                 im.coef_vals[i] = v
             cv = ctypes.addressof(im.coef_vals)
         call("dvae_stage_weights", ctypes.addressof(im.conv_descs), len(im.conv_descs), ctypes.addressof(im.fc_descs),
-             len(im.fc_descs), ptr(coef), cv, _stream())
+             len(im.fc_descs), None if im.thin_desc is None else ctypes.addressof(im.thin_desc), ptr(coef), cv, _stream())
 
     def _img(self, layer, kind):
         return self._images.ptrs[(layer, kind)]
@@ -446,7 +457,13 @@ class VAEEngine:
                  B, h, ACT_RELU, s)
             src, src_layout, h = act, NHWC, h * 2
         c = self.img_size[0]
-        if fuse_loss is None:
+        if self._images.thin_C:
+            # tuned geometry: the packed-FMA kernel on the staged pair records, with or without the fused likelihood
+            target, dist_code, coef, partials = fuse_loss if fuse_loss is not None else (None, 0, None, None)
+            call("dvae_convT3_fwd_staged", ptr(src), self._img("decoder.convT3", "pairs"), ptr(self.p("decoder.convT3.bias")),
+                 ptr(target), int(target is not None and target.dtype == torch.uint8), ptr(buf.recon),
+                 None if target is None else ptr(buf.g_logit), dist_code, ptr(coef), ptr(partials), B, c, s)
+        elif fuse_loss is None:
             call("dvae_convT4s2_fwd", ptr(src), NHWC, ptr(self.p("decoder.convT3.weight")),
                  ptr(self.p("decoder.convT3.bias")), ptr(buf.recon), NCHW, B, HID, h, h, c, ACT_SIGMOID, s)
         else:

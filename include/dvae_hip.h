@@ -92,9 +92,10 @@ size_t dvae_conv_wgrad_ws_floats(void);
  * parameters only change in optimizer.step(), training.py:158), optionally together with the step's loss coefficients
  * (= dvae_set_coef).  Images: conv img_down / img_up = 16384 floats each (wl[tap][kc/4][n][kc%4], kc = cb / cs);
  * fc img_fwd = [ceil(K/4)][N][4] floats, img_bwd = [ceil(N/4)][K][4] floats (zero padded).  Any image pointer may be NULL
- * (skipped).  `conv`, `fc`, `coef_vals` are HOST arrays read during the call.                                        */
+ * (skipped).  `conv`, `fc`, `thin`, `coef_vals` are HOST arrays / structs read during the call.                         */
 #define DVAE_STAGE_MAX_CONV 6
 #define DVAE_STAGE_MAX_FC 8
+#define DVAE_THIN_PAIR_FLOATS(C) ((C) == 3 ? 48 : 16)   /* per contracted channel: see conv_thin.hip, k_up_thin_pk */
 typedef struct {
   const float* w;       /* Conv2d [32,32,4,4] or ConvTranspose2d [32,32,4,4] weight = w[cs][cb][kh][kw] */
   float* img_down;      /* consumed by dvae_conv32_down */
@@ -106,9 +107,22 @@ typedef struct {
   float* img_bwd;       /* input-gradient operand stream of dvae_fc_chain_bwd */
   int N, K;
 } dvae_fc_image_desc;
+typedef struct {
+  const float* w;       /* the last decoder layer's ConvTranspose2d weight [32,C,4,4] (decoders.py:65), C in {1, 3} */
+  float* img_pairs;     /* 32 * DVAE_THIN_PAIR_FLOATS(C) floats: operand pairs of the packed-FMA forward kernel */
+  int C;
+} dvae_thin_image_desc;
 int dvae_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc,
+                       const dvae_thin_image_desc* thin /* may be NULL */,
                        float* coef /* device, may be NULL */, const float* coef_vals /* host float[8], may be NULL */,
                        void* stream);
+/* The last decoder layer on its staged pair records: recon[N,C,64,64] (NCHW) = sigmoid(convT(x[N,32,32,32] NHWC) + b)
+ * (decoders.py:82); with target != NULL (fp32 [N,C,64,64], or uint8 pixels when target_is_u8) also the reconstruction
+ * likelihood partial sums and g = coef[INV_B] * dLoss/dlogit, exactly as dvae_convT4s2_sigmoid_recon_fwd[_u8]
+ * (losses.py:394-449) -- the same kernel structure with the multiply-adds issued as packed fp32 FMAs.             */
+int dvae_convT3_fwd_staged(const float* x, const float* img_pairs, const float* b, const void* target, int target_is_u8,
+                           float* recon, float* g, int dist, const float* coef, float* partials, int N, int C,
+                           void* stream);
 /* "down" = big[N,32,2Hs,2Hs] -> small[N,32,Hs,Hs]: Conv2d forward (encoders.py:75-77: bias + ReLU, mask NULL) and
  * ConvTranspose2d input gradient (decoders.py:77-80 under training.py:157: bias NULL, act none, mask = the producing
  * layer's post-ReLU output, gradient zeroed where it is 0).  "up" = small -> big: ConvTranspose2d forward / Conv2d

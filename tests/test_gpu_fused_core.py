@@ -24,8 +24,8 @@ def _rand(*shape, seed=0, scale=1.0):
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
 
 
-def _stage(conv=(), fc=(), coef=None, coef_vals=None):
-    """conv: [(w, img_down, img_up)], fc: [(w, img_fwd, img_bwd, N, K)] (device tensors / None)."""
+def _stage(conv=(), fc=(), coef=None, coef_vals=None, thin=None):
+    """conv: [(w, img_down, img_up)], fc: [(w, img_fwd, img_bwd, N, K)], thin: (w, img_pairs, C) (device tensors / None)."""
     cd = (_lib.ConvImageDesc * max(1, len(conv)))()
     for d, (w, a, b) in zip(cd, conv):
         d.w, d.img_down, d.img_up = ptr(w), ptr(a), ptr(b)
@@ -36,7 +36,12 @@ def _stage(conv=(), fc=(), coef=None, coef_vals=None):
     if coef_vals is not None:
         arr = (ctypes.c_float * 8)(*coef_vals)
         cv = ctypes.addressof(arr)
-    call("dvae_stage_weights", ctypes.addressof(cd), len(conv), ctypes.addressof(fd), len(fc), ptr(coef), cv, stream())
+    ta = None
+    if thin is not None:
+        td = _lib.ThinImageDesc()
+        td.w, td.img_pairs, td.C = ptr(thin[0]), ptr(thin[1]), thin[2]
+        ta = ctypes.addressof(td)
+    call("dvae_stage_weights", ctypes.addressof(cd), len(conv), ctypes.addressof(fd), len(fc), ta, ptr(coef), cv, stream())
     torch.cuda.synchronize()
 
 

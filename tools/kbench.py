@@ -51,7 +51,7 @@ for H in (32, 16, 8):        # big side H x H x 32 <-> small side H/2
     imd, imu = torch.empty(16384, device=dev), torch.empty(16384, device=dev)
     cd = (_lib.ConvImageDesc * 1)()
     cd[0].w, cd[0].img_down, cd[0].img_up = ptr(w), ptr(imd), ptr(imu)
-    call("dvae_stage_weights", ctypes.addressof(cd), 1, None, 0, None, None, s)
+    call("dvae_stage_weights", ctypes.addressof(cd), 1, None, 0, None, None, None, s)
     report("  staged: conv fwd (down)", timeit(lambda: call("dvae_conv32_down", ptr(big), ptr(imd), ptr(b), None, ptr(small), NHWC, B, hs, 1, s)), 2 * macs, nb + ns)
     report("  staged: convT dgrad (down+mask)", timeit(lambda: call("dvae_conv32_down", ptr(big), ptr(imd), None, ptr(small), ptr(small), NHWC, B, hs, 0, s)), 2 * macs, nb + 2 * ns)
     report("  staged: convT fwd (up)", timeit(lambda: call("dvae_conv32_up", ptr(small), NHWC, ptr(imu), ptr(b), None, ptr(big), B, hs, 1, s)), 2 * macs, nb + ns)

@@ -10,6 +10,7 @@
 #   bench     python bench.py (BENCH_ARGS; default run = headline + drop-in + the other three configs + CPU baseline)
 #   sweep     short bench lines at B = 64 / 128 / 256 / 1024 (btcvae 3ch) and the dsprites / factor configs
 #   absweep   A/B of the host-side schedule knobs (DVAE_DEBUG=1) over the batch size
+#   ab2       alternating A/B runs (needs a --debug build for the grid caps)
 #   kbench    every kernel alone at B = 1024 and B = 128
 #   prof      rocprofv3 --kernel-trace --stats of the default workload + summary + timeline
 #   timeline  the B = 128 step as a timeline (rocprofv3 kernel trace)
@@ -95,6 +96,27 @@ if has absweep; then
     DVAE_DEBUG=1 DVAE_EAGER_WGRAD_ELEMS=0 timeout 200 python bench.py --config $c --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --no-parity-check --no-drop-in 2>&1 | tail -n 1 | line "$c batch-sized"
     DVAE_DEBUG=1 DVAE_EAGER_WGRAD_ELEMS=999999999 timeout 200 python bench.py --config $c --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --no-parity-check --no-drop-in 2>&1 | tail -n 1 | line "$c eager"
   done | tee -a gpurun_out/${TAG}_absweep.txt
+fi
+if has ab2; then
+  echo "== alternating A/B (debug build + DVAE_DEBUG=1): schedule, persistent-grid caps, host floor, DDP path"
+  line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'])"; }
+  BA="--steps 150 --warmup 25 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
+  {
+  for rep in 1 2 3; do
+    for b in 128 1024; do
+      DVAE_DEBUG=1 DVAE_EAGER_WGRAD_ELEMS=0 timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "rep$rep B=$b batch-sized"
+      DVAE_DEBUG=1 DVAE_EAGER_WGRAD_ELEMS=999999999 timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "rep$rep B=$b eager"
+    done
+    DVAE_WGRAD_GRID=192 DVAE_WGRAD_THIN_GRID=192 timeout 200 python bench.py $BA 2>&1 | tail -n 1 | line "rep$rep B=1024 wgrad grids capped at 192"
+    DVAE_WGRAD_GRID=224 DVAE_WGRAD_THIN_GRID=224 timeout 200 python bench.py $BA 2>&1 | tail -n 1 | line "rep$rep B=1024 wgrad grids capped at 224"
+  done
+  timeout 200 python bench.py --batch 8 $BA 2>&1 | tail -n 1 | line "B=8 (host / launch-latency floor)"
+  timeout 200 python bench.py --batch 128 --force-ddp $BA 2>&1 | tail -n 1 | line "B=128 --force-ddp (torch transport)"
+  timeout 200 python bench.py --batch 128 --force-ddp --transport rccl $BA 2>&1 | tail -n 1 | line "B=128 --force-ddp --transport rccl"
+  timeout 200 python bench.py --batch 128 $BA 2>&1 | tail -n 1 | line "B=128 single process"
+  timeout 200 python bench.py --force-ddp $BA 2>&1 | tail -n 1 | line "B=1024 --force-ddp (torch transport)"
+  timeout 200 python bench.py $BA 2>&1 | tail -n 1 | line "B=1024 single process"
+  } | tee gpurun_out/${TAG}_ab2.txt
 fi
 if has kbench; then
   echo "== kbench"
