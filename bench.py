@@ -35,6 +35,7 @@ that directory exists: the build container), kind "port" = the oracle's restatem
 import argparse
 import glob
 import json
+import ctypes
 import os
 import re
 import sys
@@ -187,12 +188,16 @@ def thin_kernel_rooflines(B, C, device):
     s = torch.cuda.current_stream().cuda_stream
     NC, NH = _lib.NCHW, _lib.NHWC
     nx, na = x.numel() * 4.0, a1.numel() * 4.0
+    pairs = torch.empty(32 * _lib.thin_pair_floats(C), device=device)
+    td = _lib.ThinImageDesc()
+    td.w, td.img_pairs, td.C = ptr(wt), ptr(pairs), C
+    call("dvae_stage_weights", None, 0, None, 0, ctypes.addressof(td), None, None, s)
     launches = [
         ("k_down_thin<%d,false>" % C, "conv1 fwd", nx + na,
          lambda: call("dvae_conv4s2_fwd", ptr(x), NC, ptr(w), ptr(b32), ptr(ga1), NH, B, C, 64, 64, 32, _lib.ACT_RELU, s)),
-        ("k_up_thin<%d,true>" % C, "convT3 fwd + sigmoid + likelihood + dL/dlogit", na + 3 * nx,
-         lambda: call("dvae_convT4s2_sigmoid_recon_fwd", ptr(a1), NH, ptr(wt), ptr(bc), ptr(x), ptr(rec), ptr(g), 0, ptr(coef),
-                      ptr(parts), B, 32, 32, 32, C, s)),
+        ("k_up_thin_pk<%d,true>" % C, "convT3 fwd + sigmoid + likelihood + dL/dlogit (staged pair records)", na + 3 * nx,
+         lambda: call("dvae_convT3_fwd_staged", ptr(a1), ptr(pairs), ptr(bc), ptr(x), 0, ptr(rec), ptr(g), 0, ptr(coef),
+                      ptr(parts), B, C, s)),
         ("k_down_thin<%d,true>" % C, "convT3 dgrad (masked)", nx + 2 * na,
          lambda: call("dvae_convT4s2_dgrad", ptr(x), NC, ptr(wt), ptr(a1), ptr(ga1), NH, B, 32, 32, 32, C, s)),
         ("k_wgrad_thin<%d>" % C, "convT3 wgrad (+reduce)", nx + na,

@@ -165,7 +165,19 @@ int reparam_kl_blocks(int B);
 int launch_kl_finish(float* kl_dim, int kl_blocks, const float* coef, int D, hipStream_t s);
 int launch_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc,
                          const dvae_thin_image_desc* thin, float* coef, const float* coef_vals, hipStream_t s);
-__host__ __device__ int thin_pair_source(int idx, int C, int* cb);       // conv_thin.hip: record entry -> (tap, channel)
+// tap (kh * 4 + kw) and output channel of entry `idx` of a contracted channel's pair record (k_up_thin_pk, conv_thin.hip;
+// the staging kernel's gather)
+static __host__ __device__ __forceinline__ int thin_pair_source(int idx, int C, int* cb) {
+  const int taps[16] = {5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15};
+  if (C == 3 && idx < 32) {
+    const int a = idx >> 1, cls = a >> 2, t = a & 3;
+    const int py = cls >> 1, px = cls & 1, ty = t >> 1, tx = t & 1;
+    *cb = idx & 1;
+    return (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+  }
+  *cb = C - 1;
+  return taps[C == 3 ? idx - 32 : idx];
+}
 int launch_up_thin_staged(const float* small, const float* wrec, const float* bias, const void* target, int target_u8,
                           float* out, float* g, int dist, const float* coef, float* partials, int N, int C, int act,
                           hipStream_t s);

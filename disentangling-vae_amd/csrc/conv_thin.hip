@@ -312,8 +312,8 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
 // the cb2 plane adds three partial accumulators (row pairs, column pairs, corners) at the end.
 //   record of channel cs, C = 3:  [2 (4 cls + t) + {0,1}] = w[cs][{0,1}][kh][kw] with cls = 2 py + px, t = 2 ty + tx,
 //                                  kh = 1 - py + 2 ty, kw = 1 - px + 2 tx;  then the 16 floats of plane cb2 (C = 1: only these,
-//                                  of plane cb0) in the tap order of THIN_PLANE_TAPS below.
-__device__ __constant__ const int THIN_PLANE_TAPS[16] = {5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15};
+//                                  of plane cb0) in the tap order below.
+// tap order of the single-plane part (thin_pair_source, common.h): {5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15} =
 // (kh*4+kw): H pairs (cls0,cls1)/(cls2,cls3) from the own pixel: (1,1),(1,2) | (2,1),(2,2); from the pixel above / below:
 // (3,1),(3,2) | (0,1),(0,2); V pairs (cls0,cls2) from the left: (1,3),(2,3); (cls1,cls3) from the right: (1,0),(2,0);
 // corners: (0,0) -> cls3, (0,3) -> cls2, (3,0) -> cls1, (3,3) -> cls0
@@ -461,19 +461,6 @@ __global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ sm
     // unused partial slots must read as zero
     for (int k = gridDim.x + blockIdx.x * 128 + tid; k < DVAE_REC_NPART; k += gridDim.x * 128) partials[k] = 0.f;
   }
-}
-
-// float index of record entry `idx` of contracted channel cs in w[cs][cb][16] (the staging kernel's gather)
-__host__ __device__ int thin_pair_source(int idx, int C, int* cb) {
-  const int taps[16] = {5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15};
-  if (C == 3 && idx < 32) {
-    const int a = idx >> 1, cls = a >> 2, t = a & 3;
-    const int py = cls >> 1, px = cls & 1, ty = t >> 1, tx = t & 1;
-    *cb = idx & 1;
-    return (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
-  }
-  *cb = C - 1;
-  return taps[C == 3 ? idx - 32 : idx];
 }
 
 // convT3 forward on the staged pair records; target == NULL: no likelihood.  Returns 1 if the shape is not covered.

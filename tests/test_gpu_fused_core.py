@@ -266,3 +266,70 @@ def test_fc_chain_backward(n, D, noise, extra):
     call("dvae_linear_dgrad", ptr(ins["gd3"]), ptr(ent["d3"][0]), ptr(ins["d2"]), _lib.ACT_RELU, ptr(gd2p), n, 256, 512, None, stream())
     call("dvae_linear_dgrad", ptr(gd2p), ptr(ent["d2"][0]), ptr(ins["d1"]), _lib.ACT_RELU, ptr(gd1p), n, 256, 256, None, stream())
     check(out["gd1"], gd1p.cpu(), rtol=2e-5, atol_rel=4e-6, what="chain gd1 vs per-layer kernels")
+
+
+def _thin_records(w):
+    """Per contracted channel the operand-pair record of k_up_thin_pk (conv_thin.hip) from the ConvTranspose2d weight
+    w[32][C][4][4]: C = 3: [2 (4 cls + t) + {0,1}] = w[cs][{0,1}][kh][kw], cls = 2 py + px, t = 2 ty + tx, kh = 1 - py + 2 ty,
+    kw = 1 - px + 2 tx; then plane C-1 in the tap order below (pairs that share their source pixel, then the four corners)."""
+    C = w.shape[1]
+    plane = [5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15]
+    wt = w.reshape(32, C, 16)
+    rec = []
+    for cs in range(32):
+        r = []
+        if C == 3:
+            for cls in range(4):
+                py, px = cls >> 1, cls & 1
+                for t in range(4):
+                    ty, tx = t >> 1, t & 1
+                    tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx)
+                    r += [wt[cs, 0, tap], wt[cs, 1, tap]]
+        r += [wt[cs, C - 1, tap] for tap in plane]
+        rec.append(torch.stack(r))
+    return torch.stack(rec).reshape(-1)
+
+
+@pytest.mark.parametrize("C", [1, 3])
+@pytest.mark.parametrize("N", [3, 300])
+def test_convT3_forward_on_staged_pair_records(N, C):
+    """The last decoder layer (decoders.py:82) as the packed-FMA kernel on the records of dvae_stage_weights: the records bit
+    for bit; reconstruction, likelihood partial sums (losses.py:394-449) and dL/dlogit vs the raw-weight entry points
+    (fp32 and uint8 targets; rtol 1e-5 + 2e-6 of the scale: the summation order of the accumulators differs) and vs fp64."""
+    w = _rand(32, C, 4, 4, seed=2, scale=0.2)
+    b = _rand(C, seed=3, scale=0.1)
+    wd, bd = dev(w), dev(b)
+    pairs = torch.full((32 * _lib.thin_pair_floats(C),), 7.0, device=DEV)
+    _stage(thin=(wd, pairs, C))
+    assert torch.equal(pairs.cpu(), _thin_records(w))
+    x = nhwc(torch.relu(_rand(N, 32, 32, 32, seed=1)))
+    tgt8 = torch.randint(0, 256, (N, C, 64, 64), dtype=torch.uint8, generator=torch.Generator().manual_seed(4))
+    tgt = tgt8.float() / 255.0
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / N
+    coefd = dev(coef)
+    f = lambda: torch.empty(N, C, 64, 64, device=DEV)
+    tol = dict(rtol=1e-5, atol_rel=2e-6)
+    # plain forward
+    r0, r1 = f(), f()
+    call("dvae_convT4s2_fwd", ptr(x), _lib.NHWC, ptr(wd), ptr(bd), ptr(r0), _lib.NCHW, N, 32, 32, 32, C, _lib.ACT_SIGMOID, stream())
+    call("dvae_convT3_fwd_staged", ptr(x), ptr(pairs), ptr(bd), None, 0, ptr(r1), None, 0, None, None, N, C, stream())
+    check(r1, r0.cpu(), what="staged convT3 fwd vs raw", **tol)
+    xr = x.cpu().permute(0, 3, 1, 2).double()
+    ref = torch.sigmoid(F.conv_transpose2d(xr, w.double(), b.double(), stride=2, padding=1))
+    check(r1, ref, what="staged convT3 fwd vs fp64", **tol)
+    # fused likelihood, fp32 and uint8 targets
+    for dist in (0, 1, 2):
+        g0, g1, g2, r2 = f(), f(), f(), f()
+        p0, p1, p2 = (torch.full((_lib.REC_NPART,), 7.0, device=DEV) for _ in range(3))
+        td = dev(tgt)
+        call("dvae_convT4s2_sigmoid_recon_fwd", ptr(x), _lib.NHWC, ptr(wd), ptr(bd), ptr(td), ptr(r0), ptr(g0), dist, ptr(coefd),
+             ptr(p0), N, 32, 32, 32, C, stream())
+        call("dvae_convT3_fwd_staged", ptr(x), ptr(pairs), ptr(bd), ptr(td), 0, ptr(r1), ptr(g1), dist, ptr(coefd), ptr(p1), N, C,
+             stream())
+        t8 = tgt8.to(DEV)
+        call("dvae_convT3_fwd_staged", ptr(x), ptr(pairs), ptr(bd), ptr(t8), 1, ptr(r2), ptr(g2), dist, ptr(coefd), ptr(p2), N, C,
+             stream())
+        check(r1, r0.cpu(), what="fused recon dist %d" % dist, **tol)
+        check(g1, g0.cpu(), rtol=1e-4, atol_rel=2e-6, what="fused dL/dlogit dist %d" % dist)
+        check(p1.sum(), p0.sum().cpu(), rtol=1e-5, what="fused loss sum dist %d" % dist)
+        assert torch.equal(r2, r1) and torch.equal(g2, g1) and torch.equal(p2, p1), "uint8 target == ToTensor(target), dist %d" % dist

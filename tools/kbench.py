@@ -74,6 +74,14 @@ for C in (3,):
     parts = torch.empty(2048, device=dev)      # DVAE_REC_NPART
     tgt, rec = torch.rand_like(x), torch.empty_like(x)
     report("convT3 fwd + likelihood (up_thin fused)", timeit(lambda: call("dvae_convT4s2_sigmoid_recon_fwd", ptr(a1), NHWC, ptr(w), ptr(bc), ptr(tgt), ptr(rec), ptr(g), 0, ptr(coef), ptr(parts), B, 32, 32, 32, C, s)), 2 * macs, 3 * nx + na)
+    pairs = torch.empty(32 * _lib.thin_pair_floats(C), device=dev)
+    td = _lib.ThinImageDesc()
+    td.w, td.img_pairs, td.C = ptr(w), ptr(pairs), C
+    call("dvae_stage_weights", None, 0, None, 0, ctypes.addressof(td), None, None, s)
+    report("  staged: convT3 fwd (up_thin_pk+sigmoid)", timeit(lambda: call("dvae_convT3_fwd_staged", ptr(a1), ptr(pairs), ptr(bc), None, 0, ptr(rec), None, 0, None, None, B, C, s)), 2 * macs, nx + na)
+    report("  staged: convT3 fwd + likelihood (up_thin_pk fused)", timeit(lambda: call("dvae_convT3_fwd_staged", ptr(a1), ptr(pairs), ptr(bc), ptr(tgt), 0, ptr(rec), ptr(g), 0, ptr(coef), ptr(parts), B, C, s)), 2 * macs, 3 * nx + na)
+    t8 = (tgt * 255).to(torch.uint8)
+    report("  staged: convT3 fwd + likelihood, uint8 target", timeit(lambda: call("dvae_convT3_fwd_staged", ptr(a1), ptr(pairs), ptr(bc), ptr(t8), 1, ptr(rec), ptr(g), 0, ptr(coef), ptr(parts), B, C, s)), 2 * macs, 2.25 * nx + na)
     dbc = torch.empty(C, device=dev)
     report("convT3 wgrad (wgrad_thin+reduce)", timeit(lambda: call("dvae_convT4s2_wgrad", ptr(a1), NHWC, ptr(g), NCHW, ptr(dw), ptr(dbc), B, 32, 32, 32, C, ptr(ws), s)), 2 * macs, nx + na)
     report("recon_loss (bernoulli)", timeit(lambda: call("dvae_recon_loss", ptr(x), ptr(x), x.numel(), 0, ptr(coef), ptr(parts), ptr(g), 1, s)), 0, 3 * nx)

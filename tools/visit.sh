@@ -82,7 +82,13 @@ if has sweep; then
 fi
 if has absweep; then
   echo "== schedule A/B (DVAE_DEBUG=1 knobs): weight-gradient schedule (eager = dependency-driven, batch = batch-sized), streams"
-  line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'])"; }
+  line() { python -c "
+import sys, json
+t = sys.stdin.read()
+try:
+    d = json.loads(t); print('$1', d['value'], d['ms_per_step'])
+except Exception:
+    print('$1 FAILED:', t[-300:])"; }
   BA="--steps 100 --warmup 20 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
   for b in 128 256 512 1024; do
     DVAE_DEBUG=1 DVAE_EAGER_WGRAD_ELEMS=0 timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "B=$b batch-sized"
@@ -99,7 +105,13 @@ if has absweep; then
 fi
 if has ab2; then
   echo "== alternating A/B (debug build + DVAE_DEBUG=1): schedule, persistent-grid caps, host floor, DDP path"
-  line() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'])"; }
+  line() { python -c "
+import sys, json
+t = sys.stdin.read()
+try:
+    d = json.loads(t); print('$1', d['value'], d['ms_per_step'])
+except Exception:
+    print('$1 FAILED:', t[-300:])"; }
   BA="--steps 150 --warmup 25 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
   {
   for rep in 1 2 3; do
