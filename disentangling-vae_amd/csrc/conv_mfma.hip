@@ -623,7 +623,14 @@ int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
   const int out_l = (a.Hs == 4 && a.out_layout == DVAE_NCHW) ? DVAE_NHWC : a.out_layout;
   if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.big_layout, out_l, DVAE_NHWC)) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
-  // HS = 16, 8: wave-specialised (4 MFMA waves + 4 loader waves); HS = 4: K-split 32x32x2 kernel
+  // HS = 16, 8: k_down32dma (conv_down_dma.hip: weights in registers, tiles by LDS-DMA); HS = 4: K-split 32x32x2 kernel.
+  // k_down32ws (LDS weight image, register-staged loaders) is what the DMA kernel replaced: debug builds keep it selectable.
+#ifdef DVAE_DEBUG_SWITCHES
+  static const int use_ws = env_int("DVAE_DOWN_WS", 0);
+#else
+  constexpr int use_ws = 0;
+#endif
+  if (!use_ws && (a.Hs == 16 || a.Hs == 8)) return launch_down_mfma32_dma(a, s);
   switch (a.Hs) {
     case 16: return launch_down_ws<16>(a, s);
     case 8: return launch_down_ws<8>(a, s);

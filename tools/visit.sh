@@ -130,6 +130,33 @@ except Exception:
   timeout 200 python bench.py $BA 2>&1 | tail -n 1 | line "B=1024 single process"
   } | tee gpurun_out/${TAG}_ab2.txt
 fi
+if has downab; then
+  echo "== k_down32dma vs k_down32ws (debug build: DVAE_DOWN_WS=1 selects the old kernel)"
+  timeout 900 python -m pytest tests/test_gpu_fused_core.py tests/test_gpu_bench_sizes.py tests/test_gpu_kernels.py -m gpu -q --timeout=300 --no-header -k "conv or staged or persistent" > gpurun_out/${TAG}_pytest_down.log 2>&1
+  echo "pytest exit: $?" | tee -a gpurun_out/${TAG}_pytest_down.log
+  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_down.log | cut -c1-260 | head -30
+  grep -n -m3 -A8 "^E  " gpurun_out/${TAG}_pytest_down.log | cut -c1-300 | head -40
+  {
+  for ws in 0 1 0 1; do
+    echo "-- DVAE_DOWN_WS=$ws kbench B=1024"; DVAE_DOWN_WS=$ws timeout 300 python tools/kbench.py 1024 2>&1 | grep -E "conv fwd|convT dgrad" | head -20
+  done
+  echo "-- DVAE_DOWN_WS=0 kbench B=128"; DVAE_DOWN_WS=0 timeout 300 python tools/kbench.py 128 2>&1 | grep -E "conv fwd|convT dgrad" | head -20
+  echo "-- DVAE_DOWN_WS=1 kbench B=128"; DVAE_DOWN_WS=1 timeout 300 python tools/kbench.py 128 2>&1 | grep -E "conv fwd|convT dgrad" | head -20
+  line() { python -c "
+import sys, json
+t = sys.stdin.read()
+try:
+    d = json.loads(t); print('$1', d['value'], d['ms_per_step'])
+except Exception:
+    print('$1 FAILED:', t[-300:])"; }
+  BA="--steps 150 --warmup 25 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
+  for rep in 1 2 3; do
+    for b in 1024 128; do
+      for ws in 0 1; do DVAE_DOWN_WS=$ws timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "rep$rep B=$b DVAE_DOWN_WS=$ws"; done
+    done
+  done
+  } | tee gpurun_out/${TAG}_downab.txt
+fi
 if has kbench; then
   echo "== kbench"
   timeout 300 python tools/kbench.py 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_kbench.txt; grep -E "staged|fc_chain|stage_w|thin|likelihood" gpurun_out/${TAG}_kbench.txt
