@@ -120,7 +120,7 @@ def kernel_rooflines(B, device):
     """HIP-event timing (events on torch's current stream = the stream the launches go to) of the three
     32 <-> 32 channel MFMA conv families at their largest geometry (32x32 <-> 16x16, 8.59 GFLOP per 1024 images:
     2 x 4.19 M MACs per image), launched through the C-ABI.  Per training step each family runs twice
-    at this geometry: k_up32ws<16> = convT2 fwd + conv2 dgrad (masked), k_down32ws<16> = conv2 fwd + convT2 dgrad
+    at this geometry: k_up32ws<16> = convT2 fwd + conv2 dgrad (masked), k_down32dma<16> = conv2 fwd + convT2 dgrad
     (masked), k_wgrad32ws<16> = conv2 wgrad + convT2 wgrad."""
     import ctypes
     from disvae_amd import _lib
@@ -142,7 +142,7 @@ def kernel_rooflines(B, device):
     fams = {
         "k_up32ws<16>": [("convT2 fwd", lambda: call("dvae_conv32_up", ptr(small), NH, ptr(imu), ptr(b), None, ptr(obig), B, 16, RELU, s)),
                        ("conv2 dgrad (masked)", lambda: call("dvae_conv32_up", ptr(small), NH, ptr(imu), None, ptr(big), ptr(obig), B, 16, NONE, s))],
-        "k_down32ws<16>": [("conv2 fwd", lambda: call("dvae_conv32_down", ptr(big), ptr(imd), ptr(b), None, ptr(osmall), NH, B, 16, RELU, s)),
+        "k_down32dma<16>": [("conv2 fwd", lambda: call("dvae_conv32_down", ptr(big), ptr(imd), ptr(b), None, ptr(osmall), NH, B, 16, RELU, s)),
                            ("convT2 dgrad (masked)", lambda: call("dvae_conv32_down", ptr(big), ptr(imd), None, ptr(small), ptr(osmall), NH, B, 16, NONE, s))],
         "k_wgrad32ws<16>": [("conv2 wgrad (+reduce)", lambda: call("dvae_conv4s2_wgrad", ptr(big), NH, ptr(small), NH, ptr(dw), ptr(db), B, 32, 32, 32, 32, ptr(ws), s))],
     }
@@ -151,7 +151,7 @@ def kernel_rooflines(B, device):
     # (+ the mask read of the masked variants)
     big_b, small_b = 32 * 32 * 32 * 4.0, 16 * 16 * 32 * 4.0          # bytes per image
     algo_bytes = {"k_up32ws<16>": (big_b + small_b) * B + big_b * B / 2,         # avg of the plain and the masked launch
-                  "k_down32ws<16>": (big_b + small_b) * B + small_b * B / 2,
+                  "k_down32dma<16>": (big_b + small_b) * B + small_b * B / 2,
                   "k_wgrad32ws<16>": (big_b + small_b) * B}
     out = []
     for name, launches in fams.items():

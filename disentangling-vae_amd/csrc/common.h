@@ -171,7 +171,7 @@ int launch_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dva
 static __host__ __device__ __forceinline__ int thin_pair_source(int idx, int C, int* cb) {
   const int taps[16] = {5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15};
   if (C == 3 && idx < 32) {
-    const int a = idx >> 1, cls = a >> 2, t = a & 3;
+    const int a = idx >> 1, t = a >> 2, cls = a & 3;      // tap-major: 16 consecutive floats feed all four classes' chains
     const int py = cls >> 1, px = cls & 1, ty = t >> 1, tx = t & 1;
     *cb = idx & 1;
     return (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);

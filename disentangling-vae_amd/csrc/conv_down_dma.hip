@@ -51,6 +51,14 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
                                                    float* __restrict__ out, int act, int n_units, int w_staged) {
   using G = Geo<HS>;
   using D = DmaGeo<HS>;
+#ifdef DVAE_DEBUG_SWITCHES
+  // timing ablations (DVAE_DMA_ABLATE, debug builds only; results invalid): 1 no output stores, 2 no mask loads, 4 no DMA
+  // transfers, 8 no LDS operand reads, 16 no per-unit barriers, 32 no MFMAs
+  const int abl = act >> 8;
+  act &= 0xff;
+#else
+  constexpr int abl = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,10 +106,10 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
       // compute waves work on `buf`; tile(unit + stride) is in flight into buf + 1; buf + 2 was released by the barrier above
       const int b2 = buf >= 1 ? buf - 1 : 2;        // (buf + 2) % 3
       const bool more = unit + 2 * stride < n_units;
-      if (more) issue(b2);
-      if (more) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   // all but the 11 newest: tile(unit + stride) has landed
+      if (more && !(abl & 4)) issue(b2);
+      if (more && !(abl & 4)) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   // all but the 11 newest: tile(unit + stride) has landed
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      barrier_nofence();
+      if (!(abl & 16)) barrier_nofence();
       buf = buf == 2 ? 0 : buf + 1;
     }
     return;
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
     f32x4 mv[2];
     if (MASK) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) mv[mt] = *reinterpret_cast<const f32x4*>(mask + obase + mt * 512);
+      for (int mt = 0; mt < 2; ++mt) mv[mt] = (abl & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(mask + obase + mt * 512);
     }
     f32x4 acc[2][4];
 #pragma unroll
@@ -162,7 +170,16 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 P[2][2][2];                                  // [slot][mt][h]
+#ifdef DVAE_DEBUG_SWITCHES
+    if (abl & 8) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) P[a >> 2][(a >> 1) & 1][a & 1] = f32x4{1.f, 2.f, 3.f, 4.f};
+    }
+#endif
     auto rd = [&](int tap, int slot) {
+#ifdef DVAE_DEBUG_SWITCHES
+      if (abl & 8) return;
+#endif
       const int kh = tap >> 2, kw = tap & 3;
       const int tc = ((kh * 2 + (kw & 1)) * G::CW) * 32;      // row 2 sy_l + kh, parity kw & 1
 #pragma unroll
@@ -183,11 +200,11 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[t][h][j], P[cur][mt][h][j], acc[mt][j], 0, 0, 0);
+            if (!(abl & 32)) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[t][h][j], P[cur][mt][h][j], acc[mt][j], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);    // 4 DS reads (next tap)
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMAs (this tap)
     }
-    barrier_nofence();                                 // the tile is consumed (every ds_read fed an MFMA above)
+    if (!(abl & 16)) barrier_nofence();                // the tile is consumed (every ds_read fed an MFMA above)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const f32x4 a = (acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]);
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
         if (MASK) x = mv[mt][v] > 0.f ? x : 0.f;
         o[v] = x;
       }
-      *reinterpret_cast<f32x4*>(out + obase + mt * 512) = o;
+      if (!(abl & 1)) *reinterpret_cast<f32x4*>(out + obase + mt * 512) = o;
     }
     buf = buf == 2 ? 0 : buf + 1;
   }
@@ -216,8 +233,9 @@ static int launch_down_dma_t(const ConvArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_down32dma<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k_down32dma<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  if (a.mask) hipLaunchKernelGGL((k_down32dma<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.act, n_units, a.w_staged);
-  else hipLaunchKernelGGL((k_down32dma<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.act, n_units, a.w_staged);
+  const int af = a.act | (env_int("DVAE_DMA_ABLATE", 0) << 8);     // debug builds only
+  if (a.mask) hipLaunchKernelGGL((k_down32dma<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, af, n_units, a.w_staged);
+  else hipLaunchKernelGGL((k_down32dma<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, af, n_units, a.w_staged);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -123,157 +123,9 @@ __global__ __launch_bounds__(512) void k_down32(const float* __restrict__ big, c
   }
 }
 
-// ---- down, version 3 (HS = 16, 8): wave-specialised ---------------------------------------
-// Waves 0-3 (one per SIMD) do nothing but MFMAs: each owns 16 pixels x all 32 output channels of the
-// unit (256 v_mfma_f32_16x16x4_f32, 8 independent accumulator chains, operands prefetched one tap
-// ahead).  Waves 4-7 are loaders: they fetch the tile of unit u+2 from HBM into registers and write
-// the tile of unit u+1 into the idle LDS buffer while the compute waves run.  One barrier per unit;
-// the matrix pipe only idles for the barrier + 8 stores per lane.
-// one unit of MFMA work of a compute wave of k_down32ws: 16 pixels x 32 channels, K = 512
-template <int HS>
-__device__ __forceinline__ void down_ws_mfma(f32x4v (&acc)[2][4], const float* bt, const float* wl, int sy_l, int sx,
-                                             int i16, int kq, int abl = 0) {
-  using G = Geo<HS>;
-#pragma unroll
-  for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[nh][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  f32x4 A0[2], A1[2], B00[2], B01[2], B10[2], B11[2];
-#ifdef DVAE_DEBUG_SWITCHES
-  if (abl & 16) {                        // timing ablation: no LDS operand reads (constant operands)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { A0[c] = f32x4{1.f, 2.f, 3.f, 4.f}; A1[c] = A0[c]; B00[c] = A0[c]; B01[c] = A0[c]; B10[c] = A0[c]; B11[c] = A0[c]; }
-  }
-#endif
-  auto rd = [&](int tap, int slot) {
-#ifdef DVAE_DEBUG_SWITCHES
-    if (abl & 16) return;
-#endif
-    const int kh = tap >> 2, kw = tap & 3;
-    const int r = 2 * sy_l + kh;
-    const int par = kw & 1, cw = sx + (kw >> 1);
-    const float* arow = bt + ((r * 2 + par) * G::CW + cw) * 32;
-    const int sw = swz_big<HS>(r, cw);
-    const float* brow = wl + (tap * 8) * 128 + i16 * 4;
-    A0[slot] = *reinterpret_cast<const f32x4*>(arow + ((kq ^ sw) << 2));
-    A1[slot] = *reinterpret_cast<const f32x4*>(arow + (((4 + kq) ^ sw) << 2));
-    B00[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128);
-    B01[slot] = *reinterpret_cast<const f32x4*>(brow + kq * 128 + 64);
-    B10[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128);
-    B11[slot] = *reinterpret_cast<const f32x4*>(brow + (4 + kq) * 128 + 64);
-  };
-  rd(0, 0);
-  __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < 16) rd(t + 1, cur ^ 1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B00[cur][j], acc[0][j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[cur][j], B01[cur][j], acc[1][j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B10[cur][j], acc[0][j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[cur][j], B11[cur][j], acc[1][j], 0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // 6 DS reads (next tap)
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMAs (this tap)
-  }
-}
-
-// Waves 0-3 (one per SIMD) do nothing but MFMAs; waves 4-7 are loaders that keep TWO tiles in flight
-// from HBM (units u+2 and u+3 in two register sets) and write tile u+1 into the idle LDS buffer while
-// the compute waves run: the whole chip issues its tile loads in the same few hundred cycles after a
-// barrier, so a single tile of look-ahead (~1 unit time) does not cover the queueing delay.
-// LT = number of loader threads (256 = one loader wave per SIMD; the debug build also instantiates 512 = two per SIMD: a wave
-// that shares its SIMD with an MFMA-streaming wave issues only ~1 instruction per 50 cycles, tools/ubench/mfma_mix.hip)
-template <int HS, bool MASK, int LT = 256>
-__global__ __launch_bounds__(256 + LT) void k_down32ws(const float* __restrict__ big, const float* __restrict__ w,
-                                                  const float* __restrict__ bias, const float* __restrict__ mask,
-                                                  float* __restrict__ out, int N, int act_flags, int n_units,
-                                                  int w_staged) {
-  using G = Geo<HS>;
-  static_assert(G::IMGS == 1, "one image per unit");
-  const int act = act_flags & 0xff;
-#ifdef DVAE_DEBUG_SWITCHES
-  const int abl = act_flags >> 8;   // timing-ablation flags (DVAE_ABLATE, debug builds only; results invalid)
-#else
-  constexpr int abl = 0;
-#endif
-  constexpr int LNPF = (G::BIG_SLOTS + LT - 1) / LT;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* wl = smem;                          // 16384 floats
-  float* bt0 = smem + 16384;
-  float* bt1 = bt0 + G::BIG_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_compute = wv < 4;
-  const int i16 = lane & 15, kq = lane >> 4;
-  const int p = (wv & 3) * 16 + i16;
-  const int sy_l = (p / HS) % G::R, sx = p % HS;
-  const int stride = gridDim.x;
-
-  SlotDesc<LNPF> sd;
-  f32x4 pfa[LNPF], pfb[LNPF];      // loader register sets: tiles of the units (u+1, u+3, ..) and (u+2, u+4, ..)
-  const int ltid = tid - 256;
-  if (!is_compute) init_big_slots<HS, LT, LNPF>(sd, ltid);
-  int unit = blockIdx.x;
-  if (!is_compute && unit < n_units) load_big<HS, LNPF>(pfa, sd, big, unit, N);
-  // the 64 KB weight image: copied as it is when pre-staged (dvae_stage_weights), else re-laid here by 512 threads
-  if (w_staged) copy_weight_image(w, wl, tid);
-  else if (LT == 256 || tid < 512) stage_weights<true>(w, wl, tid);
-  if (!is_compute && unit < n_units) store_big<HS, LNPF>(pfa, sd, bt0);
-  __syncthreads();
-  if (!is_compute) {
-    if (unit + stride < n_units) load_big<HS, LNPF>(pfa, sd, big, unit + stride, N);
-    if (unit + 2 * stride < n_units) load_big<HS, LNPF>(pfb, sd, big, unit + 2 * stride, N);
-  }
-  // The two roles run DISJOINT loops (their registers are never live together); both execute exactly
-  // one s_barrier per unit, so the workgroup barrier pairs them up unit by unit.
-  if (is_compute) {
-    const float bv0 = bias ? bias[i16] : 0.f, bv1 = bias ? bias[16 + i16] : 0.f;
-    __builtin_amdgcn_s_setprio(1);
-    int buf = 0;
-    for (; unit < n_units; unit += stride) {
-      const float* bt = buf ? bt1 : bt0;
-      const long obase = ((long)unit * G::U + (wv & 3) * 16 + 4 * kq) * 32 + i16;
-      f32x4v acc[2][4];
-      float mv[2][4];
-      if (MASK) {
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mv[nh][r] = mask[obase + r * 32 + nh * 16];
-      }
-      if (!(abl & 8)) down_ws_mfma<HS>(acc, bt, wl, sy_l, sx, i16, kq, abl);
-      if (!(abl & 32)) __syncthreads();   // (32: timing ablation, no per-unit barrier)
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
-        const f32x4v a = (acc[nh][0] + acc[nh][1]) + (acc[nh][2] + acc[nh][3]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = epilogue_act(a[r] + (nh ? bv1 : bv0), act);
-          if (MASK) v = mv[nh][r] > 0.f ? v : 0.f;
-          if (!(abl & 4)) out[obase + r * 32 + nh * 16] = v;
-        }
-      }
-      buf ^= 1;
-    }
-  } else {
-    // loader: registers pfa hold tile u+1, pfb tile u+2 (in flight); alternate
-    while (unit < n_units) {
-      if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pfa, sd, bt1);
-      if (!(abl & 32)) __syncthreads();
-      if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfa, sd, big, unit + 3 * stride, N);
-      unit += stride;
-      if (unit >= n_units) break;
-      if (unit + stride < n_units && !(abl & 1)) store_big<HS, LNPF>(pfb, sd, bt0);
-      if (!(abl & 32)) __syncthreads();
-      if (unit + 3 * stride < n_units && !(abl & 2)) load_big<HS, LNPF>(pfb, sd, big, unit + 3 * stride, N);
-      unit += stride;
-    }
-  }
-}
+// (HS = 16, 8 of the down direction: k_down32dma, conv_down_dma.hip.  Its predecessor k_down32ws -- 64 KB weight image in LDS,
+// register-staged loader waves, D fragments stored with 4-byte stores -- measured 74.5 / 80.8 us against 72.4 / 78.8 us on
+// the same box at B = 1024, profiles/r03_v7_downab.txt; git history.)
 
 // ---- up: small -> big --------------------------------------------------------------------
 // output offsets of the 16 D-fragment rows of this wave's (class, M-tile) for a given unit
@@ -524,39 +376,6 @@ int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_b
 static int units_for(int N, int HS) { return (int)(((long)N * HS * HS + 63) / 64); }
 
 template <int HS>
-static int launch_down_ws(const ConvArgs& a, hipStream_t s) {
-  using G = Geo<HS>;
-  const int n_units = units_for(a.N, HS);
-  const int grid = n_units < 256 ? n_units : 256;
-  const size_t lds = (16384 + 2 * G::BIG_FLOATS) * sizeof(float);
-  static DeviceOnce attr;
-  if (attr.first()) {
-    (void)hipFuncSetAttribute((const void*)k_down32ws<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)k_down32ws<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
-  static const int abl = env_int("DVAE_ABLATE", 0);   // timing ablation, debug builds only (results invalid)
-  const int af = a.act | (abl << 8);
-#ifdef DVAE_DEBUG_SWITCHES
-  static const int lt = env_int("DVAE_DOWN_LT", 256);  // 512: two loader waves per SIMD (768-thread workgroups)
-  if (lt == 512) {
-    static DeviceOnce attr2;
-    if (attr2.first()) {
-      (void)hipFuncSetAttribute((const void*)k_down32ws<HS, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)k_down32ws<HS, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
-    else hipLaunchKernelGGL((k_down32ws<HS, false, 512>), dim3(grid), dim3(768), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
-    DVAE_CHECK_LAUNCH();
-    return 0;
-  }
-#endif
-  if (a.mask) hipLaunchKernelGGL((k_down32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
-  else hipLaunchKernelGGL((k_down32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.big, a.w, a.bias, a.mask, a.out, a.N, af, n_units, a.w_staged);
-  DVAE_CHECK_LAUNCH();
-  return 0;
-}
-
-template <int HS>
 static int launch_down_t(const ConvArgs& a, hipStream_t s) {
   using G = Geo<HS>;
   const int n_units = units_for(a.N, HS);
@@ -623,19 +442,9 @@ int launch_down_mfma32(const ConvArgs& a, hipStream_t s) {
   const int out_l = (a.Hs == 4 && a.out_layout == DVAE_NCHW) ? DVAE_NHWC : a.out_layout;
   if (!mfma32_applicable(a.Cb, a.Cs, a.Hs, a.Ws, a.big_layout, out_l, DVAE_NHWC)) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
-  // HS = 16, 8: k_down32dma (conv_down_dma.hip: weights in registers, tiles by LDS-DMA); HS = 4: K-split 32x32x2 kernel.
-  // k_down32ws (LDS weight image, register-staged loaders) is what the DMA kernel replaced: debug builds keep it selectable.
-#ifdef DVAE_DEBUG_SWITCHES
-  static const int use_ws = env_int("DVAE_DOWN_WS", 0);
-#else
-  constexpr int use_ws = 0;
-#endif
-  if (!use_ws && (a.Hs == 16 || a.Hs == 8)) return launch_down_mfma32_dma(a, s);
-  switch (a.Hs) {
-    case 16: return launch_down_ws<16>(a, s);
-    case 8: return launch_down_ws<8>(a, s);
-    default: return launch_down_t<4>(a, s);
-  }
+  // HS = 16, 8: k_down32dma (conv_down_dma.hip: weights in registers, tiles by LDS-DMA); HS = 4: K-split 32x32x2 kernel
+  if (a.Hs == 16 || a.Hs == 8) return launch_down_mfma32_dma(a, s);
+  return launch_down_t<4>(a, s);
 }
 
 int launch_up_mfma32(const ConvArgs& a, hipStream_t s) {

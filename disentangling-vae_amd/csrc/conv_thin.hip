@@ -310,7 +310,7 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
 // the layer's weights are read from a per-channel record in pair order (DVAE_THIN_PAIR_FLOATS(C) floats per contracted
 // channel) that dvae_stage_weights writes once per step.  Every output is still a fixed-order fmaf chain per accumulator;
 // the cb2 plane adds three partial accumulators (row pairs, column pairs, corners) at the end.
-//   record of channel cs, C = 3:  [2 (4 cls + t) + {0,1}] = w[cs][{0,1}][kh][kw] with cls = 2 py + px, t = 2 ty + tx,
+//   record of channel cs, C = 3:  [2 (4 t + cls) + {0,1}] = w[cs][{0,1}][kh][kw] with cls = 2 py + px, t = 2 ty + tx,
 //                                  kh = 1 - py + 2 ty, kw = 1 - px + 2 tx;  then the 16 floats of plane cb2 (C = 1: only these,
 //                                  of plane cb0) in the tap order below.
 // tap order of the single-plane part (thin_pair_source, common.h): {5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15} =
@@ -319,6 +319,23 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
 // corners: (0,0) -> cls3, (0,3) -> cls2, (3,0) -> cls1, (3,3) -> cls0
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// What bounds this kernel (timing ablations of a debug build, profiles/r03_v10_thin_abl.txt, B = 1024, 93 us complete): the
+// FMA core alone 44 us; tile loads 16, LDS operand reads 17, the range-reduced expf + IEEE division of the sigmoid 15, the
+// scalar loads of the weight records 14, barriers 8, stores 5 -- a wave is latency-bound on all of them in turn (six
+// s_waitcnt lgkmcnt(0) per 4 channels behind ~200-cycle scalar loads), which is why halving the FMA instructions with
+// v_pk_fma_f32 bought 0-3 % (profiles/r03_v6_kbench.txt; the packed form itself runs at 1.8x the v_fma_f32 rate,
+// profiles/r03_v9_valu_fma_rate.txt).  Kept from that analysis: the hardware sigmoid, the likelihood's targets requested
+// before the FMA loop instead of one dependent round trip per output pair, tap-major records so that the first 16 weights of
+// a channel feed four accumulator chains.  Measured and NOT kept (parity green, not in the tree): the tile in two
+// 16-channel halves moved by LDS-DMA (global_load_lds_dwordx4 from inline asm, the next half in flight under the FMAs, same
+// 26 KB of LDS) -- 113 / 134 us against 70 / 93 us for this kernel on the same box (profiles/r03_v14_thin_abl.txt): with the
+// loads off the critical path a wave is paced by its scalar weight loads alone (8.2 us per unit for ONE resident workgroup
+// per CU with tile loads, LDS reads, sigmoid and stores all removed), and twice as many barrier-delimited phases per unit
+// leave the three waves of a SIMD fewer chances to cover each other's stalls.
+// torch.sigmoid on the hardware transcendentals: v_exp_f32 (x log2 e) and v_rcp_f32, <= 2-3 ulp from the correctly rounded
+// 1 / (1 + exp(-v)) (the IEEE division and range-reduced expf of the synchronous kernel cost 15 us of 93 at B = 1024)
+__device__ __forceinline__ float sigmoid_hw(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 template <int C, bool FUSE, typename TT = float>
 __global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ small, const float* __restrict__ wrec,
@@ -367,6 +384,20 @@ __global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ sm
         }
     }
     __syncthreads();
+    float2 tg[C][2];                                 // the likelihood's targets travel under the FMAs
+    if (FUSE && n < N) {
+#pragma unroll
+      for (int cb = 0; cb < C; ++cb)
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          const long o = ((((long)n * C + cb) * 64) + 2 * (sy0 + m) + py) * 64 + 2 * l;
+          if constexpr (sizeof(TT) == 4) tg[cb][py] = *reinterpret_cast<const float2*>(target + o);
+          else {
+            const uchar2 xt = *reinterpret_cast<const uchar2*>(target + o);
+            tg[cb][py] = make_float2((float)xt.x, (float)xt.y);
+          }
+        }
+    }
     f32x2 accA[4];                                   // (cb0, cb1) of class cls                     (C = 3)
     f32x2 h01 = {0.f, 0.f}, h23 = {0.f, 0.f};        // plane CS: classes (0,1) / (2,3), sources in the own column
     f32x2 v02 = {0.f, 0.f}, v13 = {0.f, 0.f};        // plane CS: classes (0,2) / (1,3), sources left / right
@@ -390,13 +421,13 @@ __global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ sm
         const f32x2* wp2 = reinterpret_cast<const f32x2*>(wp);
         if (C == 3) {
 #pragma unroll
-          for (int cls = 0; cls < 4; ++cls) {
-            const int py = cls >> 1, px = cls & 1;
+          for (int t = 0; t < 4; ++t) {                // tap-major: consecutive instructions feed four different accumulators
+            const int ty = t >> 1, tx = t & 1;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int ty = t >> 1, tx = t & 1;
+            for (int cls = 0; cls < 4; ++cls) {
+              const int py = cls >> 1, px = cls & 1;
               const float xs = x[py - ty + 1][px - tx + 1][j];
-              accA[cls] = __builtin_elementwise_fma(f32x2{xs, xs}, wp2[cls * 4 + t], accA[cls]);
+              accA[cls] = __builtin_elementwise_fma(f32x2{xs, xs}, wp2[t * 4 + cls], accA[cls]);
             }
           }
         }
@@ -431,19 +462,13 @@ __global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ sm
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
           float v0 = acc[py * 2 + 0][cb] + bv, v1 = acc[py * 2 + 1][cb] + bv;
-          if (act == DVAE_ACT_SIGMOID) { v0 = 1.f / (1.f + expf(-v0)); v1 = 1.f / (1.f + expf(-v1)); }
+          if (act == DVAE_ACT_SIGMOID) { v0 = sigmoid_hw(v0); v1 = sigmoid_hw(v1); }
           else if (act == DVAE_ACT_RELU) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
           const long o = ((((long)n * C + cb) * 64) + 2 * sy + py) * 64 + 2 * l;
           *reinterpret_cast<float2*>(out + o) = make_float2(v0, v1);
           if (FUSE) {
-            float xt0, xt1;
-            if constexpr (sizeof(TT) == 4) {
-              const float2 xt = *reinterpret_cast<const float2*>(target + o);
-              xt0 = xt.x; xt1 = xt.y;
-            } else {
-              const uchar2 xt = *reinterpret_cast<const uchar2*>(target + o);
-              xt0 = to_unit(xt.x); xt1 = to_unit(xt.y);
-            }
+            float xt0 = tg[cb][py].x, xt1 = tg[cb][py].y;
+            if constexpr (sizeof(TT) != 4) { xt0 = xt0 / 255.0f; xt1 = xt1 / 255.0f; }     // = to_unit(uint8_t): ToTensor's division
             float gl0, gl1, gr;
             lsum += recon_elem(v0, xt0, dist, &gl0, &gr);
             lsum += recon_elem(v1, xt1, dist, &gl1, &gr);

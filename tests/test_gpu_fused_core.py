@@ -270,7 +270,7 @@ def test_fc_chain_backward(n, D, noise, extra):
 
 def _thin_records(w):
     """Per contracted channel the operand-pair record of k_up_thin_pk (conv_thin.hip) from the ConvTranspose2d weight
-    w[32][C][4][4]: C = 3: [2 (4 cls + t) + {0,1}] = w[cs][{0,1}][kh][kw], cls = 2 py + px, t = 2 ty + tx, kh = 1 - py + 2 ty,
+    w[32][C][4][4]: C = 3: [2 (4 t + cls) + {0,1}] = w[cs][{0,1}][kh][kw], cls = 2 py + px, t = 2 ty + tx, kh = 1 - py + 2 ty,
     kw = 1 - px + 2 tx; then plane C-1 in the tap order below (pairs that share their source pixel, then the four corners)."""
     C = w.shape[1]
     plane = [5, 6, 9, 10, 13, 14, 1, 2, 7, 11, 4, 8, 0, 3, 12, 15]
@@ -279,10 +279,10 @@ def _thin_records(w):
     for cs in range(32):
         r = []
         if C == 3:
-            for cls in range(4):
-                py, px = cls >> 1, cls & 1
-                for t in range(4):
-                    ty, tx = t >> 1, t & 1
+            for t in range(4):
+                ty, tx = t >> 1, t & 1
+                for cls in range(4):
+                    py, px = cls >> 1, cls & 1
                     tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx)
                     r += [wt[cs, 0, tap], wt[cs, 1, tap]]
         r += [wt[cs, C - 1, tap] for tap in plane]

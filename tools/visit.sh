@@ -130,32 +130,12 @@ except Exception:
   timeout 200 python bench.py $BA 2>&1 | tail -n 1 | line "B=1024 single process"
   } | tee gpurun_out/${TAG}_ab2.txt
 fi
-if has downab; then
-  echo "== k_down32dma vs k_down32ws (debug build: DVAE_DOWN_WS=1 selects the old kernel)"
-  timeout 900 python -m pytest tests/test_gpu_fused_core.py tests/test_gpu_bench_sizes.py tests/test_gpu_kernels.py -m gpu -q --timeout=300 --no-header -k "conv or staged or persistent" > gpurun_out/${TAG}_pytest_down.log 2>&1
-  echo "pytest exit: $?" | tee -a gpurun_out/${TAG}_pytest_down.log
-  grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest_down.log | cut -c1-260 | head -30
-  grep -n -m3 -A8 "^E  " gpurun_out/${TAG}_pytest_down.log | cut -c1-300 | head -40
-  {
-  for ws in 0 1 0 1; do
-    echo "-- DVAE_DOWN_WS=$ws kbench B=1024"; DVAE_DOWN_WS=$ws timeout 300 python tools/kbench.py 1024 2>&1 | grep -E "conv fwd|convT dgrad" | head -20
-  done
-  echo "-- DVAE_DOWN_WS=0 kbench B=128"; DVAE_DOWN_WS=0 timeout 300 python tools/kbench.py 128 2>&1 | grep -E "conv fwd|convT dgrad" | head -20
-  echo "-- DVAE_DOWN_WS=1 kbench B=128"; DVAE_DOWN_WS=1 timeout 300 python tools/kbench.py 128 2>&1 | grep -E "conv fwd|convT dgrad" | head -20
-  line() { python -c "
-import sys, json
-t = sys.stdin.read()
-try:
-    d = json.loads(t); print('$1', d['value'], d['ms_per_step'])
-except Exception:
-    print('$1 FAILED:', t[-300:])"; }
-  BA="--steps 150 --warmup 25 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
-  for rep in 1 2 3; do
-    for b in 1024 128; do
-      for ws in 0 1; do DVAE_DOWN_WS=$ws timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "rep$rep B=$b DVAE_DOWN_WS=$ws"; done
-    done
-  done
-  } | tee gpurun_out/${TAG}_downab.txt
+if has dmaabl; then
+  echo "== k_down32dma timing ablations (debug build)"
+  ( for i in 1 2 3 4 5 6; do sleep 4; rocm-smi --showclocks 2>/dev/null | grep -i -E "sclk|mclk" | head -2; done ) > gpurun_out/${TAG}_clocks.txt 2>&1 &
+  timeout 300 python tools/down_abl.py 1024 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_down_abl.txt
+  wait
+  cat gpurun_out/${TAG}_clocks.txt | head -12
 fi
 if has kbench; then
   echo "== kbench"
@@ -181,6 +161,6 @@ fi
 if has pmc; then
   echo "== PMC passes"
   bash tools/pmc_collect.sh > gpurun_out/${TAG}_pmc.log 2>&1; cp gpurun_out/pmc_summary.md gpurun_out/${TAG}_pmc_summary.md 2>/dev/null
-  grep -E "k_up32ws<16|k_wgrad32ws<16|k_down32ws<16|thin" gpurun_out/${TAG}_pmc_summary.md | cut -c1-200
+  grep -E "k_up32ws<16|k_wgrad32ws<16|k_down32dma<16|thin" gpurun_out/${TAG}_pmc_summary.md | cut -c1-200
 fi
 echo "== done"
