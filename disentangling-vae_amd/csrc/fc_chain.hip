@@ -166,6 +166,24 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ x, int row0,
   }
 }
 
+// L2 warm-up of a weight image.  Inside a training step the FC images were written ~200 us (and several hundred MB of conv
+// traffic) before this kernel runs: on boxes whose caches do not retain them the chain's dependent weight stream pays HBM
+// latency per ring refill -- 45-64 us per launch instead of 24-26 (profiles/r03_v15_fcc_cold.txt; in the step:
+// profiles/r03_final_timeline.md 61 / 69 us, profiles/r03_v4_timeline.md 27 / 37 us on another box).  Every workgroup
+// therefore touches, at its start and all at once, every 64-byte sector of its share of the four large images with LDS-DMA
+// transfers into a 1 KB scratch block (no destination registers, so nothing to keep live; the data is never used): one parallel HBM round trip,
+// after which the stream runs from L2.  Workgroups b, b + 8, b + 16 .. share an XCD (and its L2): they split each image
+// among themselves.  Vector-memory operations return in order, so the wave's real weight loads queue behind its prefetches.
+__device__ __forceinline__ void l2_warm(const float* __restrict__ p, int nfloats, int share, int nshares, int wv, int nwaves,
+                                        int lane, unsigned lds_byte_addr) {
+  // one transfer touches 64 different 64-byte sectors (16 bytes of each): 4 KB of the image per instruction
+  const int nblk = nfloats >> 10;                   // 4 KB blocks
+  for (int b = share + nshares * wv; b < nblk; b += nshares * nwaves)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(p + (long)b * 1024 + lane * 16),
+                 "s"(lds_byte_addr)
+                 : "memory", "m0");
+}
+
 struct FwdArgs { dvae_fc_chain_fwd_args a; };
 struct BwdArgs { dvae_fc_chain_bwd_args a; };
 
@@ -230,6 +248,7 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   __shared__ float red[NWV][FCC_R][64];
   __shared__ float mlt[FCC_R][64];
   __shared__ float part[KS == 2 ? FCC_R * FCC_HID : 1];
+  __shared__ __attribute__((aligned(16))) float warm_sink[256];
   const Lane<KS> L;
   const int tid = L.tid, lane = L.lane, wv = L.wv, col = L.col, xo = L.xo;
   const bool own = L.kh == 0;                       // this wave finishes the 256-wide layers (bias, activation, stores)
@@ -240,6 +259,14 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   Ring<DEPTH, 1> r1, r2, dummy;
   Ring<SD, 1> dummy_s;
   fill256<DEPTH, KS, 128>(L, r1, a.w_e1 + col * 4, CS);
+  {
+    const int nsh = gridDim.x >= 8 ? gridDim.x >> 3 : 1, sh = (blockIdx.x >> 3) % nsh;
+    const unsigned sink = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)warm_sink;
+    l2_warm(a.w_e1, FCC_FLAT * FCC_HID, sh, nsh, wv, NWV, lane, sink);
+    l2_warm(a.w_e2, FCC_HID * FCC_HID, sh, nsh, wv, NWV, lane, sink);
+    l2_warm(a.w_d2, FCC_HID * FCC_HID, sh, nsh, wv, NWV, lane, sink);
+    l2_warm(a.w_d3, FCC_HID * FCC_FLAT, sh, nsh, wv, NWV, lane, sink);
+  }
   load_rows<FCC_FLAT, NT>(a.a_flat, row0, a.n_enc, tA, tid);
   const float be1 = a.b_e1[col], be2 = a.b_e2[col];
   __syncthreads();
@@ -384,6 +411,7 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   __shared__ __attribute__((aligned(16))) float tB[FCC_R * FCC_XS];
   __shared__ float red[NWV][FCC_R][64];
   __shared__ float part[KS == 2 ? FCC_R * FCC_HID : 1];
+  __shared__ __attribute__((aligned(16))) float warm_sink[256];
   const Lane<KS> L;
   const int tid = L.tid, lane = L.lane, wv = L.wv, col = L.col, xo = L.xo;
   const bool own = L.kh == 0;
@@ -395,6 +423,14 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   Ring<DEPTH, 1> r3, r2, re2, dummy;
   Ring<SD, 1> dummy_s;
   fill256<DEPTH, KS, 128>(L, r3, a.w_d3 + col * 4, CS);
+  {
+    const int nsh = gridDim.x >= 8 ? gridDim.x >> 3 : 1, sh = (blockIdx.x >> 3) % nsh;
+    const unsigned sink = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)warm_sink;
+    l2_warm(a.w_d3, FCC_HID * FCC_FLAT, sh, nsh, wv, NWV, lane, sink);
+    l2_warm(a.w_d2, FCC_HID * FCC_HID, sh, nsh, wv, NWV, lane, sink);
+    l2_warm(a.w_e2, FCC_HID * FCC_HID, sh, nsh, wv, NWV, lane, sink);
+    l2_warm(a.w_e1, FCC_FLAT * FCC_HID, sh, nsh, wv, NWV, lane, sink);
+  }
   load_rows<FCC_FLAT, NT>(a.gd3, row0, n, tA, tid);
   float mk[8], v[8];
   // ReLU mask of a 256-wide layer = its saved post-activation output (zero rows beyond n: their gradients are not stored)

@@ -1,5 +1,7 @@
 """FC-chain kernels alone at batch B (debug builds: DVAE_FCC_VARIANT = 10 * ring depth + contraction split selects the
-instantiation).  usage: DVAE_FCC_VARIANT=162 python tools/fcc_ab.py [B ...]"""
+instantiation).  usage: DVAE_FCC_VARIANT=162 python tools/fcc_ab.py [B ...]
+FCC_COLD=1: every timed launch follows a 1 GB streaming write, i.e. the weight images come from HBM as they do inside a
+training step on a box whose caches do not retain them (profiles/r03_final_timeline.md: 61 us in the step, 26 us here)."""
 import os
 import sys
 
@@ -36,7 +38,20 @@ for B in [int(a) for a in sys.argv[1:]] or [128, 1024]:
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
 
+    if os.environ.get("FCC_COLD") == "1":
+        junk = torch.empty(256 * 1024 * 1024, device=dev)
+
+        def timeit(fn, n=12):          # noqa: F811
+            tot = 0.0
+            for it in range(n + 2):
+                junk.fill_(float(it))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); fn(); e1.record()
+                torch.cuda.synchronize()
+                if it >= 2:
+                    tot += e0.elapsed_time(e1)
+            return tot / n * 1e3
     f = timeit(lambda: eng.fc_chain_fwd(buf, eps, kl, B))
     b = timeit(lambda: eng.fc_chain_bwd(buf, eps, None, None, None, None, scal, coefd, B))
-    print("variant %s B=%d: fc_chain_fwd %.1f us, fc_chain_bwd %.1f us; checksums %.9e %.9e" % (
+    print(("cold " if os.environ.get("FCC_COLD") == "1" else "") + "variant %s B=%d: fc_chain_fwd %.1f us, fc_chain_bwd %.1f us; checksums %.9e %.9e" % (
         os.environ.get("DVAE_FCC_VARIANT", "default"), B, f, b, buf.d3.double().sum().item(), buf.ga_flat.double().sum().item()))

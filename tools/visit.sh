@@ -30,6 +30,10 @@ if has fccab; then
   echo "== FC chain variants (debug build: DVAE_FCC_VARIANT = 10 * ring depth + contraction split)"
   for v in 81 161 82 162; do DVAE_FCC_VARIANT=$v timeout 120 python tools/fcc_ab.py 128 1024 2>&1 | grep variant; done | tee gpurun_out/${TAG}_fcc_ab.txt
 fi
+if has fcccold; then
+  echo "== FC chain variants with cold caches (debug build)"
+  for v in 82 162 82 162; do FCC_COLD=1 DVAE_FCC_VARIANT=$v timeout 120 python tools/fcc_ab.py 128 1024 2>&1 | grep variant; done | tee gpurun_out/${TAG}_fcc_cold.txt
+fi
 if has fused; then
   echo "== pytest (round-3 kernels)"
   timeout 900 python -m pytest tests/test_gpu_fused_core.py ${FUSED_EXTRA:-} -m gpu -q --timeout=300 --no-header > gpurun_out/${TAG}_pytest_fused.log 2>&1
