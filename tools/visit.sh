@@ -141,6 +141,26 @@ if has dmaabl; then
   wait
   cat gpurun_out/${TAG}_clocks.txt | head -12
 fi
+if has ddp; then
+  echo "== data-parallel code path on one rank (--force-ddp), both transports"
+  line() { python -c "
+import sys, json
+t = sys.stdin.read()
+try:
+    d = json.loads(t); print('$1', d['value'], d['ms_per_step'])
+except Exception:
+    print('$1 FAILED:', t[-300:])"; }
+  BA="--steps 150 --warmup 25 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
+  {
+  for rep in 1 2; do
+    for b in 128 1024; do
+      timeout 200 python bench.py --batch $b $BA 2>&1 | tail -n 1 | line "rep$rep B=$b single process"
+      timeout 200 python bench.py --batch $b --force-ddp $BA 2>&1 | tail -n 1 | line "rep$rep B=$b --force-ddp (torch.distributed)"
+      timeout 200 python bench.py --batch $b --force-ddp --transport rccl $BA 2>&1 | tail -n 1 | line "rep$rep B=$b --force-ddp --transport rccl"
+    done
+  done
+  } | tee gpurun_out/${TAG}_ddp.txt
+fi
 if has kbench; then
   echo "== kbench"
   timeout 300 python tools/kbench.py 1024 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_kbench.txt; grep -E "staged|fc_chain|stage_w|thin|likelihood" gpurun_out/${TAG}_kbench.txt
