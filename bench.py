@@ -461,6 +461,7 @@ def extra_config(name, device, steps, warmup, with_cpu, with_parity):
 
 # ---------------------------------------------------------------------------------- main
 def main():
+    t_main = time.time()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -665,6 +666,7 @@ def main():
         out["configs"] = [extra_config(n, device, steps=min(args.steps, 30), warmup=min(args.warmup, 10),
                                        with_cpu=not args.no_cpu_baseline, with_parity=not args.no_parity_check)
                           for n in ("factor_celeba", "btcvae_dsprites", "factor_dsprites")]
+    out["bench_wall_s"] = round(time.time() - t_main, 1)     # this process, main() entry to the line below (imports excluded)
     flush_c_stdio()
     print(json.dumps(out), flush=True)
     if parity is not None and not parity["ok"]:

@@ -45,7 +45,7 @@ def main(root):
         gui = v.get("GRBM_GUI_ACTIVE", float("nan"))
         mf = v.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan"))
         # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (check:
-        # k_down32ws<16> 92.7 us x 2.4 GHz = 2.2e5 cycles vs GUI 1.76e6): utilisation = busy / (gui / 8 * 1024)
+        # a 32-channel conv kernel at 92.7 us x 2.4 GHz = 2.2e5 cycles vs GUI 1.76e6): utilisation = busy / (gui / 8 * 1024)
         print("| %s | " % k + " | ".join("%.3g" % v.get(c, float("nan")) for c in cols) +
               " | %.1f | %.1f | %.3f |" % (2 * f * 1024 / 1e6, w * 1024 / 1e6, mf / (gui / 8 * 1024) if gui else float("nan")))
 
