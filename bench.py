@@ -223,25 +223,31 @@ def _oracle_hp(cfg):
     return dict(HP, n_data=cfg["n_data"], lr_disc=cfg["lr_disc"])
 
 
+_THREADS = {}
+
+
 def _calibrate_threads(make_step, img):
-    """torch's default of one thread per logical CPU oversubscribes large hosts badly: the fastest of {8,16,32,64,all}
-    on a B = 128 probe is used."""
+    """torch's default of one thread per logical CPU oversubscribes large hosts badly (a 256-thread probe alone takes tens
+    of seconds on a 256-CPU box): the fastest of {8, 16, 32, 64} (or all CPUs of a smaller host) on a B = 128 probe is used.
+    Calibrated ONCE per process: the default bench line times four workloads on the CPU."""
     ncpu = os.cpu_count() or 1
+    if "n" in _THREADS:
+        torch.set_num_threads(_THREADS["n"])
+        return _THREADS["n"], ncpu
     probe = torch.rand((128,) + tuple(img))
     best_t, best_n = None, 1
-    for n in sorted(set([t for t in (8, 16, 32, 64) if t <= ncpu] + [ncpu])):
+    cands = [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]
+    for n in cands:
         torch.set_num_threads(n)
         step = make_step()
         step(probe)
-        dt = None
-        for _ in range(2):               # best of two: a single probe on a shared host is noisy
-            t0 = time.perf_counter()
-            step(probe)
-            d_ = time.perf_counter() - t0
-            dt = d_ if dt is None or d_ < dt else dt
+        t0 = time.perf_counter()
+        step(probe)
+        dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
             best_t, best_n = dt, n
     torch.set_num_threads(best_n)
+    _THREADS["n"] = best_n
     return best_n, ncpu
 
 
@@ -442,6 +448,7 @@ def extra_config(name, device, steps, warmup, with_cpu, with_parity):
     """A BASELINE workload other than the headline one as a short single-GPU leg (outside the headline timed region)."""
     cfg = dict(CONFIGS[name])
     B, C = cfg["batch"], cfg["img"][0]
+    mark("configs:%s:gpu" % name)
     ms, final_loss = time_leg(cfg, B, device, steps, warmup)
     flops_img = flops_per_image_factor(C) if cfg["loss"] == "factor" else flops_per_image_train(C)
     tf = flops_img * B / (ms * 1e-3) / 1e12
@@ -449,10 +456,12 @@ def extra_config(name, device, steps, warmup, with_cpu, with_parity):
            "value": round(B / (ms * 1e-3), 1), "unit": "images/s", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup,
            "step_tflops": round(tf, 2), "step_frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
            "final_loss": round(final_loss, 4)}
+    mark("configs:%s:parity" % name)
     if with_parity:
         pc = parity_check(cfg, B, device)
         out["parity_check"] = {k: pc[k] for k in ("ok", "loss_rel_err", "worst_grad_err_over_max_abs_grad_vs_gate_matched_fp64",
                                                   "units_gated_differently_than_fp64", "seconds")}
+    mark("configs:%s:cpu" % name)
     if with_cpu:
         # bounded sample: at most 256 images per CPU iteration (the oracle's factor iteration at tensor 2048 is ~25 s)
         out["cpu_baseline"] = cpu_baseline(cfg, min(B, 256), iters=3, warm=1)
@@ -460,8 +469,20 @@ def extra_config(name, device, steps, warmup, with_cpu, with_parity):
 
 
 # ---------------------------------------------------------------------------------- main
+_MARKS = []
+
+
+def mark(what):
+    """progress on stderr (a run killed by a time limit still shows where the time went) + the `timing_s` entry of the line"""
+    now = time.time()
+    _MARKS.append((what, now))
+    if len(_MARKS) > 1 and os.environ.get("RANK", "0") == "0":
+        print("[bench] %-28s %6.1f s" % (_MARKS[-2][0], now - _MARKS[-2][1]), file=sys.stderr, flush=True)
+
+
 def main():
     t_main = time.time()
+    mark("setup")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -544,8 +565,10 @@ def main():
     from disvae_amd import parallel
 
     parity = None
+    mark("parity_check")
     if world == 1 and not args.no_parity_check:
         parity = parity_check(cfg, B, device)
+    mark("timed_leg")
 
     torch.manual_seed(1234)
     model = init_specific_model("Burgess", img, 10).to(device)
@@ -647,11 +670,13 @@ def main():
     }
     if parity is not None:
         out["parity_check"] = parity
+    mark("rooflines")
     if not args.no_roofline:
         nimg = B if loss_name != "factor" else B // 2
         fams = kernel_rooflines(nimg, device)
         out["roofline"] = fams[0]           # the family with the largest share of the step
         out["roofline_kernels"] = fams[1:] + thin_kernel_rooflines(nimg, C, device)
+    mark("drop_in")
     if world == 1 and not args.no_drop_in:
         d_steps = min(args.steps, 50)
         d_ms, _ = time_leg(cfg, B, device, d_steps, min(args.warmup, 10), drop_in=True)
@@ -659,13 +684,17 @@ def main():
                           "optimizer": "torch.optim.Adam(model.parameters(), lr) (main.py:208 verbatim, not fused, 28 tensors)",
                           "host_sync": "loss.item() every iteration (Trainer._train_iteration, training.py:164)",
                           "over_timed_configuration": round(d_ms / ms, 3)}
+    mark("cpu_baseline")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, B)
+    mark("configs")
     if world == 1 and not args.force_ddp and not args.no_extra_configs and name == "btcvae_celeba" and not (
             args.batch or args.channels or args.loss):
         out["configs"] = [extra_config(n, device, steps=min(args.steps, 30), warmup=min(args.warmup, 10),
                                        with_cpu=not args.no_cpu_baseline, with_parity=not args.no_parity_check)
                           for n in ("factor_celeba", "btcvae_dsprites", "factor_dsprites")]
+    mark("end")
+    out["timing_s"] = {a[0]: round(b[1] - a[1], 1) for a, b in zip(_MARKS[:-1], _MARKS[1:])}
     out["bench_wall_s"] = round(time.time() - t_main, 1)     # this process, main() entry to the line below (imports excluded)
     flush_c_stdio()
     print(json.dumps(out), flush=True)
