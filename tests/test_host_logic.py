@@ -2,6 +2,7 @@
 state_dict compatibility, annealing / storer cadence, log importance weights."""
 import math
 import os
+import sys
 from collections import defaultdict
 
 import numpy as np
@@ -271,3 +272,81 @@ def test_device_image_loader_draws_batches_like_the_reference_dataloader():
     # no shuffle: slices in order
     ld = DeviceImageLoader(imgs, batch_size=10, shuffle=False, device="cpu")
     assert [x.shape[0] for x, _ in ld] == [10, 10, 10, 7]
+
+
+# ---------------------------------------------------------------------------------- bench.py host logic (no GPU)
+def _bench_module():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_bench_refuses_without_gpu_and_names_the_reason():
+    """no CPU fallback: the benchmark exits with a clear message instead of timing the oracle (tier rule 3)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0
+    assert "no CPU fallback" in (r.stdout + r.stderr)
+
+
+def test_bench_workloads_are_the_baseline_configs():
+    """the four workloads of BASELINE.json (configs[1..4]) by shape, batch, loss and n_data"""
+    import json
+    b = _bench_module()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert set(b.CONFIGS) == {"btcvae_celeba", "factor_celeba", "btcvae_dsprites", "factor_dsprites"}
+    for name, cfg in b.CONFIGS.items():
+        assert cfg["img"] == ((3, 64, 64) if "celeba" in name else (1, 64, 64)) or list(cfg["img"]) == ([3, 64, 64] if "celeba" in name else [1, 64, 64])
+        assert cfg["loss"] == name.split("_")[0]
+        assert cfg["n_data"] == (202599 if "celeba" in name else 737280)
+        assert 1 <= cfg["baseline_config"] < len(base["configs"])
+    assert b.CONFIGS["btcvae_celeba"]["batch"] == 1024 and b.CONFIGS["factor_celeba"]["batch"] == 2048
+    assert b.CONFIGS["btcvae_dsprites"]["batch"] == 256 and b.CONFIGS["factor_dsprites"]["batch"] == 256
+
+
+def test_bench_pmc_traffic_parser(tmp_path, monkeypatch):
+    """`traffic` of the roofline entries = FETCH + WRITE megabytes of the newest committed PMC summary, per kernel prefix"""
+    b = _bench_module()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    hdr = "| kernel | A | FETCH_MB | WRITE_MB | mfma_busy |\n|---|---|---|---|---|\n"
+    (prof / "r02_final_pmc_summary.md").write_text(hdr + "| k_down32dma<16, false> | 1 | 100.0 | 20.0 | 0.5 |\n")
+    (prof / "r03_final_pmc_summary.md").write_text(hdr + "| k_down32dma<16, false> | 1 | 160.0 | 33.6 | 0.6 |\n"
+                                                   "| k_down32dma<16, true> | 1 | 193.6 | 33.6 | 0.5 |\n")
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    val, src = b.pmc_traffic("k_down32dma<16")
+    assert src.endswith("r03_final_pmc_summary.md")
+    assert abs(val - ((160.0 + 33.6) + (193.6 + 33.6)) / 2 * 1e6) < 1.0
+    assert b.pmc_traffic("k_nonexistent") == (None, None)
+
+
+def test_bench_cpu_baseline_leg_runs_the_port_and_calibrates_threads_once(monkeypatch):
+    """the CPU leg (tier rule 4: a bounded sample of the same workload on the host cores) on a tiny batch; the thread count is
+    probed once per process, never with more than 64 threads"""
+    b = _bench_module()
+    seen = []
+    real = torch.set_num_threads
+    monkeypatch.setattr(torch, "set_num_threads", lambda n: (seen.append(n), real(min(n, 4)))[1])
+    monkeypatch.setattr(b, "have_reference", lambda: False)
+    cfg = dict(b.CONFIGS["btcvae_dsprites"])
+    try:
+        r1 = b.cpu_baseline(cfg, 8, iters=1, warm=0)
+        n_probe = len(seen)
+        r2 = b.cpu_baseline(cfg, 8, iters=1, warm=0)
+    finally:
+        real(max(1, min(4, os.cpu_count() or 1)))
+    assert r1["kind"] == "port" and r1["unit"] == "images/s" and r1["value"] > 0 and r1["cores"] == r2["cores"]
+    assert max(seen) <= 64 or max(seen) <= (os.cpu_count() or 1)
+    assert len(seen) - n_probe == 1, "the second leg re-uses the calibrated thread count"
