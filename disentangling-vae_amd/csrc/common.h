@@ -210,7 +210,7 @@ int launch_add(const float* a, const float* b, float* out, long n, hipStream_t s
 
 bool use_generic_only();  // DVAE_FORCE_GENERIC=1 (on-device reference path of the parity tests, still HIP)
 
-// A/B and timing-ablation switches (DVAE_DOWN_V1, DVAE_ABLATE, ...) and the experimental kernel variants they
+// A/B and timing-ablation switches (DVAE_UP_WS, DVAE_DMA_ABLATE, DVAE_FCC_VARIANT, ...) and the kernel variants they
 // select exist only in a library built with -DDVAE_DEBUG_SWITCHES (python build.py --debug); the shipped
 // library compiles them out.  A switch is ON only for the value "1" (integers: atoi of the value).
 #ifdef DVAE_DEBUG_SWITCHES
