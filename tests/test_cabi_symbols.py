@@ -50,3 +50,41 @@ def test_graft_entry_build_runs():
     g.build()
     hdr = open(os.path.join(root, "include", "dvae_hip.h")).read()
     assert int(re.search(r"#define DVAE_VERSION (\d+)", hdr).group(1)) == _lib.lib().dvae_version()
+
+
+def test_argument_structs_have_the_headers_layout(tmp_path):
+    """The by-pointer argument blocks (dvae_*_image_desc, dvae_fc_chain_*_args) as the C header lays them out (gcc, the
+    header is plain C) == the ctypes mirrors in disvae_amd/_lib.py: size, and name / offset / size of every field in order.
+    A silent mismatch here would hand a kernel the wrong pointers."""
+    import ctypes
+    import shutil
+    import subprocess
+    from disvae_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    pairs = [("dvae_conv_image_desc", _lib.ConvImageDesc), ("dvae_fc_image_desc", _lib.FcImageDesc),
+             ("dvae_thin_image_desc", _lib.ThinImageDesc), ("dvae_fc_chain_fwd_args", _lib.FcChainFwdArgs),
+             ("dvae_fc_chain_bwd_args", _lib.FcChainBwdArgs)]
+    body = []
+    for cname, cls in pairs:
+        body.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            body.append('printf("%s.%s %%zu %%zu\\n", offsetof(%s, %s), sizeof(((%s*)0)->%s));' % (cname, fname, cname, fname, cname, fname))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dvae_hip.h"\nint main(void) {\n' + "\n".join(body) + "\nreturn 0;\n}\n")
+    exe = tmp_path / "layout"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict((l.split()[0], [int(x) for x in l.split()[1:]]) for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert got[cname] == [ctypes.sizeof(cls)], (cname, got[cname], ctypes.sizeof(cls))
+        for fname, ftype in cls._fields_:
+            f = getattr(cls, fname)
+            assert got["%s.%s" % (cname, fname)] == [f.offset, f.size], (cname, fname, got["%s.%s" % (cname, fname)], f.offset, f.size)
+    # ... and the header declares no further members (sizes match and the last field ends at the padded size)
+    hdr = open(os.path.join(root, "include", "dvae_hip.h")).read()
+    for cname, cls in pairs:
+        decl = hdr[:hdr.index("} %s;" % cname)]
+        decl = decl[decl.rindex("typedef struct"):]
+        names = re.findall(r"[\*\s,]([A-Za-z_][A-Za-z_0-9]*)\s*(?=[,;])", re.sub(r"/\*.*?\*/", "", decl, flags=re.S))
+        assert names == [n for n, _ in cls._fields_], (cname, names)
