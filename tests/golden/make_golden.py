@@ -18,6 +18,7 @@ from collections import defaultdict, OrderedDict
 
 import numpy as np
 import torch
+torch.set_num_threads(8)      # the digests compare fp32 CPU gradients at rtol 2e-5: the thread count fixes the reduction order (tests/conftest.py)
 
 REF = os.environ.get("DVAE_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))

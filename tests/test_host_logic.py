@@ -346,7 +346,7 @@ def test_bench_cpu_baseline_leg_runs_the_port_and_calibrates_threads_once(monkey
         n_probe = len(seen)
         r2 = b.cpu_baseline(cfg, 8, iters=1, warm=0)
     finally:
-        real(before)             # the golden-vector tests that follow were recorded with the default thread count
+        real(before)
     assert r1["kind"] == "port" and r1["unit"] == "images/s" and r1["value"] > 0 and r1["cores"] == r2["cores"]
     assert max(seen) <= 64 or max(seen) <= (os.cpu_count() or 1)
     assert len(seen) - n_probe == 1, "the second leg re-uses the calibrated thread count"

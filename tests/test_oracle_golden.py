@@ -9,6 +9,8 @@ import torch
 from oracle import disvae_oracle as O
 from golden_util import load, tensor_digest, assert_digest_close
 
+pytestmark = pytest.mark.usefixtures("golden_threads")     # the digests were recorded with 8 torch threads (conftest.py)
+
 HP = dict(rec_dist="bernoulli", reg_anneal=10000, betaH_B=4, betaB_initC=0, betaB_finC=25,
           betaB_G=1000, factor_G=6.4, latent_dim=10, lr_disc=1e-4, btcvae_A=1, btcvae_B=6.4,
           btcvae_G=1)
