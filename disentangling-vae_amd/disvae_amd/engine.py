@@ -106,7 +106,7 @@ class ParamArena:
 
 # which encoder conv weight gradients the MAIN stream computes itself at the very end of the backward pass (after conv1's),
 # instead of leaving them in the side stream's queue: the side stream is the tail of the iteration (timeline:
-# profiles/r02_run9_timeline.md), the main stream is idle from the end of conv1's weight gradient to the join
+# profiles/r02_final_timeline.md), the main stream is idle from the end of conv1's weight gradient to the join
 # (measured -1.5 %: profiles/r02_run12_tail_ab.txt)
 _TAIL_MAIN = ("conv3", "conv_64")
 
