@@ -99,15 +99,16 @@ def kats(losses, dmath):
     return out
 
 
-def run_case(ref, loss_name, img_size, batch, n_steps, seed, n_data, lr, rec_dist="bernoulli"):
+def run_case(ref, loss_name, img_size, batch, n_steps, seed, n_data, lr, rec_dist="bernoulli", latent_dim=10):
     """Run the reference Trainer._train_iteration n_steps times; record everything."""
     disvae, losses, vae, discriminator, dmath, training = ref
     torch.manual_seed(seed)
-    model = vae.init_specific_model("Burgess", img_size, 10)
+    model = vae.init_specific_model("Burgess", img_size, latent_dim)
     init_state = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     kw = dict(HP)
     kw["rec_dist"] = rec_dist
+    kw["latent_dim"] = latent_dim
     loss_f = losses.get_loss_f(loss_name, n_data=n_data, device=torch.device("cpu"), **kw)
     init_dstate = None
     if loss_name == "factor":
@@ -121,6 +122,7 @@ def run_case(ref, loss_name, img_size, batch, n_steps, seed, n_data, lr, rec_dis
     out["seed"] = np.int64(seed)
     out["n_data"] = np.int64(n_data)
     out["lr"] = np.float64(lr)
+    out["latent_dim"] = np.int64(latent_dim)
     for k, v in init_state.items():
         out["init_digest/" + k] = tensor_digest(v)
     if init_dstate is not None:
@@ -208,6 +210,15 @@ def main():
         return
     ref = import_reference()
     _, losses, vae, discriminator, dmath, training = ref
+    if "--latent" in sys.argv:        # latent dimensions other than the default 10 (main.py -z): only these files are written
+        for name, loss, img, b, steps, seed, n_data, lr, zdim in [
+                ("btcvae_z16_dsprites", "btcvae", (1, 64, 64), 8, 2, 4321, 737280, 5e-4, 16),
+                ("btcvae_z3_mnist", "btcvae", (1, 32, 32), 6, 2, 4321, 60000, 5e-4, 3),
+                ("betaB_z16_celeba", "betaB", (3, 64, 64), 4, 2, 4321, 202599, 5e-4, 16)]:
+            out = run_case(ref, loss, img, b, steps, seed, n_data, lr, latent_dim=zdim)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "loss", [out["step%d/loss" % s] for s in range(steps)])
+        return
     np.savez_compressed(os.path.join(HERE, "kats.npz"), **kats(losses, dmath))
     cases = [
         # name,           loss,     img_size,    B, steps, seed, n_data,  lr

@@ -96,6 +96,42 @@ def test_single_optimizer_cases(name, loss, img, batch, steps):
                                 what="%s step%d param %s" % (name, s, k))
 
 
+@pytest.mark.parametrize("name,loss,img,batch,steps,zdim", [
+    ("btcvae_z16_dsprites", "btcvae", (1, 64, 64), 8, 2, 16),
+    ("btcvae_z3_mnist", "btcvae", (1, 32, 32), 6, 2, 3),
+    ("betaB_z16_celeba", "betaB", (3, 64, 64), 4, 2, 16),
+])
+def test_other_latent_dimensions(name, loss, img, batch, steps, zdim):
+    """main.py -z: latent dimensions other than 10 (the largest the native engine takes, and a small one), recorded from the
+    real reference with `make_golden.py --latent`: initial weights bit for bit, losses, storer scalars, gradients, parameters"""
+    g = load(name)
+    assert int(g["latent_dim"]) == zdim
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    params = O.init_vae_params(img, zdim)
+    for k, v in params.items():
+        np.testing.assert_array_equal(tensor_digest(v), g["init_digest/" + k], err_msg=k)
+    hp = dict(HP, n_data=int(g["n_data"]), latent_dim=zdim)
+    tr = O.OracleTrainer(loss, hp, img, zdim, lr=float(g["lr"]), rec_dist="bernoulli", steps_anneal=HP["reg_anneal"], params=params)
+    gen = torch.Generator().manual_seed(seed + 1)
+    for s in range(steps):
+        data = torch.rand((batch,) + tuple(img), generator=gen)
+        eps = torch.from_numpy(g["step%d/randn0" % s])
+        assert eps.shape == (batch, zdim)
+        loss_val, logs = tr.train_iteration(data, eps=eps)
+        np.testing.assert_allclose(loss_val, g["step%d/loss" % s], rtol=2e-6)
+        if s == 0:
+            for k in logs:
+                np.testing.assert_allclose(logs[k].item(), g["step0/storer/" + k], rtol=1e-5, atol=1e-6, err_msg=k)
+            assert set(logs) == {k.split("/")[-1] for k in g if k.startswith("step0/storer/")}
+            assert sum(k.startswith("kl_loss_") for k in logs) == zdim
+        for k, p in tr.params.items():
+            assert_digest_close(tensor_digest(p.grad), g["step%d/grad_digest/%s" % (s, k)], rtol=2e-5,
+                                what="%s step%d grad %s" % (name, s, k))
+            assert_digest_close(tensor_digest(p), g["step%d/param_digest/%s" % (s, k)], rtol=2e-5,
+                                what="%s step%d param %s" % (name, s, k))
+
+
 @pytest.mark.parametrize("name,img", [("factor_dsprites", (1, 64, 64)), ("factor_celeba", (3, 64, 64))])
 def test_factor_cases(name, img):
     g = load(name)
