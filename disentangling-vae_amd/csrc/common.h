@@ -156,6 +156,11 @@ int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int
 int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, float* ws,
                         size_t ws_floats, hipStream_t s);
 
+// gemm_dma.hip: LDS-DMA GEMMs for the large (discriminator) shapes; true if the launch was taken
+bool try_gdma(bool b_jfast, const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
+              const float* bias, int act, const float* mask, int mask_act, hipStream_t s);
+bool try_gdma_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, hipStream_t s);
+
 size_t latent_entropy_ws_floats(long N, int D, int S);
 int launch_latent_entropy(const float* z_ds, const float* mean, const float* logvar, long N, int D, int S, float* ws,
                           float* H, hipStream_t s);

@@ -551,216 +551,8 @@ static bool try_fcw32(const float* x, const float* dy, float* dw, float* db, int
   return true;
 }
 
-// ---- large FC GEMM (the 1000-wide discriminator layers): TM x 64 output tile, contraction in slabs of 64 ----
-// 4 waves; wave w owns rows (w&1)*TM/2 .. +TM/2 and columns (w>>1)*32 .. +32 of the tile, i.e. TM/64 accumulators of
-// 32x32 that share one B fragment.  Operand tiles are double-buffered in LDS ([row][64+4] images, 16-byte operand
-// reads through the permuted contraction index kappa = h*32 + t of k_fc32; the j-fast B of the dgrad form as a
-// [kappa][64] image whose upper half is skewed by 32 floats so that the two lane halves use disjoint banks).
-//   A(i,k) = a[i*lda + k];  B_JFAST ? B(k,j) = b[k*ldb + j] (dgrad)  :  B(k,j) = b[j*ldb + k] (forward)
-// Memory pipeline interleaved into the MFMA stream.  PMC on a phase-separated version of this kernel
-// (profiles/r01_run41_gemm_pmc.txt): 43 % MFMA-busy; the one wave per SIMD spent half of its cycles outside the
-// MFMA phase (address arithmetic, global-load issue, predication, LDS stores, barrier).  A wave is in-order, but
-// while an MFMA occupies the pipe (64 cycles) it can issue other work for free.  Slab j lives in register set
-// j&1 and LDS image j&1; iteration s
-// multiplies slab s while it ISSUES the global loads of slab s+2 between its first MFMAs and WRITES slab s+1
-// (loaded one iteration earlier: two-slab prefetch distance, longer than the memory latency) to LDS between its
-// later MFMAs -- the order is pinned with sched_group_barrier.  Rows / columns outside the matrices are read from
-// clamped addresses (they only feed outputs that are never stored); only A's contraction tail is zeroed.
-template <int TM, bool B_JFAST>
-__global__ __launch_bounds__(256) void k_gemm_big(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
-                                                 float* __restrict__ c, long ldc, int M, int N, int Kc,
-                                                 const float* __restrict__ bias, int act,
-                                                 const float* __restrict__ mask, int mask_act) {
-  extern __shared__ __attribute__((aligned(16))) float fc_lds[];
-  constexpr int KS = 64, SA = KS + 4;
-  constexpr int A_FLOATS = TM * SA;
-  constexpr int B_FLOATS = B_JFAST ? KS * 64 + 32 : 64 * SA;
-  constexpr int NLA = TM / 16, NLB = 4, NACC = TM / 64;
-  float* As = fc_lds;
-  float* Bs = fc_lds + 2 * A_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 31, h = lane >> 5;
-  int tm, tn;
-  {
-    const int tiles_n = gridDim.x, T = gridDim.x * gridDim.y;
-    const int L = blockIdx.y * gridDim.x + blockIdx.x;
-    const int xcd = L & 7, slot = L >> 3, per = T >> 3, rem = T & 7;
-    const int t = xcd * per + (xcd < rem ? xcd : rem) + slot;
-    tm = t / tiles_n; tn = t - tm * tiles_n;
-  }
-  const int m0 = tm * TM, n0 = tn * 64;
-  const int r0 = (wv & 1) * (TM / 2), c0 = (wv >> 1) * 32;
-  const int trow = tid >> 4, c4 = (tid & 15) * 4;          // this thread's row (+16p) and 16-byte column in a slab
-
-  // invariant source pointers (slab offset added per load)
-  const float* pa[NLA];
-#pragma unroll
-  for (int p = 0; p < NLA; ++p) { const int gi = m0 + trow + 16 * p; pa[p] = a + (long)(gi < M ? gi : M - 1) * lda + c4; }
-  const float* pb[NLB];
-#pragma unroll
-  for (int p = 0; p < NLB; ++p) {
-    if (!B_JFAST) { const int gj = n0 + trow + 16 * p; pb[p] = b + (long)(gj < N ? gj : N - 1) * ldb + c4; }
-    else { const int gj = n0 + c4; pb[p] = b + (long)(trow + 16 * p) * ldb + (gj < N ? gj : 0); }
-  }
-  f32x4 ra[2][NLA], rb[2][NLB];
-  bool okk[2];
-  const int klast = ((Kc + KS - 1) / KS - 1) * KS;
-
-  // one 16-byte global load / LDS store of the slab pipeline (index l: first the A chunks, then the B chunks)
-  int kslab[2], kofs[2];
-  auto slab_begin = [&](auto PAR, int k0) {
-    constexpr int P = decltype(PAR)::value;
-    k0 = k0 < klast ? k0 : klast;                          // past the end: re-load the last slab (never used)
-    okk[P] = k0 + c4 < Kc;
-    kslab[P] = k0;
-    kofs[P] = okk[P] ? k0 : -c4;                           // contraction tail: stay inside the row (value zeroed at the store)
-  };
-  auto load_one = [&](auto PAR, int l) {
-    constexpr int P = decltype(PAR)::value;
-    if (l < NLA) { ra[P][l] = *reinterpret_cast<const f32x4*>(pa[l] + kofs[P]); return; }
-    const int p = l - NLA;
-    if (!B_JFAST) rb[P][p] = *reinterpret_cast<const f32x4*>(pb[p] + kofs[P]);
-    else { const int kap = kslab[P] + trow + 16 * p; rb[P][p] = *reinterpret_cast<const f32x4*>(pb[p] + (long)(kap < Kc ? kslab[P] : -(trow + 16 * p)) * ldb); }
-  };
-  auto store_one = [&](auto PAR, int l) {
-    constexpr int P = decltype(PAR)::value;
-    float* Ab = As + P * A_FLOATS;
-    float* Bb = Bs + P * B_FLOATS;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    if (l < NLA) { *reinterpret_cast<f32x4*>(Ab + (trow + 16 * l) * SA + c4) = okk[P] ? ra[P][l] : zero; return; }
-    const int p = l - NLA;
-    if (!B_JFAST) *reinterpret_cast<f32x4*>(Bb + (trow + 16 * p) * SA + c4) = rb[P][p];
-    else { const int kap = trow + 16 * p; *reinterpret_cast<f32x4*>(Bb + kap * 64 + (kap >= 32 ? 32 : 0) + c4) = rb[P][p]; }
-  };
-  constexpr int NLD = NLA + NLB;           // 16-byte chunks per thread and slab
-  auto load = [&](auto PAR, int k0) {
-    slab_begin(PAR, k0);
-#pragma unroll
-    for (int l = 0; l < NLD; ++l) load_one(PAR, l);
-  };
-  auto store = [&](auto PAR) {
-#pragma unroll
-    for (int l = 0; l < NLD; ++l) store_one(PAR, l);
-  };
-
-  f32x16 acc[NACC];
-#pragma unroll
-  for (int q = 0; q < NACC; ++q)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
-
-#ifdef DVAE_DEBUG_SWITCHES
-  const int abl = act >> 8;                // timing ablations (tools/gemm_one.py): 1 no global loads, 2 no LDS stores, 4 no barriers
-#else
-  constexpr int abl = 0;
-#endif
-  act &= 0xff;
-  // One slab = 8 steps of 4*NACC MFMAs.  Every step also carries its share of the memory pipeline IN PROGRAM ORDER --
-  // steps 0-3 issue the global loads of slab s+2, steps 4-7 the LDS stores of slab s+1 -- and ends with a scheduling
-  // fence, so that those instructions are issued in the shadow of this step's MFMAs instead of in phases of their own.
-  auto body = [&](auto PAR, int sl) {
-    constexpr int P = decltype(PAR)::value;
-    using Q = std::integral_constant<int, 1 - P>;
-    slab_begin(PAR, (sl + 2) * KS);
-    const float* Ab = As + P * A_FLOATS + (r0 + i) * SA + h * 32;
-    const float* Bb = Bs + P * B_FLOATS + (B_JFAST ? h * (32 * 64 + 32) + c0 + i : (c0 + i) * SA + h * 32);
-    f32x4 av[2][NACC], bv[2];
-    auto rd = [&](int q, int slot) {
-#pragma unroll
-      for (int t = 0; t < NACC; ++t) av[slot][t] = *reinterpret_cast<const f32x4*>(Ab + t * 32 * SA + 4 * q);
-      if (B_JFAST) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bv[slot][u] = Bb[(4 * q + u) * 64];
-      } else {
-        bv[slot] = *reinterpret_cast<const f32x4*>(Bb + 4 * q);
-      }
-    };
-    constexpr int PER = (NLD + 3) / 4;     // chunks per step
-    rd(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (q + 1 < 8) rd(q + 1, (q + 1) & 1);
-      if (q < 4) {
-        if (!(abl & 1)) {
-#pragma unroll
-          for (int l = q * PER; l < (q + 1) * PER && l < NLD; ++l) load_one(PAR, l);
-        }
-      } else if (!(abl & 2)) {
-#pragma unroll
-        for (int l = (q - 4) * PER; l < (q - 3) * PER && l < NLD; ++l) store_one(Q{}, l);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < NACC; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][t][u], bv[q & 1][u], acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!(abl & 4)) __syncthreads();
-  };
-
-  const int nslab = (Kc + KS - 1) / KS;
-  load(std::integral_constant<int, 0>{}, 0);
-  store(std::integral_constant<int, 0>{});
-  load(std::integral_constant<int, 1>{}, KS);
-  __syncthreads();
-  for (int sl = 0; sl < nslab; sl += 2) {
-    body(std::integral_constant<int, 0>{}, sl);
-    if (sl + 1 < nslab) body(std::integral_constant<int, 1>{}, sl + 1);
-  }
-
-  const int col = n0 + c0 + i;
-#pragma unroll
-  for (int t = 0; t < NACC; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = m0 + r0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (row < M && col < N) {
-        float v = acc[t][e];
-        if (bias) v += bias[col];
-        if (act == DVAE_ACT_RELU) v = v > 0.f ? v : 0.f;
-        else if (act == DVAE_ACT_LEAKY02) v = v > 0.f ? v : 0.2f * v;
-        const long o = (long)row * ldc + col;
-        if (mask) {
-          const float mv = mask[o];
-          if (mask_act == DVAE_ACT_RELU) v = mv > 0.f ? v : 0.f;
-          else if (mask_act == DVAE_ACT_LEAKY02) v = mv > 0.f ? v : 0.2f * v;
-        }
-        c[o] = v;
-      }
-    }
-}
-
-template <int TM, bool BJ>
-static void launch_gemm_big_t(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
-                             const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
-  const size_t lds = sizeof(float) * 2 * (TM * 68 + (BJ ? 64 * 64 + 32 : 64 * 68));
-  static DeviceOnce attr;
-  if (attr.first()) {
-    (void)hipFuncSetAttribute((const void*)k_gemm_big<TM, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
-  static const int abl = env_int("DVAE_GEMM_ABLATE", 0);   // timing ablation, debug builds only (results invalid)
-  hipLaunchKernelGGL((k_gemm_big<TM, BJ>), dim3((N + 63) / 64, (M + TM - 1) / TM), dim3(256), lds, s, a, lda, b, ldb, c, ldc,
-                     M, N, Kc, bias, act | (abl << 8), mask, mask_act);
-}
-
-// true if the launch was taken: long contractions and wide outputs with 16-byte-aligned rows
-template <bool BJ>
-static bool try_gemm_big(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
-                         const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
-  static const bool off = env_off("DVAE_GEMM_BIG");   // A/B switch, debug builds only
-  if (off || Kc < 256 || N < 128 || Kc % 4 || lda % 4 || ldb % 4 || (BJ && N % 4)) return false;
-  if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return false;
-  // TM = 64 -> 2 workgroups per CU (70 KB of LDS each): measured 76.7 vs 69.6 TFLOP/s for TM = 128 at 2048x1000x1000
-  static const int force_tm = env_int("DVAE_GEMM_TM", 0);        // A/B switch, debug builds only
-  if (force_tm == 128) launch_gemm_big_t<128, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
-  else launch_gemm_big_t<64, BJ>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
-  return true;
-}
-
-// small problems (everything in the VAE) go to k_gemm32; large ones (discriminator) to k_gemm
+// (the large discriminator shapes are taken by the LDS-DMA kernels of gemm_dma.hip before this point)
+// small problems (everything in the VAE) go to k_gemm32; the remaining large ones (unaligned rows) to k_gemm
 // measured (profiles/r01_run12): k_gemm32 wins only for the forward form with 16-byte loads on both
 // operands (11.2 vs 13.3 us at 1024x512x256); the lane-contiguous dgrad / wgrad forms are slower than the
 // LDS-staged split-K kernel (16.4 vs 14.0, 22.9 vs 14.6 us) -> forward only unless DVAE_GEMM_SMALL=all
@@ -829,7 +621,7 @@ int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, 
                       size_t ws_floats, hipStream_t s) {
   // A = x (k contiguous), B(k,j) = w[j*K + k] (k contiguous)
   if (try_fc32<false>(x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s) ||
-      try_gemm_big<false>(x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s)) {
+      try_gdma(false, x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s)) {
     DVAE_CHECK_LAUNCH();
     return 0;
   }
@@ -867,7 +659,7 @@ int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int
                         float* ws, size_t ws_floats, hipStream_t s) {
   // dx[M,K] = dy[M,N] w[N,K]: contraction length N
   if (try_fc32<true>(dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s) ||
-      try_gemm_big<true>(dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s)) {
+      try_gdma(true, dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s)) {
     DVAE_CHECK_LAUNCH();
     return 0;
   }
@@ -906,7 +698,7 @@ int launch_linear_wgrad(const float* x, const float* dy, float* dw, float* db, i
                         size_t ws_floats, hipStream_t s) {
   // dw[N,K] = dy^T[N,M] x[M,K]: contraction length M (the batch); db[n] = sum_m dy[m][n] = row sums of A.
   // Few output tiles + a long contraction: split the batch over gridDim.z and reduce (fixed order).
-  if (try_fcw32(x, dy, dw, db, M, K, N, s)) {
+  if (try_gdma_wgrad(x, dy, dw, db, M, K, N, s) || try_fcw32(x, dy, dw, db, M, K, N, s)) {
     DVAE_CHECK_LAUNCH();
     return 0;
   }

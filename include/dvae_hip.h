@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DVAE_VERSION 103
+#define DVAE_VERSION 104
 
 /* latent dimensions the fused kernels cover (the reference's --latent-dim is 10 in every experiment of
  * hyperparam.ini): reparameterisation / KL / scalar slots, the FC chain and the beta-TCVAE estimator up to 16.
