@@ -64,19 +64,25 @@ __device__ __forceinline__ void gdma_tile(int tiles_m, int tiles_n, int* tm, int
   }
 }
 
-template <int TM_, int KS_, int D_>
+template <int TM_, int TN_, int KS_, int D_, int NWK_>
 struct GdmaGeo {
-  static constexpr int TM = TM_, KS = KS_, D = D_, NS = D_ + 1;
+  static constexpr int TM = TM_, TN = TN_, KS = KS_, D = D_, NS = D_ + 1, NWK = NWK_;
   static constexpr int CPR = KS / 4;                     // 16-byte chunks per row of a k-contiguous tile
   static constexpr int RPB = 64 / CPR;                   // its rows per 1 KB transfer
   static constexpr int SWD = 16 / CPR;                   // rows that share a swizzle value
   static constexpr int NBA = TM * KS / 256;              // transfers per slab: A tile
-  static constexpr int NBB = 64 * KS / 256;              //                     B tile (either orientation)
+  static constexpr int NBB = TN * KS / 256;              //                     B tile (either orientation)
   static constexpr int P = (NBA + NBB) / 4;              // per loader wave
-  static constexpr int STAGE_FLOATS = (TM + 64) * KS;
+  static constexpr int STAGE_FLOATS = (TM + TN) * KS;
   static constexpr int NR = KS / 8;                      // rounds (4 MFMAs per accumulator) per slab
-  static constexpr int NACC = TM / 64;
-  static_assert((NBA + NBB) % 4 == 0 && NR % 2 == 0 && (D - 2) * P < 64 && D >= 2, "geometry");
+  // the four MFMA waves: NWN column blocks of 32 x NWM row blocks x NWK shares of every slab's rounds
+  static constexpr int NWN = TN / 32, NWM = 4 / (NWN * NWK);
+  static constexpr int NACC = TM / NWM / 32;             // 32-row accumulators per wave
+  static constexpr int NRW = NR / NWK;                   // rounds per wave and slab
+  static constexpr int JCH = TN / 4, JRPB = 256 / TN;    // contraction-slow B tile: chunks per row, rows per transfer
+  static_assert((NBA + NBB) % 4 == 0 && NRW % 2 == 0 && NRW * NWK == NR && (D - 2) * P < 64 && D >= 2, "geometry");
+  static_assert(NWN * NWM * NWK == 4 && NACC * NWM * 32 == TM && (TN == 32 || TN == 64), "wave layout");
+  static_assert(NWK == 1 || NS * STAGE_FLOATS >= NWK * 16 * 64, "the ring holds the partial tiles of the final sum");
   __host__ __device__ static constexpr int swz(int r) { return (r / SWD) & (CPR - 1); }
 };
 
@@ -84,25 +90,27 @@ struct GdmaGeo {
 //   B_JFAST = false: B(k,j) = b[j*ldb + k]  (forward:  y  = act(x w^T + bias))
 //   B_JFAST = true : B(k,j) = b[k*ldb + j]  (dgrad:    dx = (dy w) * act'(mask))
 // Requirements (checked by the launcher): Kc % 4 == lda % 4 == ldb % 4 == 0, N % 4 == 0 for B_JFAST, 16-byte aligned bases.
+// Tile TM x TN; NWK > 1: the MFMA waves share one 32 x 32 output block and split every slab's rounds among themselves
+// (small batches: 32 x 32 tiles give every CU a workgroup at M = 256), partial blocks summed through LDS in wave order.
 // ABL: timing ablations, compile-time so that the instruction schedule of the surviving parts is the shipped one
 // (DVAE_GDMA_ABLATE, debug builds only): 1 no transfers, 2 no LDS operand reads (results invalid); 8 loader waves NOT at
 // s_setprio 2 (results valid).  Measured and dropped (profiles/r04_v4_variants.txt, r04_v5_variants.txt): ring depth D = 3 / 5
 // (equal), KS = 64 with D = 2 at TM = 128 (+12 %), 8 loader waves (equal), s_setprio 1 on the MFMA waves (equal), plain
 // row-major tile order (+1 %).
-template <int TM, int KS, int D, bool B_JFAST, int ABL = 0>
+template <int TM, int TN, int KS, int D, int NWK, bool B_JFAST, int ABL = 0>
 __global__ __launch_bounds__(512) void k_gdma(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
                                               float* __restrict__ c, long ldc, int M, int N, int Kc,
                                               const float* __restrict__ bias, int act,
                                               const float* __restrict__ mask, int mask_act, int tiles_m, int tiles_n,
                                               int vec_ok) {
-  using G = GdmaGeo<TM, KS, D>;
+  using G = GdmaGeo<TM, TN, KS, D, NWK>;
   constexpr int abl = ABL;
   extern __shared__ __attribute__((aligned(16))) float gd_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tm, tn;
   gdma_tile(tiles_m, tiles_n, &tm, &tn);
-  const int m0 = tm * TM, n0 = tn * 64;
+  const int m0 = tm * TM, n0 = tn * TN;
   const int nslab = (Kc + KS - 1) / KS;
 
   if (wv >= 4) {
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(512) void k_gdma(const float* __restrict__ a, long 
         if (klast + 4 * q < Kc) tail_ok |= 1u << p;
       } else {
         const int blk = g - G::NBA;
-        const int kk = blk * 4 + (lane >> 4), col = n0 + 4 * (lane & 15);
+        const int kk = blk * G::JRPB + lane / G::JCH, col = n0 + 4 * (lane % G::JCH);
         const bool col_ok = col < N;
         src[p] = col_ok ? reinterpret_cast<const char*>(b + (long)kk * ldb + col) : reinterpret_cast<const char*>(k_gdma_zero16);
         step[p] = col_ok ? (unsigned)(KS * ldb * 4) : 0u;
@@ -169,18 +177,19 @@ __global__ __launch_bounds__(512) void k_gdma(const float* __restrict__ a, long 
       gdma_barrier();
       isb = isb + 1 == G::NS ? 0 : isb + 1;
     }
+    if (NWK > 1) gdma_barrier();                           // the barrier of the final sum
     return;
   }
 
   // -------------------------------------------------------------------------------------------------- MFMA waves
   const int i = lane & 31, h = lane >> 5;
-  const int wi = wv & 1, wj = wv >> 1;
-  // operand read offsets (floats, relative to a stage)
-  int offr[G::NR];                                         // k-contiguous tiles: row i, round rr -> swizzled chunk of this lane half
+  const int wj = wv % G::NWN, wi = (wv / G::NWN) % G::NWM, wk = wv / (G::NWN * G::NWM);
+  // operand read offsets (floats, relative to a stage): this wave's rounds of a slab are wk NRW .. wk NRW + NRW - 1
+  int offr[G::NRW];                                        // k-contiguous tiles: row i, round -> swizzled chunk of this lane half
 #pragma unroll
-  for (int rr = 0; rr < G::NR; ++rr) offr[rr] = i * KS + (((2 * rr + h) ^ G::swz(i)) << 2);
-  const int a_base = wi * (TM / 2) * KS;
-  const int b_base = TM * KS + (B_JFAST ? 4 * h * 64 + wj * 32 + i : wj * 32 * KS);
+  for (int j = 0; j < G::NRW; ++j) offr[j] = i * KS + (((2 * (wk * G::NRW + j) + h) ^ G::swz(i)) << 2);
+  const int a_base = wi * (TM / G::NWM) * KS;
+  const int b_base = TM * KS + (B_JFAST ? (8 * wk * G::NRW + 4 * h) * TN + wj * 32 + i : wj * 32 * KS);
 
   constexpr int NCH = G::NACC == 1 ? 2 : 1;                // accumulator chains per 32x32 output block
   f32x16 acc[G::NACC][NCH];
@@ -200,15 +209,15 @@ __global__ __launch_bounds__(512) void k_gdma(const float* __restrict__ a, long 
       for (int t = 0; t < G::NACC; ++t) av[q][t] = f32x4{1.f, 2.f + lane, 3.f, 4.f};
     }
   }
-  auto rd = [&](const float* st, int rr, int slot) {
+  auto rd = [&](const float* st, int j, int slot) {        // round j of this wave's share of a slab
     if (abl & 2) return;
 #pragma unroll
-    for (int t = 0; t < G::NACC; ++t) av[slot][t] = *reinterpret_cast<const f32x4*>(st + a_base + t * 32 * KS + offr[rr]);
+    for (int t = 0; t < G::NACC; ++t) av[slot][t] = *reinterpret_cast<const f32x4*>(st + a_base + t * 32 * KS + offr[j]);
     if (B_JFAST) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) bv[slot][u] = st[b_base + (8 * rr + u) * 64];
+      for (int u = 0; u < 4; ++u) bv[slot][u] = st[b_base + (8 * j + u) * TN];
     } else {
-      bv[slot] = *reinterpret_cast<const f32x4*>(st + b_base + offr[rr]);
+      bv[slot] = *reinterpret_cast<const f32x4*>(st + b_base + offr[j]);
     }
   };
 
@@ -220,9 +229,9 @@ __global__ __launch_bounds__(512) void k_gdma(const float* __restrict__ a, long 
     const int nxt = cur + 1 == G::NS ? 0 : cur + 1;
     const float* stn = gd_lds + nxt * G::STAGE_FLOATS;
 #pragma unroll
-    for (int rr = 0; rr < G::NR; ++rr) {
-      const int sl = rr & 1;
-      if (rr + 1 < G::NR) rd(st, rr + 1, sl ^ 1);
+    for (int j = 0; j < G::NRW; ++j) {
+      const int sl = j & 1;
+      if (j + 1 < G::NRW) rd(st, j + 1, sl ^ 1);
       else rd(stn, 0, sl ^ 1);                             // slab s + 1 was certified by the previous barrier (unused after the last slab)
       // transposed product: MFMA A operand = the weight fragment (rows of D = output columns), B operand = batch rows
 #pragma unroll
@@ -237,51 +246,69 @@ __global__ __launch_bounds__(512) void k_gdma(const float* __restrict__ a, long 
     cur = nxt;
   }
 
-  // ---- epilogue: lane (i, h) of accumulator t holds row m0 + wi TM/2 + 32 t + i, columns n0 + 32 wj + 8 g + 4 h + (0..3)
+  // ---- epilogue: lane (i, h) of accumulator t holds row m0 + wi TM/NWM + 32 t + i, columns n0 + 32 wj + 8 g + 4 h + (0..3)
   // in registers 4 g .. 4 g + 3: bias, activation, mask (act'(x_act) of the producing layer) on 16-byte accesses
   const int colb = n0 + wj * 32 + 4 * h;
+  auto finish = [&](int row, int g, f32x4 v) {
+    const int col = colb + 8 * g;
+    if (row >= M || col >= N) return;
+    const long o = (long)row * ldc + col;
+    f32x4 bb = {0.f, 0.f, 0.f, 0.f}, mv = {1.f, 1.f, 1.f, 1.f};
+    if (vec_ok) {
+      if (bias) bb = *reinterpret_cast<const f32x4*>(bias + col);
+      if (mask) mv = *reinterpret_cast<const f32x4*>(mask + o);
+    } else {
 #pragma unroll
-  for (int t = 0; t < G::NACC; ++t) {
-    f32x16 r = acc[t][0];
-    if (NCH == 2) r += acc[t][NCH - 1];
-    const int row = m0 + wi * (TM / 2) + t * 32 + i;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int col = colb + 8 * g;
-      if (row >= M || col >= N) continue;
-      const long o = (long)row * ldc + col;
-      f32x4 v = {r[4 * g], r[4 * g + 1], r[4 * g + 2], r[4 * g + 3]};
-      f32x4 bb = {0.f, 0.f, 0.f, 0.f}, mv = {1.f, 1.f, 1.f, 1.f};
-      if (vec_ok) {
-        if (bias) bb = *reinterpret_cast<const f32x4*>(bias + col);
-        if (mask) mv = *reinterpret_cast<const f32x4*>(mask + o);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (col + q < N) {
-            if (bias) bb[q] = bias[col + q];
-            if (mask) mv[q] = mask[o + q];
-          }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float x = v[q] + bb[q];
-        if (act == DVAE_ACT_RELU) x = x > 0.f ? x : 0.f;
-        else if (act == DVAE_ACT_LEAKY02) x = x > 0.f ? x : 0.2f * x;
-        if (mask) {
-          if (mask_act == DVAE_ACT_RELU) x = mv[q] > 0.f ? x : 0.f;
-          else if (mask_act == DVAE_ACT_LEAKY02) x = mv[q] > 0.f ? x : 0.2f * x;
+      for (int q = 0; q < 4; ++q)
+        if (col + q < N) {
+          if (bias) bb[q] = bias[col + q];
+          if (mask) mv[q] = mask[o + q];
         }
-        v[q] = x;
-      }
-      if (vec_ok) {
-        *reinterpret_cast<f32x4*>(c + o) = v;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (col + q < N) c[o + q] = v[q];
-      }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x = v[q] + bb[q];
+      if (act == DVAE_ACT_RELU) x = x > 0.f ? x : 0.f;
+      else if (act == DVAE_ACT_LEAKY02) x = x > 0.f ? x : 0.2f * x;
+      if (mask) {
+        if (mask_act == DVAE_ACT_RELU) x = mv[q] > 0.f ? x : 0.f;
+        else if (mask_act == DVAE_ACT_LEAKY02) x = mv[q] > 0.f ? x : 0.2f * x;
+      }
+      v[q] = x;
+    }
+    if (vec_ok) {
+      *reinterpret_cast<f32x4*>(c + o) = v;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (col + q < N) c[o + q] = v[q];
+    }
+  };
+  if (NWK == 1) {
+#pragma unroll
+    for (int t = 0; t < G::NACC; ++t) {
+      f32x16 r = acc[t][0];
+      if (NCH == 2) r += acc[t][NCH - 1];
+      const int row = m0 + wi * (TM / G::NWM) + t * 32 + i;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) finish(row, g, f32x4{r[4 * g], r[4 * g + 1], r[4 * g + 2], r[4 * g + 3]});
+    }
+  } else {
+    // the NWK waves hold partial sums of the SAME 32 x 32 block: red[wave][register][lane], summed in wave order; wave w
+    // finishes registers 4 w .. 4 w + 3 (the ring is free: every transfer has landed and been consumed)
+    static_assert(NWK == 1 || (NWK == 4 && G::NACC == 1), "the final sum assumes four waves on one block");
+    float* red = gd_lds;
+    const f32x16 r = acc[0][0] + acc[0][NCH - 1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wk * 16 + e) * 64 + lane] = r[e];
+    gdma_barrier();
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = (4 * wk + q) * 64 + lane;
+      v[q] = (red[o] + red[o + 16 * 64]) + (red[o + 2 * 16 * 64] + red[o + 3 * 16 * 64]);
+    }
+    finish(m0 + i, wk, v);
   }
 }
 
@@ -448,18 +475,18 @@ __global__ __launch_bounds__(512) void k_gdma_wg(const float* __restrict__ dy, c
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
-template <int TM, int KS, int D, bool BJ, int ABL = 0>
+template <int TM, int TN, int KS, int D, int NWK, bool BJ, int ABL = 0>
 static void launch_gdma_t(const float* a, long lda, const float* b, long ldb, float* c, long ldc, int M, int N, int Kc,
                           const float* bias, int act, const float* mask, int mask_act, hipStream_t s) {
-  using G = GdmaGeo<TM, KS, D>;
+  using G = GdmaGeo<TM, TN, KS, D, NWK>;
   const size_t lds = (size_t)G::NS * G::STAGE_FLOATS * sizeof(float);
   static DeviceOnce attr;
   if (attr.first())
-    (void)hipFuncSetAttribute((const void*)k_gdma<TM, KS, D, BJ, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + 63) / 64;
+    (void)hipFuncSetAttribute((const void*)k_gdma<TM, TN, KS, D, NWK, BJ, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
   const int vec_ok = N % 4 == 0 && ldc % 4 == 0 && (((uintptr_t)c | (uintptr_t)bias | (uintptr_t)mask) & 15) == 0;
-  hipLaunchKernelGGL((k_gdma<TM, KS, D, BJ, ABL>), dim3(tiles_m * tiles_n), dim3(512), lds, s, a, lda, b, ldb, c, ldc, M, N, Kc,
-                     bias, act, mask, mask_act, tiles_m, tiles_n, vec_ok);
+  hipLaunchKernelGGL((k_gdma<TM, TN, KS, D, NWK, BJ, ABL>), dim3(tiles_m * tiles_n), dim3(512), lds, s, a, lda, b, ldb, c, ldc,
+                     M, N, Kc, bias, act, mask, mask_act, tiles_m, tiles_n, vec_ok);
 }
 
 // true if the launch was taken: long contractions and wide outputs with 16-byte-aligned rows
@@ -469,30 +496,33 @@ bool try_gdma(bool b_jfast, const float* a, long lda, const float* b, long ldb, 
   if (off || Kc < 256 || N < 128 || M < 1 || Kc % 4 || lda % 4 || ldb % 4 || (b_jfast && N % 4)) return false;
   if ((((uintptr_t)a | (uintptr_t)b) & 15) != 0) return false;
   if ((long)Kc * ldb * 4 >= (1L << 31) || (long)M * lda * 4 >= (1L << 40)) return false;   // 32-bit per-slab steps
-  // 128-row tiles when they still give every CU a workgroup, else 64-row tiles
-  const long tiles128 = (long)((M + 127) / 128) * ((N + 63) / 64);
-  static const int force_tm = env_int("DVAE_GDMA_TM", 0);      // A/B switches, debug builds only
-  const bool big = force_tm ? force_tm == 128 : tiles128 >= 224;
+  // the largest tile that still gives (nearly) every CU a workgroup: 128 x 64, 64 x 64, else 32 x 32 with the
+  // contraction split over the workgroup's four MFMA waves
+  const long cols64 = (N + 63) / 64;
+  static const int force = env_int("DVAE_GDMA_TILE", 0);       // A/B switch, debug builds only: 128 / 64 / 32
+  const int tile = force ? force : ((M + 127) / 128 * cols64 >= 224 ? 128 : ((M + 63) / 64 * cols64 >= 192 ? 64 : 32));
 #ifdef DVAE_DEBUG_SWITCHES
   static const int abl = env_int("DVAE_GDMA_ABLATE", 0);   // timing ablations of the forward form (results invalid)
-  if (abl && !b_jfast) {
-#define DVAE_GDMA_ABL(V)                                                                                            \
-  if (abl == V) {                                                                                                   \
-    if (big) launch_gdma_t<128, 32, 4, false, V>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);   \
-    else launch_gdma_t<64, 64, 3, false, V>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);        \
-    return true;                                                                                                    \
+  if (abl && !b_jfast && tile != 32) {
+#define DVAE_GDMA_ABL(V)                                                                                               \
+  if (abl == V) {                                                                                                      \
+    if (tile == 128) launch_gdma_t<128, 64, 32, 4, 1, false, V>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s); \
+    else launch_gdma_t<64, 64, 64, 3, 1, false, V>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);    \
+    return true;                                                                                                       \
   }
     DVAE_GDMA_ABL(1) DVAE_GDMA_ABL(2) DVAE_GDMA_ABL(3) DVAE_GDMA_ABL(8)
 #undef DVAE_GDMA_ABL
   }
 #endif
-  if (big) {
-    if (b_jfast) launch_gdma_t<128, 32, 4, true>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
-    else launch_gdma_t<128, 32, 4, false>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
-  } else {
-    if (b_jfast) launch_gdma_t<64, 64, 3, true>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
-    else launch_gdma_t<64, 64, 3, false>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);
-  }
+#define DVAE_GDMA_GO(TM, TN, KS, D, NWK)                                                                         \
+  do {                                                                                                           \
+    if (b_jfast) launch_gdma_t<TM, TN, KS, D, NWK, true>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s); \
+    else launch_gdma_t<TM, TN, KS, D, NWK, false>(a, lda, b, ldb, c, ldc, M, N, Kc, bias, act, mask, mask_act, s);        \
+  } while (0)
+  if (tile == 128) DVAE_GDMA_GO(128, 64, 32, 4, 1);
+  else if (tile == 64) DVAE_GDMA_GO(64, 64, 64, 3, 1);
+  else DVAE_GDMA_GO(32, 32, 64, 3, 4);
+#undef DVAE_GDMA_GO
   return true;
 }
 

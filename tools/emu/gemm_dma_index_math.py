@@ -34,16 +34,20 @@ def mfma_32x32x2(acc, a_lane, b_lane):
             acc[l, e] += C[(e & 3) + 8 * (e >> 2) + 4 * (l // 32), l % 32]
 
 
-def emu_gdma(a, b, M, N, Kc, TM, KS, b_jfast):
+def emu_gdma(a, b, M, N, Kc, TM, TN, KS, NWK, b_jfast):
     """a [M, Kc]; b [N, Kc] (forward form) or [Kc, N] (input-gradient form) -> C [M, N]."""
     lda, ldb = a.shape[1], b.shape[1]
     af, bf = a.ravel(), b.ravel()
     CPR, RPB, SWD = KS // 4, 64 // (KS // 4), 16 // (KS // 4)
-    NBA, NBB = TM * KS // 256, 64 * KS // 256
+    NBA, NBB = TM * KS // 256, TN * KS // 256
     P = (NBA + NBB) // 4
-    NR, NACC = KS // 8, TM // 64
+    NR = KS // 8
+    NWN = TN // 32
+    NWM = 4 // (NWN * NWK)
+    NACC, NRW = TM // NWM // 32, NR // NWK
+    JCH, JRPB = TN // 4, 256 // TN
     swz = lambda r: (r // SWD) & (CPR - 1)
-    tiles_m, tiles_n = (M + TM - 1) // TM, (N + 63) // 64
+    tiles_m, tiles_n = (M + TM - 1) // TM, (N + TN - 1) // TN
     nslab = (Kc + KS - 1) // KS
     klast = (nslab - 1) * KS
     C = np.full((M, N), np.nan)
@@ -52,13 +56,13 @@ def emu_gdma(a, b, M, N, Kc, TM, KS, b_jfast):
         tm, tn = tile_of(L, tiles_m, tiles_n)
         assert (tm, tn) not in seen and tm < tiles_m and tn < tiles_n
         seen.add((tm, tn))
-        m0, n0 = tm * TM, tn * 64
+        m0, n0 = tm * TM, tn * TN
         acc = np.zeros((4, NACC, 64, 16))
         for slab in range(nslab):
-            lds = np.full((TM + 64) * KS, np.nan)
-            for wv in range(4):
+            lds = np.full((TM + TN) * KS, np.nan)
+            for lw in range(4):
                 for p in range(P):
-                    g = wv + 4 * p
+                    g = lw + 4 * p
                     for lane in range(64):
                         if g < NBA or not b_jfast:
                             isA = g < NBA
@@ -71,7 +75,7 @@ def emu_gdma(a, b, M, N, Kc, TM, KS, b_jfast):
                             src, arr = base + slab * KS, (af if isA else bf)
                         else:
                             blk = g - NBA
-                            kk, col = blk * 4 + (lane >> 4), n0 + 4 * (lane & 15)
+                            kk, col = blk * JRPB + lane // JCH, n0 + 4 * (lane % JCH)
                             col_ok = col < N
                             ok = klast + kk < Kc
                             src, arr = (kk * ldb + col + slab * KS * ldb, bf) if col_ok else (None, None)
@@ -81,34 +85,37 @@ def emu_gdma(a, b, M, N, Kc, TM, KS, b_jfast):
                         else:
                             assert src + 4 <= arr.size, "out-of-bounds source"
                             lds[dst:dst + 4] = arr[src:src + 4]
+            assert not np.isnan(lds).any(), "every LDS byte of the stage is written by exactly the transfers"
             for wv in range(4):
-                wi, wj = wv & 1, wv >> 1
-                for rr in range(NR):
+                wj, wi, wk = wv % NWN, (wv // NWN) % NWM, wv // (NWN * NWM)
+                for j in range(NRW):
+                    rr = wk * NRW + j
                     for u in range(4):
                         for t in range(NACC):
                             al, bl = np.zeros(64), np.zeros(64)
                             for lane in range(64):
                                 i, h = lane & 31, lane >> 5
                                 offr = i * KS + (((2 * rr + h) ^ swz(i)) << 2)
-                                al[lane] = lds[wi * (TM // 2) * KS + t * 32 * KS + offr + u]
+                                al[lane] = lds[wi * (TM // NWM) * KS + t * 32 * KS + offr + u]
                                 if b_jfast:
-                                    bl[lane] = lds[TM * KS + 4 * h * 64 + wj * 32 + i + (8 * rr + u) * 64]
+                                    bl[lane] = lds[TM * KS + (8 * wk * NRW + 4 * h) * TN + wj * 32 + i + (8 * j + u) * TN]
                                 else:
                                     bl[lane] = lds[TM * KS + wj * 32 * KS + offr + u]
-                            assert not (np.isnan(al).any() or np.isnan(bl).any())
                             mfma_32x32x2(acc[wv, t], bl, al)       # transposed product: A operand = weights
+        if NWK > 1:                                               # the waves hold partial sums of the same block
+            tot = (acc[0] + acc[1]) + (acc[2] + acc[3])
         for wv in range(4):
-            wi, wj = wv & 1, wv >> 1
+            wj, wi, wk = wv % NWN, (wv // NWN) % NWM, wv // (NWN * NWM)
             for t in range(NACC):
                 for lane in range(64):
                     i, h = lane & 31, lane >> 5
-                    row = m0 + wi * (TM // 2) + t * 32 + i
-                    for g in range(4):
+                    row = m0 + wi * (TM // NWM) + t * 32 + i
+                    for g in (range(4) if NWK == 1 else [wk]):
                         for q in range(4):
                             col = n0 + wj * 32 + 4 * h + 8 * g + q
                             if row < M and col < N:
                                 assert np.isnan(C[row, col])
-                                C[row, col] = acc[wv, t, lane, 4 * g + q]
+                                C[row, col] = acc[wv, t, lane, 4 * g + q] if NWK == 1 else tot[t, lane, 4 * g + q]
     return C
 
 
@@ -181,17 +188,18 @@ def emu_wg(dy, x, M, N, K, KS):
 
 if __name__ == "__main__":
     rng = np.random.default_rng(0)
-    for (M, N, Kc, TM, KS) in ((130, 136, 260, 128, 32), (70, 200, 264, 64, 64), (64, 128, 256, 64, 64), (129, 132, 292, 128, 32)):
+    for (M, N, Kc, TM, TN, KS, NWK) in ((130, 136, 260, 128, 64, 32, 1), (70, 200, 264, 64, 64, 64, 1), (64, 128, 256, 64, 64, 64, 1),
+                                        (129, 132, 292, 128, 64, 32, 1), (70, 132, 264, 32, 32, 64, 4), (33, 100, 320, 32, 32, 64, 4)):
         a = rng.standard_normal((M, Kc))
         w = rng.standard_normal((N, Kc))
-        C = emu_gdma(a, w, M, N, Kc, TM, KS, False)
-        print("fwd   M=%d N=%d K=%d TM=%d KS=%d  max err %.2e" % (M, N, Kc, TM, KS, np.abs(C - a @ w.T).max()))
+        C = emu_gdma(a, w, M, N, Kc, TM, TN, KS, NWK, False)
+        print("fwd   M=%d N=%d K=%d tile %dx%d KS=%d NWK=%d  max err %.2e" % (M, N, Kc, TM, TN, KS, NWK, np.abs(C - a @ w.T).max()))
         assert np.allclose(C, a @ w.T)
-        # input-gradient form: contraction over the rows of w2 [Kc2 = N', N2]: dx[M, K'] = dy[M, N'] w2[N', K']
+        # input-gradient form: contraction over the rows of w2 [Kc, N]: dx[M, N] = dy[M, Kc] w2[Kc, N]
         dy = rng.standard_normal((M, Kc))
         w2 = rng.standard_normal((Kc, N))
-        C = emu_gdma(dy, w2, M, N, Kc, TM, KS, True)
-        print("dgrad M=%d N=%d K=%d TM=%d KS=%d  max err %.2e" % (M, N, Kc, TM, KS, np.abs(C - dy @ w2).max()))
+        C = emu_gdma(dy, w2, M, N, Kc, TM, TN, KS, NWK, True)
+        print("dgrad M=%d N=%d K=%d tile %dx%d KS=%d NWK=%d  max err %.2e" % (M, N, Kc, TM, TN, KS, NWK, np.abs(C - dy @ w2).max()))
         assert np.allclose(C, dy @ w2)
     for (M, N, K, KS) in ((70, 136, 132, 64), (128, 128, 200, 64), (200, 132, 128, 64)):
         dy = rng.standard_normal((M, N))
