@@ -161,6 +161,11 @@ bool try_gdma(bool b_jfast, const float* a, long lda, const float* b, long ldb, 
               const float* bias, int act, const float* mask, int mask_act, hipStream_t s);
 bool try_gdma_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int K, int N, hipStream_t s);
 
+// linear_narrow.hip: the discriminator's last layer (1000 -> 2), forward and input gradient, as streaming passes; true if taken
+bool try_narrow_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, hipStream_t s);
+bool try_narrow_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
+                      hipStream_t s);
+
 size_t latent_entropy_ws_floats(long N, int D, int S);
 int launch_latent_entropy(const float* z_ds, const float* mean, const float* logvar, long N, int D, int S, float* ws,
                           float* H, hipStream_t s);

@@ -620,7 +620,8 @@ static int pick_split(int tiles, int Kc, size_t out_elems, float* ws, size_t ws_
 int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, float* ws,
                       size_t ws_floats, hipStream_t s) {
   // A = x (k contiguous), B(k,j) = w[j*K + k] (k contiguous)
-  if (try_fc32<false>(x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s) ||
+  if (try_narrow_fwd(x, w, b, y, M, K, N, act, s) ||
+      try_fc32<false>(x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s) ||
       try_gdma(false, x, (long)K, w, (long)K, y, (long)N, M, N, K, b, act, (const float*)nullptr, 0, s)) {
     DVAE_CHECK_LAUNCH();
     return 0;
@@ -658,7 +659,8 @@ int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, 
 int launch_linear_dgrad(const float* dy, const float* w, const float* x_act, int act, float* dx, int M, int K, int N,
                         float* ws, size_t ws_floats, hipStream_t s) {
   // dx[M,K] = dy[M,N] w[N,K]: contraction length N
-  if (try_fc32<true>(dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s) ||
+  if (try_narrow_dgrad(dy, w, x_act, act, dx, M, K, N, s) ||
+      try_fc32<true>(dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s) ||
       try_gdma(true, dy, (long)N, w, (long)K, dx, (long)K, M, K, N, (const float*)nullptr, 0, x_act, x_act ? act : 0, s)) {
     DVAE_CHECK_LAUNCH();
     return 0;

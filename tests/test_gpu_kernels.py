@@ -151,7 +151,9 @@ def test_relayout():
                                         (256, 10, 1000, _lib.ACT_LEAKY02), (100, 1000, 2, _lib.ACT_NONE),
                                         (1, 256, 512, _lib.ACT_RELU), (1024, 512, 256, _lib.ACT_RELU), (700, 256, 20, _lib.ACT_NONE),
                                         (5, 64, 48, _lib.ACT_RELU), (40, 100, 36, _lib.ACT_LEAKY02), (300, 128, 128, _lib.ACT_NONE),
-                                        (1800, 1000, 1000, _lib.ACT_LEAKY02), (200, 300, 260, _lib.ACT_RELU)])
+                                        (1800, 1000, 1000, _lib.ACT_LEAKY02), (200, 300, 260, _lib.ACT_RELU),
+                                        (2050, 1000, 2, _lib.ACT_NONE), (2050, 10, 1000, _lib.ACT_LEAKY02), (130, 16, 600, _lib.ACT_NONE),
+                                        (300, 1000, 1000, _lib.ACT_LEAKY02), (1030, 1000, 1000, _lib.ACT_LEAKY02)])
 def test_linear(M, K, N, act):
     x = _rand(M, K, seed=1)
     w = _rand(N, K, seed=2, scale=1 / math.sqrt(K))

@@ -12,12 +12,15 @@ from disvae_amd import _lib
 from disvae_amd._lib import call, ptr
 
 PEAK = 157.3
-Ms = [int(v) for v in sys.argv[1:]] or [2048, 1024, 256, 128]
-K = N = 1000
+NARROW = "--narrow" in sys.argv          # the discriminator's narrow layers instead: M x 1000 -> 2 and M x 10 -> 1000
+Ms = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [2048, 1024, 256, 128]
+SHAPES = [(1000, 2), (10, 1000)] if NARROW else [(1000, 1000)]
 dev = "cuda"
 s = torch.cuda.current_stream().cuda_stream
 ws = torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), device=dev)
 tag = "DVAE_GEMM_DMA=%s" % os.environ.get("DVAE_GEMM_DMA", "default")
+if NARROW:
+    tag = "DVAE_NARROW=%s" % os.environ.get("DVAE_NARROW", "default")
 
 
 def timeit(fn, n=30):
@@ -37,7 +40,7 @@ def err(got, ref):
     return float(((got.double() - ref).abs().max() / ref.abs().max()))
 
 
-for M in Ms:
+for M, (K, N) in [(m_, kn) for m_ in Ms for kn in SHAPES]:
     g = torch.Generator().manual_seed(M)
     x = (torch.rand(M, K, generator=g) - 0.5).to(dev)
     w = ((torch.rand(N, K, generator=g) - 0.5) * 0.1).to(dev)
@@ -57,5 +60,5 @@ for M in Ms:
     fl = 2.0 * M * K * N
     for name, fn, e in (("fwd", fwd, e_f), ("dgrad", dgr, e_d), ("wgrad", wgr, max(e_w, e_b))):
         us = timeit(fn)
-        print("%s M=%-5d %-5s %7.1f us  %6.1f TFLOP/s  %.3f of peak   max rel err %.1e %s" % (
-            tag, M, name, us, fl / us / 1e6, fl / us / 1e6 / PEAK, e, "OK" if e < 2e-6 else "MISMATCH"))
+        print("%s M=%-5d %4dx%-4d %-5s %7.1f us  %6.1f TFLOP/s  %.3f of peak   max rel err %.1e %s" % (
+            tag, M, K, N, name, us, fl / us / 1e6, fl / us / 1e6 / PEAK, e, "OK" if e < 2e-6 else "MISMATCH"))

@@ -1,12 +1,12 @@
 #!/bin/bash
-# round-4 visit: 32x32 k-split tiles for small batches (debug build)
+# round-4 visit: narrow discriminator layers alone, A/B against the generic paths (debug build), and in the factor_celeba step
 set -u
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 mkdir -p gpurun_out
-T=gpurun_out/${TAG:-r04_v7}
-{
-for t in 32 64 32 64; do echo "DVAE_GDMA_TILE=$t"; DVAE_GDMA_TILE=$t timeout 100 python tools/gemm_ab.py 512 256 128 2>&1 | grep -E "fwd|dgrad" | cut -c25-120; done
-echo "default tile choice"; timeout 100 python tools/gemm_ab.py 2048 1024 512 256 128 2>&1 | cut -c25-120
-} | tee ${T}_tile_ab.txt
-timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_discriminator.py -m gpu -q --timeout=300 --no-header -k "linear or discriminator" 2>&1 | tail -n 5
+T=gpurun_out/${TAG:-r04_v10}
+for v in 1 0; do DVAE_NARROW=$v timeout 100 python tools/gemm_ab.py --narrow 2050 1024 256 2>&1 | grep -v amdgpu; done | tee ${T}_narrow_ab.txt
+BA="--no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
+for v in 1 0 1 0; do
+  DVAE_NARROW=$v timeout 200 python bench.py --config factor_celeba --steps 60 --warmup 15 $BA 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('factor_celeba DVAE_NARROW=$v', d['value'], d['ms_per_step'])"
+done | tee ${T}_factor.txt
