@@ -153,7 +153,7 @@ int dvae_conv4s2_fwd_u8(const uint8_t* x, const float* w, const float* b, float*
   DVAE_CHECK_ARG(x && w && y && N > 0);
   DVAE_CHECK_ARG(u8_fused_shape(Cin, H, W, Cout));
   DVAE_CHECK_ARG(act == DVAE_ACT_NONE || act == DVAE_ACT_RELU);
-  return launch_down_thin_u8(x, w, b, y, N, Cin, act, (hipStream_t)stream);
+  return launch_down_thin_u8(x, w, b, y, nullptr, N, Cin, act, (hipStream_t)stream);
 }
 
 int dvae_conv4s2_wgrad_u8(const uint8_t* x, const float* dy, float* dw, float* db, int N, int Cin, int H, int W,
@@ -349,6 +349,41 @@ int dvae_conv32_up(const float* small, int small_layout, const float* img_up, co
   int r = launch_up_mfma32_ws(a, (hipStream_t)stream);
   if (r > 0) r = launch_up_mfma32(a, (hipStream_t)stream);
   if (r > 0) { set_error("dvae_conv32_up: geometry not covered"); return -1; }
+  return r;
+}
+
+// ---- ReLU masks as bit planes (include/dvae_hip.h) ---------------------------------------------------------------------
+int dvae_conv1_fwd_bits(const void* x, int x_is_u8, const float* w, const float* b, float* y, uint32_t* y_bits, int N,
+                        int Cin, void* stream) {
+  DVAE_CHECK_ARG(x && w && y && y_bits && N > 0 && (Cin == 1 || Cin == 3));
+  if (x_is_u8) return launch_down_thin_u8((const uint8_t*)x, w, b, y, y_bits, N, Cin, DVAE_ACT_RELU, (hipStream_t)stream);
+  ConvArgs a{(const float*)x, DVAE_NCHW, nullptr, 0, w, b, nullptr, y, DVAE_NHWC, N, Cin, 32, 32, 32, DVAE_ACT_RELU, 0};
+  a.out_bits = y_bits;
+  const int r = launch_down_thin(a, (hipStream_t)stream);
+  if (r > 0) { set_error("dvae_conv1_fwd_bits: geometry not covered"); return -1; }
+  return r;
+}
+
+int dvae_conv32_up_bits(const float* small, const float* img_up, const float* bias, const uint32_t* mask_bits, float* out,
+                        uint32_t* out_bits, int N, int act, void* stream) {
+  DVAE_CHECK_ARG(small && img_up && out && N > 0 && (mask_bits != nullptr) != (out_bits != nullptr));
+  DVAE_CHECK_ARG(act == DVAE_ACT_NONE || act == DVAE_ACT_RELU);
+  DVAE_CHECK_ARG(!out_bits || act == DVAE_ACT_RELU);
+  ConvArgs a{nullptr, 0, small, DVAE_NHWC, img_up, bias, nullptr, out, DVAE_NHWC, N, 32, 32, 16, 16, act, 1};
+  a.mask_bits = mask_bits;
+  a.out_bits = out_bits;
+  const int r = launch_up_mfma32_ws(a, (hipStream_t)stream);
+  if (r > 0) { set_error("dvae_conv32_up_bits: geometry not covered"); return -1; }
+  return r;
+}
+
+int dvae_convT3_dgrad_bits(const float* dy, const float* w, const uint32_t* x_act_bits, float* dx, int N, int Cout,
+                           void* stream) {
+  DVAE_CHECK_ARG(dy && w && x_act_bits && dx && N > 0 && (Cout == 1 || Cout == 3));
+  ConvArgs a{dy, DVAE_NCHW, nullptr, 0, w, nullptr, nullptr, dx, DVAE_NHWC, N, Cout, 32, 32, 32, DVAE_ACT_NONE, 0};
+  a.mask_bits = x_act_bits;
+  const int r = launch_down_thin(a, (hipStream_t)stream);
+  if (r > 0) { set_error("dvae_convT3_dgrad_bits: geometry not covered"); return -1; }
   return r;
 }
 

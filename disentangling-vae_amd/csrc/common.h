@@ -112,6 +112,9 @@ struct ConvArgs {
   int N, Cb, Cs, Hs, Ws;  // Hs,Ws: SMALL spatial dims (big is 2Hs x 2Ws)
   int act;
   int w_staged;           // 1: `w` is the pre-staged LDS weight image of dvae_stage_weights (tuned 32-channel kernels only)
+  // ReLU masks as bit planes (one uint32 per pixel of a 32-channel NHWC activation, bit c = [a[p][c] > 0]):
+  const uint32_t* mask_bits = nullptr;   // consumed instead of `mask` by the input-gradient kernels that support it
+  uint32_t* out_bits = nullptr;          // emitted next to `out` by the forward kernels that support it
 };
 int launch_down_generic(const ConvArgs& a, hipStream_t s);
 int launch_up_generic(const ConvArgs& a, hipStream_t s);
@@ -137,7 +140,8 @@ int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int d
 int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big,
                       int N, int Cb, int Hs, float* ws, hipStream_t s);
 // uint8 input image x[N,C,64,64] (NCHW), converted on the fly with ToTensor's float(v)/255; return 1 if C is not 1 or 3
-int launch_down_thin_u8(const uint8_t* x, const float* w, const float* bias, float* out, int N, int C, int act, hipStream_t s);
+int launch_down_thin_u8(const uint8_t* x, const float* w, const float* bias, float* out, uint32_t* out_bits, int N, int C, int act,
+                        hipStream_t s);
 int launch_up_thin_recon_u8(const ConvArgs& a, const uint8_t* target, float* g, int dist, const float* coef,
                             float* partials, hipStream_t s);
 int launch_wgrad_thin_u8(const uint8_t* x, const float* small, float* dw, float* db, int N, int C, float* ws, hipStream_t s);

@@ -90,10 +90,17 @@ __device__ __forceinline__ void store_big_thin(const BigThinRegs<C, TB>& r, floa
 // persistent workgroups (4 waves = 4 small rows of 32 pixels per unit); weights go through LDS
 // once per workgroup (coalesced read, transposed [k][cs] image) into 8*C VGPRs per lane; the
 // next unit's big tile is prefetched into registers during the MFMA phase.
-template <int C, bool MASK, typename TB = float>
-__global__ __launch_bounds__(256, 4) void k_down_thin(const TB* __restrict__ big, const float* __restrict__ w,
+// MODE: 0 plain; 1 output masked by an fp32 activation (`mask`); 2 output masked by its bit plane (`bits`: one uint32 per
+// output pixel, bit c = [activation channel c > 0]: 128 bytes per wave and row instead of 4 KB); 3 plain + EMIT the bit
+// plane of the output (the forward pass of conv1: consumed by conv2's input-gradient kernel, conv_up_ws.hip).
+// (the fp32-mask form keeps 16 mask values in flight over the MFMA phase: at C = 3 it needs more than the 128 registers of four
+// waves per SIMD -- it spilled 12 bytes -- so it is built for three; the training step uses MODE 2)
+template <int C, int MODE, typename TB = float>
+__global__ __launch_bounds__(256, (MODE == 1 && C == 3) ? 3 : 4) void k_down_thin(const TB* __restrict__ big, const float* __restrict__ w,
                                                    const float* __restrict__ bias, const float* __restrict__ mask,
-                                                   float* __restrict__ out, int N, int act, int n_units) {
+                                                   float* __restrict__ out, int N, int act, int n_units,
+                                                   uint32_t* __restrict__ bits) {
+  constexpr bool MASK = MODE == 1;
   __shared__ float bt[C * TB_PLANE];
   __shared__ float wT[16 * C * 32];
   __shared__ UnitLut lut_s[1];
@@ -140,6 +147,9 @@ __global__ __launch_bounds__(256, 4) void k_down_thin(const TB* __restrict__ big
 #pragma unroll
       for (int e = 0; e < 16; ++e) mv[e] = mask[rowbase + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32];
     }
+    const long pixbase = ((long)n * 32 + sy0 + sy_l) * 32;         // this wave's row of 32 pixels
+    uint32_t word = 0;                                              // lane L < 32: the bit plane word of pixel L
+    if (MODE == 2) word = bits[pixbase + i];
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -153,12 +163,22 @@ __global__ __launch_bounds__(256, 4) void k_down_thin(const TB* __restrict__ big
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int sx = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int sx0 = (e & 3) + 8 * (e >> 2);                      // lanes 0-31 hold pixel sx0, lanes 32-63 pixel sx0 + 4
+      const int sx = sx0 + 4 * h;
       float v = acc[e] + bv;
       if (act == DVAE_ACT_RELU) v = v > 0.f ? v : 0.f;
       if (MASK) v = mv[e] > 0.f ? v : 0.f;
+      if (MODE == 2) {
+        const uint32_t lo = __builtin_amdgcn_readlane(word, sx0), hi = __builtin_amdgcn_readlane(word, sx0 + 4);
+        v = (((h ? hi : lo) >> i) & 1u) ? v : 0.f;
+      }
+      if (MODE == 3) {
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(v > 0.f);   // bit l = lane l: low half pixel sx0, high half sx0 + 4
+        word = i == sx0 ? (uint32_t)b : (i == sx0 + 4 ? (uint32_t)(b >> 32) : word);
+      }
       out[rowbase + sx * 32] = v;
     }
+    if (MODE == 3 && h == 0) bits[pixbase + i] = word;
   };
   while (unit < n_units) {
     body(pfa, unit);
@@ -628,13 +648,15 @@ int launch_down_thin(const ConvArgs& a, hipStream_t s) {
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
   const int n_units = a.N * 8;
   const int grid = n_units < 1536 ? n_units : 1536;     // 6 resident workgroups per CU
+  if ((a.mask_bits && (a.mask || a.out_bits)) || (a.out_bits && a.mask)) return 1;
+  uint32_t* bits = a.mask_bits ? const_cast<uint32_t*>(a.mask_bits) : a.out_bits;
+#define DVAE_DT(C, MODE) hipLaunchKernelGGL((k_down_thin<C, MODE>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units, bits)
   if (a.Cb == 1) {
-    if (a.mask) hipLaunchKernelGGL((k_down_thin<1, true>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
-    else hipLaunchKernelGGL((k_down_thin<1, false>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+    if (a.mask_bits) DVAE_DT(1, 2); else if (a.out_bits) DVAE_DT(1, 3); else if (a.mask) DVAE_DT(1, 1); else DVAE_DT(1, 0);
   } else {
-    if (a.mask) hipLaunchKernelGGL((k_down_thin<3, true>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
-    else hipLaunchKernelGGL((k_down_thin<3, false>), dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.act, n_units);
+    if (a.mask_bits) DVAE_DT(3, 2); else if (a.out_bits) DVAE_DT(3, 3); else if (a.mask) DVAE_DT(3, 1); else DVAE_DT(3, 0);
   }
+#undef DVAE_DT
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -662,12 +684,15 @@ int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int d
 }
 
 // ---- uint8 input image (conv1 forward, conv1 weight gradient, fused likelihood target) ----------
-int launch_down_thin_u8(const uint8_t* x, const float* w, const float* bias, float* out, int N, int C, int act, hipStream_t s) {
+int launch_down_thin_u8(const uint8_t* x, const float* w, const float* bias, float* out, uint32_t* out_bits, int N, int C, int act,
+                        hipStream_t s) {
   const int n_units = N * 8;
   const int grid = n_units < 1536 ? n_units : 1536;
-  if (C == 1) hipLaunchKernelGGL((k_down_thin<1, false, uint8_t>), dim3(grid), dim3(256), 0, s, x, w, bias, (const float*)nullptr, out, N, act, n_units);
-  else if (C == 3) hipLaunchKernelGGL((k_down_thin<3, false, uint8_t>), dim3(grid), dim3(256), 0, s, x, w, bias, (const float*)nullptr, out, N, act, n_units);
+#define DVAE_DT8(C, MODE) hipLaunchKernelGGL((k_down_thin<C, MODE, uint8_t>), dim3(grid), dim3(256), 0, s, x, w, bias, (const float*)nullptr, out, N, act, n_units, out_bits)
+  if (C == 1) { if (out_bits) DVAE_DT8(1, 3); else DVAE_DT8(1, 0); }
+  else if (C == 3) { if (out_bits) DVAE_DT8(3, 3); else DVAE_DT8(3, 0); }
   else return 1;
+#undef DVAE_DT8
   DVAE_CHECK_LAUNCH();
   return 0;
 }

@@ -72,10 +72,17 @@ __device__ __forceinline__ void store_small_n(const f32x4 (&pf)[NPF], const Slot
 
 #define UPWS_OUT_FLOATS 8192        // one unit's output block: 64 small pixels x 4 parity classes x 32 channels
 
-template <int HS, bool MASK>
+// MASK: 0 none; 1 the producing layer's fp32 activation (32 KB per unit); 2 its bit plane (`bits`: one uint32 per big-side
+// pixel, bit c = [channel c > 0]: 1 KB per unit).  OUTBITS: the forward pass also EMITS the bit plane of its (post-ReLU)
+// output into `bits` -- the compute waves take it from the accumulators with one ballot per D-fragment row (lanes 0-31 /
+// 32-63 of a row are the 32 channels of two pixels) into a 1 KB LDS image per output image, the memory waves drain it.
+template <int HS, int MASK, bool OUTBITS = false>
 __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small, const float* __restrict__ w,
                                                 const float* __restrict__ bias, const float* __restrict__ mask,
-                                                float* __restrict__ out, int act, int n_units, int w_staged) {
+                                                float* __restrict__ out, int act, int n_units, int w_staged,
+                                                uint32_t* __restrict__ bits) {
+  static_assert(!(MASK && OUTBITS), "a forward pass emits bits, an input-gradient pass consumes a mask");
+  static_assert(!OUTBITS || HS == 16, "the bit image's lane-half offset (8 big columns) assumes 16-pixel small rows");
   using G = Geo<HS>;
   static_assert(G::IMGS == 1, "one image per unit");
   constexpr int HB = 2 * HS;
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
   float* wl = smem;                                  // 16384 floats: w[tap][cs/4][cb][cs%4] -- prologue only
   float* out0 = smem;                                // 2 x UPWS_OUT_FLOATS: the output images REUSE the weight image's space
   float* in0 = smem + 16384;                         // 2 x G::SH_FLOATS
+  uint32_t* bimg = reinterpret_cast<uint32_t*>(smem + 16384 + 2 * G::SH_FLOATS);   // OUTBITS: 2 x 256 words
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_compute = wv < 4;
@@ -178,8 +186,19 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
         const int dpp = (e & 3) + 8 * (e >> 2);
         const int dm = dpp / HS, dl = dpp % HS;
         const int d = (2 * dm * HB + 2 * dl) * 32;
-        ob[ooff[0] + d] = epilogue_act(P.a0[e] + bv, act);
-        ob[ooff[1] + d] = epilogue_act(P.a1[e] + bv, act);
+        const float v0 = epilogue_act(P.a0[e] + bv, act), v1 = epilogue_act(P.a1[e] + bv, act);
+        ob[ooff[0] + d] = v0;
+        ob[ooff[1] + d] = v1;
+        if (OUTBITS) {
+          // output image `ob` is out0 + b * UPWS_OUT_FLOATS: its bit image is bimg + b * 256 (pixel index = float offset / 32).
+          // Lane 0 writes both words of a ballot: the upper lane half's pixel is 4 small = 8 big columns to the right
+          const unsigned long long b0 = __builtin_amdgcn_ballot_w64(v0 > 0.f), b1 = __builtin_amdgcn_ballot_w64(v1 > 0.f);
+          if (lane == 0) {
+            uint32_t* bi = bimg + ((ob - out0) >> 5) + (d >> 5);
+            bi[ooff[0] >> 5] = (uint32_t)b0; bi[(ooff[0] >> 5) + 8] = (uint32_t)(b0 >> 32);
+            bi[ooff[1] >> 5] = (uint32_t)b1; bi[(ooff[1] >> 5) + 8] = (uint32_t)(b1 >> 32);
+          }
+        }
       }
     };
     // One unit: 128 MFMAs into C from the input image `in`; the PREVIOUS unit's results P are finished (bias, ReLU, LDS
@@ -222,19 +241,21 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
     __syncthreads();
     unit += stride; k = 1;
     for (;;) {
-      if (unit >= n_units) { epilogue(X, out0 + ((k - 1) & 1) * UPWS_OUT_FLOATS, 0, 16); break; }
+      if (unit >= n_units) break;
       unit_body(Y, X, in0 + (k & 1) * G::SH_FLOATS, out0 + ((k - 1) & 1) * UPWS_OUT_FLOATS, true);
       __syncthreads();
       unit += stride; ++k;
-      if (unit >= n_units) { epilogue(Y, out0 + ((k - 1) & 1) * UPWS_OUT_FLOATS, 0, 16); break; }
+      if (unit >= n_units) { X = Y; break; }         // (one copy of the tail epilogue: 32 register moves, once per kernel)
       unit_body(X, Y, in0 + (k & 1) * G::SH_FLOATS, out0 + ((k - 1) & 1) * UPWS_OUT_FLOATS, true);
       __syncthreads();
       unit += stride; ++k;
     }
+    epilogue(X, out0 + ((k - 1) & 1) * UPWS_OUT_FLOATS, 0, 16);   // the last unit's results
     __syncthreads();                                 // the last unit's image is visible to the memory waves
   } else {
     // ---------------------------------------------------------------- memory waves
-    f32x4 mk[8];
+    f32x4 mk[MASK == 1 ? 8 : 1];
+    uint32_t mw[MASK == 2 ? 8 : 1];                  // bit plane words of this thread's 8 chunks (chunk = 4 channels of a pixel)
     auto drain = [&](int u, int b) {
       // unit u's output block is contiguous: out + u * 8192 floats
       const float* ob = out0 + b * UPWS_OUT_FLOATS;
@@ -243,12 +264,18 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
       for (int j = 0; j < 8; ++j) {
         const int c = (ht + 256 * j) * 4;
         f32x4 v = *reinterpret_cast<const f32x4*>(ob + c);
-        if (MASK) {
+        if (MASK == 1) {
 #pragma unroll
           for (int x = 0; x < 4; ++x) v[x] = mk[j][x] > 0.f ? v[x] : 0.f;
         }
+        if (MASK == 2) {
+          const uint32_t nib = mw[j] >> (4 * (ht & 7));          // channels 4 (ht & 7) .. + 3 of pixel (ht + 256 j) / 8
+#pragma unroll
+          for (int x = 0; x < 4; ++x) v[x] = ((nib >> x) & 1u) ? v[x] : 0.f;
+        }
         if (!(abl & 1)) *reinterpret_cast<f32x4*>(dst + c) = v;
       }
+      if (OUTBITS) bits[(long)u * 256 + ht] = bimg[b * 256 + ht];
     };
     // iteration k (k = 0 .. K, K = number of units of this workgroup): input image of unit k+1 <- registers, loads of unit
     // k+2; output image of unit k-2 -> HBM (the compute waves write unit k-1's image during this iteration); mask of
@@ -262,10 +289,15 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
         if (unit + 2 * stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit + 2 * stride);
       }
       if (u2 >= 0) drain(u2, k & 1);
-      if (MASK && u1 >= 0 && !(abl & 2)) {
+      if (MASK == 1 && u1 >= 0 && !(abl & 2)) {
         const float* src = mask + (long)u1 * UPWS_OUT_FLOATS;
 #pragma unroll
         for (int j = 0; j < 8; ++j) mk[j] = *reinterpret_cast<const f32x4*>(src + (ht + 256 * j) * 4);
+      }
+      if (MASK == 2 && u1 >= 0) {
+        const uint32_t* src = bits + (long)u1 * 256;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mw[j] = src[(ht >> 3) + 32 * j];
       }
       __syncthreads();
       if (!have) break;
@@ -281,16 +313,32 @@ static int launch_up_ws_t(const ConvArgs& a, hipStream_t s) {
   const int n_units = (int)(((long)a.N * HS * HS) / 64);     // HS*HS is a multiple of 64: every unit is complete
   const int grid = n_units < 256 ? n_units : 256;
   static_assert(2 * UPWS_OUT_FLOATS == 16384, "the two output images occupy exactly the weight image");
-  const size_t lds = (size_t)(16384 + 2 * G::SH_FLOATS) * sizeof(float);
+  const size_t lds = (size_t)(16384 + 2 * G::SH_FLOATS + 512) * sizeof(float);   // + the two 1 KB bit images (OUTBITS)
   static DeviceOnce attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute((const void*)k_up32ws<HS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)k_up32ws<HS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_up32ws<HS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_up32ws<HS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (HS == 16) {
+      (void)hipFuncSetAttribute((const void*)k_up32ws<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)k_up32ws<16, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
   }
   static const int abl = env_int("DVAE_UPWS_ABLATE", 0);      // debug builds only
   const int af = a.act | (abl << 8);
-  if (a.mask) hipLaunchKernelGGL((k_up32ws<HS, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units, a.w_staged);
-  else hipLaunchKernelGGL((k_up32ws<HS, false>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units, a.w_staged);
+  if (a.mask_bits || a.out_bits) {
+    // bit planes: the 16 -> 32 geometry only (the two 134 MB activations of the B = 1024 step: conv1's and convT2's outputs)
+    if (HS != 16 || (a.mask_bits && (a.mask || a.out_bits)) || (a.out_bits && (a.mask || a.act != DVAE_ACT_RELU))) return 1;
+    if (a.mask_bits)
+      hipLaunchKernelGGL((k_up32ws<16, 2>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units,
+                         a.w_staged, const_cast<uint32_t*>(a.mask_bits));
+    else
+      hipLaunchKernelGGL((k_up32ws<16, 0, true>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units,
+                         a.w_staged, a.out_bits);
+  } else if (a.mask) {
+    hipLaunchKernelGGL((k_up32ws<HS, 1>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units, a.w_staged, (uint32_t*)nullptr);
+  } else {
+    hipLaunchKernelGGL((k_up32ws<HS, 0>), dim3(grid), dim3(512), lds, s, a.small, a.w, a.bias, a.mask, a.out, af, n_units, a.w_staged, (uint32_t*)nullptr);
+  }
   DVAE_CHECK_LAUNCH();
   return 0;
 }

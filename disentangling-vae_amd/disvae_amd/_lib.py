@@ -42,6 +42,9 @@ SIGNATURES = {
     "dvae_convT3_fwd_staged": [_p, _p, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p],
     "dvae_conv32_down": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "dvae_conv32_up": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "dvae_conv1_fwd_bits": [_p, _i, _p, _p, _p, _p, _i, _i, _p],
+    "dvae_conv32_up_bits": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "dvae_convT3_dgrad_bits": [_p, _p, _p, _p, _i, _i, _p],
     "dvae_fc_chain_fwd": [_p, _p],
     "dvae_fc_chain_bwd": [_p, _p],
     "dvae_reparam_kl_blocks": [_i],

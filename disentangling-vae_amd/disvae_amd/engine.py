@@ -19,6 +19,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib
+from ._debug import knob
 from ._lib import call, ptr, record_py, NCHW, NHWC, ACT_NONE, ACT_RELU, ACT_SIGMOID
 
 HID = 32
@@ -141,6 +142,12 @@ class _Buffers:
         self.gd1, self.gd2, self.gd3 = f(B, HIDDEN_DIM), f(B, HIDDEN_DIM), f(B, HID * 16)
         self.dec_act = [f(B, h, h, HID) for h in eng.dec_sizes]       # NHWC outputs of the hidden convT layers
         self.dec_gact = [f(B, h, h, HID) for h in eng.dec_sizes]
+        # ReLU masks as bit planes (one uint32 per pixel of a 32-channel NHWC activation) for the two 32x32x32 activations of
+        # the 64x64 geometry: conv1's output (mask of conv2's input gradient) and convT2's output (mask of convT3's)
+        self.bits_conv1 = self.bits_convT2 = None
+        if eng.mask_bits:
+            self.bits_conv1 = torch.empty(B * 32 * 32, dtype=torch.int32, device=dev)
+            self.bits_convT2 = torch.empty(B * 32 * 32, dtype=torch.int32, device=dev)
         c, hh, ww = eng.img_size
         self.recon = f(B, c, hh, ww)
         self.g_logit = f(B, c, hh, ww)
@@ -228,6 +235,9 @@ class VAEEngine:
         #          early as the data allows (profiles/r03_v2_timeline_b128.md: backward pass 287 us against ~150 us of
         #          dependent work).  Set per step by the loss plugins (BaseLoss._streams).
         self.eager_wgrad = False
+        # 64x64 images with 1 / 3 channels: the forward kernels of conv1 and convT2 also emit the sign bits of their outputs and
+        # the input-gradient kernels of conv2 and convT3 read those instead of the 32x32x32 fp32 activations (dvae_*_bits)
+        self.mask_bits = self.is64 and c in (1, 3) and knob("DVAE_MASK_BITS", "1") != "0"   # (A/B knob: DVAE_DEBUG=1 only)
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
         self._fc_descs = {}    # host descriptor arrays / argument structs of launches, kept alive for recorded plans
         self._images = None
@@ -372,6 +382,9 @@ class VAEEngine:
             if k > 0:
                 call("dvae_conv32_down", ptr(src), self._img(lname, "down"), ptr(self.p(lname + ".bias")), None, ptr(dst),
                      dst_layout, B, h // 2, ACT_RELU, s)
+            elif self.mask_bits:
+                call("dvae_conv1_fwd_bits", ptr(src), int(x.dtype == torch.uint8), ptr(self.p(lname + ".weight")),
+                     ptr(self.p(lname + ".bias")), ptr(dst), ptr(buf.bits_conv1), B, c, s)
             elif x.dtype == torch.uint8:
                 call("dvae_conv4s2_fwd_u8", ptr(src), ptr(self.p(lname + ".weight")), ptr(self.p(lname + ".bias")),
                      ptr(dst), B, c, h, h, HID, ACT_RELU, s)
@@ -453,8 +466,12 @@ class VAEEngine:
         src, src_layout, h = buf.d3, NCHW, 4
         for name, act in zip(self.dec_names, buf.dec_act):
             lname = "decoder.%s" % name
-            call("dvae_conv32_up", ptr(src), src_layout, self._img(lname, "up"), ptr(self.p(lname + ".bias")), None, ptr(act),
-                 B, h, ACT_RELU, s)
+            if self.mask_bits and h == 16:          # convT2: also emits the sign bits of its output (convT3's backward mask)
+                call("dvae_conv32_up_bits", ptr(src), self._img(lname, "up"), ptr(self.p(lname + ".bias")), None, ptr(act),
+                     ptr(buf.bits_convT2), B, ACT_RELU, s)
+            else:
+                call("dvae_conv32_up", ptr(src), src_layout, self._img(lname, "up"), ptr(self.p(lname + ".bias")), None,
+                     ptr(act), B, h, ACT_RELU, s)
             src, src_layout, h = act, NHWC, h * 2
         c = self.img_size[0]
         if self._images.thin_C:
@@ -535,6 +552,9 @@ class VAEEngine:
             if couts[k] == HID:
                 call("dvae_conv32_down", ptr(dy), self._img(lname, "down"), None, ptr(x_in), ptr(gx), out_layout, B, h,
                      ACT_NONE, s)
+            elif self.mask_bits:
+                call("dvae_convT3_dgrad_bits", ptr(dy), ptr(self.p(lname + ".weight")), ptr(buf.bits_convT2), ptr(gx), B,
+                     couts[k], s)
             else:
                 call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p(lname + ".weight")), ptr(x_in), ptr(gx),
                      out_layout, B, HID, h, h, couts[k], s)
@@ -572,6 +592,16 @@ class VAEEngine:
             self._side_wgrad_grouped(fc)
         if join:
             self._join_side()
+
+    def _conv_dgrad(self, dy, dy_layout, lname, x_in, buf, k, B, h_in, s):
+        """Input gradient of encoder conv layer k (> 0) into buf.enc_gact[k - 1], masked by the ReLU of layer k - 1: by the
+        bit plane conv1's forward emitted where there is one (conv2 at the 64x64 geometry), else by the fp32 activation."""
+        if self.mask_bits and k == 1:
+            call("dvae_conv32_up_bits", ptr(dy), self._img(lname, "up"), None, ptr(buf.bits_conv1), ptr(buf.enc_gact[0]),
+                 None, B, ACT_NONE, s)
+        else:
+            call("dvae_conv32_up", ptr(dy), dy_layout, self._img(lname, "up"), None, ptr(x_in), ptr(buf.enc_gact[k - 1]),
+                 B, h_in // 2, ACT_NONE, s)
 
     def encode_backward(self, x, buf, n=None, fc_chain=False):
         """buf.dml (grad w.r.t. the interleaved mu/logvar output) -> encoder weight grads.  fc_chain: the three FC input
@@ -623,8 +653,7 @@ class VAEEngine:
                         self._conv_wgrad(*wargs, fork=False, main=True)
                     break
                 self._conv_wgrad(*wargs, fork=k < last)      # (k == last: the fork above covers it)
-                call("dvae_conv32_up", ptr(dy), dy_layout, self._img(lname, "up"), None, ptr(x_in), ptr(buf.enc_gact[k - 1]),
-                     B, h_in // 2, ACT_NONE, s)
+                self._conv_dgrad(dy, dy_layout, lname, x_in, buf, k, B, h_in, s)
             self._join_side()
             return
         for k in range(last, -1, -1):
@@ -664,8 +693,7 @@ class VAEEngine:
             else:
                 deferred.append(lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False))
             if k > 0:                            # this stream's next kernel first, then the side launches
-                call("dvae_conv32_up", ptr(dy), dy_layout, self._img(lname, "up"), None, ptr(x_in), ptr(buf.enc_gact[k - 1]),
-                     B, h_in // 2, ACT_NONE, s)
+                self._conv_dgrad(dy, dy_layout, lname, x_in, buf, k, B, h_in, s)
             for launch in side:
                 launch()
         if deferred:

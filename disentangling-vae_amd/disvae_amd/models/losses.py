@@ -629,6 +629,25 @@ class FactorKLoss(BaseLoss):
     def __call__(self, *args, **kwargs):
         raise ValueError("Use `call_optimize` to also train the discriminator")  # losses.py:240-241
 
+    _PERM_RING = 4
+
+    def _draw_perms(self, D, n):
+        """D independent torch.randperm(n) draws (losses.py:505, CPU generator, the reference's order) into the next slot of
+        a small ring of pinned [D, n] int64 buffers -> (buffer, slot); slot[1] is the event that marks the slot's last
+        host-to-device copy (waited for before the slot is overwritten: normally long past)."""
+        ring = self.__dict__.setdefault("_perm_ring", {})
+        ent = ring.get((D, n))
+        if ent is None:
+            ent = ring[(D, n)] = {"slots": [[torch.empty(D, n, dtype=torch.int64).pin_memory(), None]
+                                            for _ in range(self._PERM_RING)], "next": 0}
+        slot = ent["slots"][ent["next"]]
+        ent["next"] = (ent["next"] + 1) % self._PERM_RING
+        if slot[1] is not None:
+            slot[1].synchronize()
+        for d in range(D):
+            torch.randperm(n, out=slot[0][d])
+        return slot[0], slot
+
     def _device_step(self, data, model, sc, eps1, eps2, perms):
         """Training iteration of FactorVAE as one stream of launches (no host-dependent values):
         VAE forward on both halves, discriminator on (z1, z_perm), both backward passes."""
@@ -740,21 +759,27 @@ class FactorKLoss(BaseLoss):
         else:
             eps1 = eps2 = perms = None       # training draws them on the device in _device_step
         if is_train:
+            slot = None
             if perms is None:
-                # CPU generator (shared seed across ranks), reference order losses.py:505
-                perms = torch.stack([torch.randperm(Bh * self._est_world()[0]) for _ in range(D)])
+                # CPU generator (shared seed across ranks), reference order losses.py:505 -- drawn straight into a pinned
+                # staging buffer: the copy to the device is then truly asynchronous (from pageable memory it blocks the host
+                # until every launch enqueued before it has run, i.e. the host could never run ahead of the GPU)
+                perms, slot = self._draw_perms(D, Bh * self._est_world()[0])
             perms = perms.to(dtype=torch.int64)
             mode = self._replay_mode(True, data)
+            if mode == "graph":
+                data = self._static_buf("data", data)
+            perms = self._static_buf("perms", perms)      # device copy (non-blocking from the pinned ring)
+            if slot is not None:
+                slot[1] = torch.cuda.Event()
+                slot[1].record()                          # the staging buffer is free again once this has passed
             if mode:
-                if mode == "graph":
-                    data = self._static_buf("data", data)
-                perms = self._static_buf("perms", perms)
                 if noise is not None:
                     eps1, eps2 = self._static_buf("eps1", eps1), self._static_buf("eps2", eps2)
                 self._graphs.run(self._replay_key(model, data, noise is not None) + (disc.arena.flat.data_ptr(),),
                                  lambda: self._device_step(data, model, sc, eps1, eps2, perms), mode)
             else:
-                self._device_step(data, model, sc, eps1, eps2, perms.to(device=dev).contiguous())
+                self._device_step(data, model, sc, eps1, eps2, perms)
         else:
             buf = eng.buffers(B)
             data = eng.input(data, buf)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DVAE_VERSION 104
+#define DVAE_VERSION 105
 
 /* latent dimensions the fused kernels cover (the reference's --latent-dim is 10 in every experiment of
  * hyperparam.ini): reparameterisation / KL / scalar slots, the FC chain and the beta-TCVAE estimator up to 16.
@@ -133,6 +133,26 @@ int dvae_conv32_down(const float* big, const float* img_down, const float* bias,
                      int out_layout, int N, int Hs, int act, void* stream);
 int dvae_conv32_up(const float* small, int small_layout, const float* img_up, const float* bias, const float* mask,
                    float* out, int N, int Hs, int act, void* stream);
+
+/* ---- ReLU masks as bit planes (new; the reference's autograd keeps the whole post-ReLU activation for relu's backward:
+ * encoders.py:73-77, decoders.py:77-80 under training.py:157).  For a 32-channel NHWC activation a[P pixels][32] the bit plane
+ * is bits[P] (uint32), bit c = [a[p][c] > 0]: 4 bytes per pixel instead of 128.  At the 32x32x32 geometry (the outputs of
+ * conv1 and convT2 on 64x64 images: 134 MB each at B = 1024) the forward kernels EMIT the plane next to the activation and the
+ * input-gradient kernels of the following layer CONSUME it instead of re-reading the activation for its sign.  Results are
+ * bit-identical to the fp32-mask entry points.
+ *   dvae_conv1_fwd_bits    : y[N,32,32,32] (NHWC) = relu(conv(x[N,Cin,64,64] NCHW fp32 or uint8 pixels) + b) and y_bits[N*1024]
+ *                            (= dvae_conv4s2_fwd / _u8 at that geometry, encoders.py:54,73)
+ *   dvae_conv32_up_bits    : the 16x16 -> 32x32 member of dvae_conv32_up; exactly one of mask_bits (input-gradient form: the
+ *                            result is zeroed where the bit is clear; conv2's input gradient, mask = conv1's output) and
+ *                            out_bits (forward form with ReLU: convT2's forward, decoders.py:80) is given
+ *   dvae_convT3_dgrad_bits : dx[N,32,32,32] (NHWC) = convT3 input gradient of dy[N,Cout,64,64] (NCHW), zeroed where the bit of
+ *                            x_act_bits[N*1024] (convT2's output) is clear (= dvae_convT4s2_dgrad at that geometry)          */
+int dvae_conv1_fwd_bits(const void* x, int x_is_u8, const float* w, const float* b, float* y, uint32_t* y_bits, int N,
+                        int Cin, void* stream);
+int dvae_conv32_up_bits(const float* small, const float* img_up, const float* bias, const uint32_t* mask_bits, float* out,
+                        uint32_t* out_bits, int N, int act, void* stream);
+int dvae_convT3_dgrad_bits(const float* dy, const float* w, const uint32_t* x_act_bits, float* dx, int N, int Cout,
+                           void* stream);
 
 /* ---- uint8 input pipeline: utils/datasets.py:204-213 (dSprites: imgs * 255 -> ToTensor), :282-291 (CelebA:
  * imread -> ToTensor).  The batch stays uint8 [N,C,H,W] in HBM (NCHW = ToTensor's output order, 1 byte per pixel);

@@ -56,6 +56,17 @@ for H in (32, 16, 8):        # big side H x H x 32 <-> small side H/2
     report("  staged: convT dgrad (down+mask)", timeit(lambda: call("dvae_conv32_down", ptr(big), ptr(imd), None, ptr(small), ptr(small), NHWC, B, hs, 0, s)), 2 * macs, nb + 2 * ns)
     report("  staged: convT fwd (up)", timeit(lambda: call("dvae_conv32_up", ptr(small), NHWC, ptr(imu), ptr(b), None, ptr(big), B, hs, 1, s)), 2 * macs, nb + ns)
     report("  staged: conv dgrad (up+mask)", timeit(lambda: call("dvae_conv32_up", ptr(small), NHWC, ptr(imu), None, ptr(big), ptr(big), B, hs, 0, s)), 2 * macs, 2 * nb + ns)
+# ReLU masks as bit planes (dvae_*_bits): the 16 -> 32 "up" kernel and the thin "down" kernel, emitting / consuming one uint32 per pixel
+small = torch.rand(B, 16, 16, 32, device=dev); big = torch.rand(B, 32, 32, 32, device=dev) - 0.5
+w = torch.rand(32, 32, 4, 4, device=dev) - 0.5; b = torch.zeros(32, device=dev)
+imd, imu = torch.empty(16384, device=dev), torch.empty(16384, device=dev)
+cd = (_lib.ConvImageDesc * 1)()
+cd[0].w, cd[0].img_down, cd[0].img_up = ptr(w), ptr(imd), ptr(imu)
+call("dvae_stage_weights", ctypes.addressof(cd), 1, None, 0, None, None, None, s)
+bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (B * 1024,), dtype=torch.int32, device=dev)
+macs = B * 256 * 32 * 512
+report("  bits: convT2 fwd (up, emits bits)", timeit(lambda: call("dvae_conv32_up_bits", ptr(small), ptr(imu), ptr(b), None, ptr(big), ptr(bits), B, 1, s)), 2 * macs, big.numel() * 4 + small.numel() * 4 + bits.numel() * 4)
+report("  bits: conv2 dgrad (up, bit mask)", timeit(lambda: call("dvae_conv32_up_bits", ptr(small), ptr(imu), None, ptr(bits), ptr(big), None, B, 0, s)), 2 * macs, big.numel() * 4 + small.numel() * 4 + bits.numel() * 4)
 for C in (3,):
     x = torch.rand(B, C, 64, 64, device=dev)
     a1 = torch.rand(B, 32, 32, 32, device=dev)
@@ -69,6 +80,8 @@ for C in (3,):
     report("convT3 dgrad (down_thin+mask)", timeit(lambda: call("dvae_convT4s2_dgrad", ptr(x), NCHW, ptr(w), ptr(a1), ptr(a1), NHWC, B, 32, 32, 32, C, s)), 2 * macs, nx + 2 * na)
     report("convT3 fwd (up_thin+sigmoid)", timeit(lambda: call("dvae_convT4s2_fwd", ptr(a1), NHWC, ptr(w), ptr(bc), ptr(x), NCHW, B, 32, 32, 32, C, 3, s)), 2 * macs, nx + na)
     report("conv1 wgrad (wgrad_thin+reduce)", timeit(lambda: call("dvae_conv4s2_wgrad", ptr(x), NCHW, ptr(a1), NHWC, ptr(dw), ptr(db), B, C, 64, 64, 32, ptr(ws), s)), 2 * macs, nx + na)
+    report("  bits: conv1 fwd (down_thin, emits bits)", timeit(lambda: call("dvae_conv1_fwd_bits", ptr(x), 0, ptr(w), ptr(b), ptr(a1), ptr(bits), B, C, s)), 2 * macs, nx + na + bits.numel() * 4)
+    report("  bits: convT3 dgrad (down_thin, bit mask)", timeit(lambda: call("dvae_convT3_dgrad_bits", ptr(x), ptr(w), ptr(bits), ptr(a1), B, C, s)), 2 * macs, nx + na + bits.numel() * 4)
     g = torch.empty_like(x)
     coef = torch.full((32,), 1.0 / B, device=dev)
     parts = torch.empty(2048, device=dev)      # DVAE_REC_NPART
