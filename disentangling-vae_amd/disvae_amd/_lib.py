@@ -89,13 +89,15 @@ SIGNATURES = {
     "dvae_comm_group_end": [],
     "dvae_add": [_p, _p, _p, _l, _p],
     "dvae_stream_order": [_p, _p],
+    "dvae_plan_op": [ctypes.c_char_p],
+    "dvae_plan_run": [_p, _i],
 }
 _RESTYPE = {"dvae_last_error": ctypes.c_char_p, "dvae_conv_wgrad_ws_floats": ctypes.c_size_t,
             "dvae_latent_entropy_ws_floats": ctypes.c_size_t}
 
 
 FCW_MAX = 8
-KL_MAX_BLOCKS = 1024                 # DVAE_KL_MAX_BLOCKS
+KL_MAX_BLOCKS = 8192                 # DVAE_KL_MAX_BLOCKS
 KL_FLOATS = 16 + KL_MAX_BLOCKS * 16   # DVAE_KL_FLOATS
 FC_CHAIN_ROWS = 8                    # batch rows per workgroup of dvae_fc_chain_*: ceil(n / 8) KL partial blocks
 
@@ -189,7 +191,28 @@ def note_alloc():
     ALLOC_GEN[0] += 1
 
 
-_REC = None   # launch list being recorded (graph.py: "plan" replay), or None
+PLAN_MAX_ARGS = 20                   # DVAE_PLAN_MAX_ARGS
+
+
+class PlanEntry(ctypes.Structure):
+    """dvae_plan_entry (include/dvae_hip.h)."""
+    _fields_ = [("op", _i), ("nargs", _i), ("args", ctypes.c_uint64 * PLAN_MAX_ARGS)]
+
+
+_REC = None      # launch list being recorded (graph.py: "plan" replay), or None
+_OPS = {}        # entry point name -> dvae_plan_op code (-1: not replayable from C)
+
+
+def _pack(ctype, v):
+    """One argument of a recorded call as the 64 bits dvae_plan_run unpacks (pointers / integers by value, floats as their
+    fp32 bit pattern)."""
+    if v is None:
+        return 0
+    if ctype is ctypes.c_float:
+        return ctypes.c_uint32.from_buffer_copy(ctypes.c_float(v)).value
+    if isinstance(v, bytes):
+        raise DvaeHipError("byte-string arguments cannot be recorded")
+    return int(v) & 0xFFFFFFFFFFFFFFFF
 
 
 def call(name, *args):
@@ -197,9 +220,15 @@ def call(name, *args):
     h = lib()
     fn = getattr(h, name)
     if _REC is not None:
-        # frozen copy of the launch: arguments pre-converted to their ctypes so that a replay is
-        # one foreign call per launch with no Python-side marshalling
-        _REC.append((fn, tuple(None if a is None else t(a) for t, a in zip(fn.argtypes, args)), name))
+        # frozen copy of the launch: the arguments as 64-bit words (replayed by dvae_plan_run, one foreign call per run of
+        # consecutive entry-point calls) when the entry point is replayable, else pre-converted to their ctypes
+        op = _OPS.get(name)
+        if op is None:
+            op = _OPS[name] = h.dvae_plan_op(name.encode())
+        if op >= 0 and len(args) <= PLAN_MAX_ARGS:
+            _REC.append(("c", op, tuple(_pack(t, a) for t, a in zip(fn.argtypes, args)), name))
+        else:
+            _REC.append(("f", fn, tuple(None if a is None else t(a) for t, a in zip(fn.argtypes, args)), name))
     rc = fn(*args)
     if rc != 0:
         raise DvaeHipError("%s failed (%d): %s" % (name, rc, h.dvae_last_error().decode()))
@@ -209,7 +238,7 @@ def record_py(fn, *args):
     """Run a host-side callable that belongs to the launch sequence (stream fork/join, a torch
     copy) and keep it in the recorded plan."""
     if _REC is not None:
-        _REC.append((fn, args, None))
+        _REC.append(("p", fn, args, None))
     return fn(*args)
 
 
@@ -219,16 +248,46 @@ def begin_record():
 
 
 def end_record():
+    """-> the plan: a list of segments, ("c", PlanEntry array, n, names) for a run of replayable entry-point calls,
+    ("f", fn, args, name) for a foreign call that is not, ("p", fn, args) for a host-side callable."""
     global _REC
-    plan, _REC = _REC, None
+    rec, _REC = _REC, None
+    plan, run = [], []
+
+    def flush():
+        if run:
+            arr = (PlanEntry * len(run))()
+            for e, (_, op, words, _) in zip(arr, run):
+                e.op, e.nargs = op, len(words)
+                for i, w in enumerate(words):
+                    e.args[i] = w
+            plan.append(("c", arr, len(run), tuple(r[3] for r in run)))
+            del run[:]
+
+    for ent in rec:
+        if ent[0] == "c":
+            run.append(ent)
+        else:
+            flush()
+            plan.append(ent)
+    flush()
     return plan
 
 
 def replay(plan):
-    for fn, args, name in plan:
-        rc = fn(*args)
-        if name is not None and rc != 0:
-            raise DvaeHipError("%s failed (%d): %s" % (name, rc, lib().dvae_last_error().decode()))
+    h = lib()
+    for seg in plan:
+        kind = seg[0]
+        if kind == "c":
+            rc = h.dvae_plan_run(ctypes.addressof(seg[1]), seg[2])
+            if rc != 0:
+                raise DvaeHipError("replay of %d recorded launches failed (%d): %s" % (seg[2], rc, h.dvae_last_error().decode()))
+        elif kind == "f":
+            rc = seg[1](*seg[2])
+            if rc != 0:
+                raise DvaeHipError("%s failed (%d): %s" % (seg[3], rc, h.dvae_last_error().decode()))
+        else:
+            seg[1](*seg[2])
 
 
 def ptr(t):

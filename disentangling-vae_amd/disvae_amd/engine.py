@@ -255,6 +255,8 @@ class VAEEngine:
     def buffers(self, B):
         b = self._bufs.get(B)
         if b is None or b.recon.device != self.device:
+            if b is not None:
+                self._fc_descs.clear()     # cached argument structs hold pointers into the workspace being replaced
             b = _Buffers(self, B)
             self._bufs[B] = b
         if self._ws is None or self._ws.device != self.device:
@@ -270,6 +272,7 @@ class VAEEngine:
     def images(self):
         im = self._images
         if im is None or im.flat_ptr != self.arena.flat.data_ptr():
+            self._fc_descs.clear()         # cached argument structs hold pointers into the old images / parameter arena
             im = self._images = _Images(self)
         return im
 

@@ -183,9 +183,14 @@ class _DiscFn(torch.autograd.Function):
             raise _lib.DvaeHipError("Discriminator input must be fp32 on %s" % disc.arena.flat.device)
         z = z.contiguous()
         M = z.shape[0]
+        if not any(ctx.needs_input_grad):
+            # inference (torch.no_grad(), evaluation): nothing is kept for a backward pass -- the module's shared workspace,
+            # no per-call activation / gradient buffers
+            return disc.forward_raw(z, M).clone()
         acts = disc._fresh_buffers(M)
         logits = disc.forward_raw(z, M, acts=acts).clone()
         ctx.disc, ctx.M, ctx.acts = disc, M, acts
+        ctx.version = disc.arena.flat._version      # backward reads the CURRENT weights: they must not change in between
         ctx.save_for_backward(z)
         return logits
 
@@ -193,6 +198,9 @@ class _DiscFn(torch.autograd.Function):
     def backward(ctx, g_logits):
         disc, M = ctx.disc, ctx.M
         (z,) = ctx.saved_tensors
+        if disc.arena.flat._version != ctx.version:
+            raise RuntimeError("the discriminator's parameters were modified in place (optimizer step, load_state_dict) between "
+                               "this forward and its backward: the gradients would be computed with the new weights")
         disc.unalias_grads()
         dz = disc.backward_raw(z, g_logits.contiguous(), M, wgrad=True, chain="g", acts=ctx.acts)
         grads = []

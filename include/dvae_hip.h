@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DVAE_VERSION 105
+#define DVAE_VERSION 106
 
 /* latent dimensions the fused kernels cover (the reference's --latent-dim is 10 in every experiment of
  * hyperparam.ini): reparameterisation / KL / scalar slots, the FC chain and the beta-TCVAE estimator up to 16.
@@ -247,7 +247,7 @@ int dvae_fc_chain_bwd(const dvae_fc_chain_bwd_args* args, void* stream);
  * the rest (kl_dim + 16) holds per-workgroup partial sums, blocks of 16 floats.  With kl_dim != NULL and coef == NULL
  * only the dvae_reparam_kl_blocks(B) partial blocks are written (no finishing launch): dvae_loss_epilogue(kl_blocks = that
  * count) or dvae_kl_finish completes them -- every consumer adds the blocks in the same fixed order.            */
-#define DVAE_KL_MAX_BLOCKS 1024
+#define DVAE_KL_MAX_BLOCKS 8192
 #define DVAE_KL_FLOATS (16 + DVAE_KL_MAX_BLOCKS * 16)
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z,
                         float* kl_dim, const float* coef, int B, int D, void* stream);
@@ -359,6 +359,21 @@ int dvae_add(const float* a, const float* b, float* out, long n, void* stream);
  * its fork / join primitive: an event recorded with a DEVICE-scope release (hipEventReleaseToDevice: no system-scope cache
  * flush, the two streams share the device) from a small internal pool, then hipStreamWaitEvent.  Capturable.            */
 int dvae_stream_order(void* earlier, void* later);
+
+/* ---- recorded launch lists (new; host-side overhead only) ------------------------------------------------------------
+ * A training iteration at a fixed batch size repeats the same entry-point calls with the same arguments; the host records
+ * them once and replays the list with ONE call per step segment instead of one foreign call per launch.  An entry names its
+ * entry point by dvae_plan_op("dvae_...") (>= 0; -1: not replayable) and carries every argument in 64 bits: pointers and
+ * integers by value (sign-extended), floats as their fp32 bit pattern in the low word.  HOST structs passed by pointer
+ * (dvae_stage_weights tables, dvae_fc_chain_*_args, wgrad descriptors) must stay alive and are re-read at every replay.
+ * dvae_plan_run executes the entries in order and stops at the first failure (returns its status).               */
+#define DVAE_PLAN_MAX_ARGS 20
+typedef struct {
+  int op, nargs;
+  uint64_t args[DVAE_PLAN_MAX_ARGS];
+} dvae_plan_entry;
+int dvae_plan_op(const char* name);
+int dvae_plan_run(const dvae_plan_entry* entries, int n);
 
 /* ---- RCCL collectives over xGMI (data parallelism over the GPUs of one node; new, the reference is single-process) ----
  * One communicator per process (= per GPU).  Every collective is ENQUEUED on `stream` (ordered with the kernels around

@@ -26,7 +26,7 @@ def test_header_symbols_exported():
 def test_ctypes_table_matches_header():
     assert sorted(_lib.SIGNATURES) == _declared()
     h = _lib.lib()
-    assert h.dvae_version() == 105
+    assert h.dvae_version() == 106
     assert h.dvae_conv_wgrad_ws_floats() > 4_000_000
 
 
@@ -38,6 +38,28 @@ def test_argument_errors_are_reported():
         assert "invalid argument" in str(e)
     else:
         raise AssertionError("expected DvaeHipError")
+
+
+def test_plan_ops_cover_the_launching_entry_points():
+    """dvae_plan_op resolves every entry point the training step records; dvae_plan_run rejects malformed entries before any
+    launch (no GPU needed) and runs an argument-checked call through its trampoline (the NULL-pointer error comes back)."""
+    h = _lib.lib()
+    not_replayable = {"dvae_version", "dvae_last_error", "dvae_conv_wgrad_ws_floats", "dvae_latent_entropy_ws_floats",
+                      "dvae_reparam_kl_blocks", "dvae_u8_fused_supported", "dvae_plan_op", "dvae_plan_run", "dvae_comm_load",
+                      "dvae_comm_unique_id", "dvae_comm_init", "dvae_comm_destroy", "dvae_comm_world", "dvae_comm_rank"}
+    for name in _lib.SIGNATURES:
+        assert (h.dvae_plan_op(name.encode()) >= 0) == (name not in not_replayable), name
+    assert h.dvae_plan_op(b"no_such_entry_point") == -1
+    arr = (_lib.PlanEntry * 1)()
+    arr[0].op, arr[0].nargs = h.dvae_plan_op(b"dvae_add"), 2              # dvae_add takes 5 arguments
+    assert h.dvae_plan_run(ctypes.addressof(arr), 1) != 0 and b"arguments recorded" in h.dvae_last_error()
+    arr[0].nargs = 5                                                        # all-NULL pointers: dvae_add's own check fires
+    assert h.dvae_plan_run(ctypes.addressof(arr), 1) != 0 and b"invalid argument" in h.dvae_last_error()
+    arr[0].op = 10 ** 6
+    assert h.dvae_plan_run(ctypes.addressof(arr), 1) != 0 and b"unknown op" in h.dvae_last_error()
+    # the recorder packs what the trampolines unpack
+    assert _lib._pack(ctypes.c_float, 1.5) == 0x3FC00000 and _lib._pack(ctypes.c_int, -1) == 2 ** 64 - 1
+    assert _lib._pack(ctypes.c_void_p, None) == 0
 
 
 def test_graft_entry_build_runs():
@@ -64,7 +86,7 @@ def test_argument_structs_have_the_headers_layout(tmp_path):
         pytest.skip("needs gcc")
     pairs = [("dvae_conv_image_desc", _lib.ConvImageDesc), ("dvae_fc_image_desc", _lib.FcImageDesc),
              ("dvae_thin_image_desc", _lib.ThinImageDesc), ("dvae_fc_chain_fwd_args", _lib.FcChainFwdArgs),
-             ("dvae_fc_chain_bwd_args", _lib.FcChainBwdArgs)]
+             ("dvae_fc_chain_bwd_args", _lib.FcChainBwdArgs), ("dvae_plan_entry", _lib.PlanEntry)]
     body = []
     for cname, cls in pairs:
         body.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -86,5 +108,6 @@ def test_argument_structs_have_the_headers_layout(tmp_path):
     for cname, cls in pairs:
         decl = hdr[:hdr.index("} %s;" % cname)]
         decl = decl[decl.rindex("typedef struct"):]
+        decl = re.sub(r"\[[^\]]*\]", "", decl)                # array members: name[N]
         names = re.findall(r"[\*\s,]([A-Za-z_][A-Za-z_0-9]*)\s*(?=[,;])", re.sub(r"/\*.*?\*/", "", decl, flags=re.S))
         assert names == [n for n, _ in cls._fields_], (cname, names)

@@ -45,22 +45,7 @@ def _native(loss, img, seed, n_data, lr, rec_dist="bernoulli"):
     return model, opt, loss_f
 
 
-def check_frac(got, ref, rtol, atol_rel, max_bad, what):
-    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
-    assert torch.isfinite(got).all(), what
-    err = (got - ref).abs() / (rtol * ref.abs() + atol_rel * ref.abs().max() + 1e-30)
-    bad = float((err > 1).double().mean())
-    assert bad <= max_bad, "%s: %.3f%% of entries outside tolerance (worst x%.1f)" % (what, 100 * bad, err.max().item())
-    assert err.max().item() < 200, "%s: gross error x%.0f" % (what, err.max().item())
-
-
-def _compare_grads(model, ref_grads, what):
-    """LATER steps only (each side on its own trajectory): loose, with outliers."""
-    for k, p in model.named_parameters():
-        check_frac(p.grad, ref_grads[k], 2e-2, 5e-3, 2e-2, "%s grad %s" % (what, k))
-
-
-G_RTOL, G_ATOL = 1e-5, 2e-6        # first-step gradients vs the gate-matched fp64 oracle, no outliers
+G_RTOL, G_ATOL = 1e-5, 2e-6        # gradients of EVERY step vs the gate-matched fp64 oracle at the engine's parameters, no outliers
 
 
 def _assert_gate_pattern(gates, log, what):
@@ -83,52 +68,56 @@ def test_fused_step_vs_oracle(loss, img, B, rec_dist):
     torch.manual_seed(seed)
     params = O.init_vae_params(img, 10)
     hp = dict(HP, n_data=n_data)
-    orc = O.OracleTrainer(loss, hp, img, 10, lr=lr, rec_dist=rec_dist, steps_anneal=HP["reg_anneal"], params=params)
+    # Every step is checked the way the first one is: the oracle is evaluated AT THE ENGINE'S CURRENT PARAMETERS (fp32 for the
+    # loss / outputs / logged scalars, gate-matched fp64 for the gradients, rtol 1e-5, no outliers), so steps 2 and 3 hold the
+    # arena reuse, the cached gradient views, the advancing annealing coefficient and the weights Adam has moved to the same
+    # bound.  The optimizer is checked on its own: torch's CPU Adam fed with the engine's gradients must land on the engine's
+    # parameters (<= 2 ulp, or 4e-6 of an update).
+    cpu = [p.detach().cpu().clone().requires_grad_(True) for p in model.parameters()]
+    oc = torch.optim.Adam(cpu, lr=lr)
+    assert all(torch.equal(pc.detach(), params[k]) for pc, (k, _) in zip(cpu, model.named_parameters()))
     gen = torch.Generator().manual_seed(seed + 1)
     for step in range(3):
         data = torch.rand((B,) + tuple(img), generator=gen)
         eps = torch.randn(B, 10, generator=gen)
-        # oracle forward/backward (before its optimizer step) for activations and gradients
-        pre = O.clone_params(orc.params, requires_grad=True)
-        st = O.LossState(rec_dist=rec_dist, steps_anneal=HP["reg_anneal"]); st.n_train_steps = orc.state.n_train_steps
-        ref_loss, ref_logs, ref_grads, ref_outs = O.train_iteration_grads(loss, hp, st, pre, data, eps)
-        p_step = O.clone_params(orc.params)
-        orc.train_iteration(data, eps=eps)
+        p_step = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
+        st = O.LossState(rec_dist=rec_dist, steps_anneal=HP["reg_anneal"]); st.n_train_steps = step
+        ref_loss, ref_logs, _, ref_outs = O.train_iteration_grads(loss, hp, st, O.clone_params(p_step, requires_grad=True),
+                                                                  data, eps)
         storer = defaultdict(list)
         out = loss_f.fused_step(dev(data), model, opt, storer, eps=dev(eps))
         buf = model.engine.buffers(B)
-        first = step == 0
-        np.testing.assert_allclose(out.item(), ref_loss.item(), rtol=2e-5 if first else 1e-3, err_msg="loss step %d" % step)
-        if first:
-            check(buf.mu, ref_outs["mu"], what="mu")
-            check(buf.logvar, ref_outs["logvar"], what="logvar")
-            check(buf.z, ref_outs["z"], what="z")
-            check(buf.recon, ref_outs["recon"], what="recon")
-        if first:
-            # gradient reference = the fp64 oracle evaluated with the engine's ReLU on/off pattern; the pattern is checked
-            gates = engine_gates(model, B)
-            log = []
-            with torch.no_grad(), O.gates(None, record=log):
-                O.vae_forward(O.clone_params(p_step, dtype=torch.float64), data.double(), eps.double())
-            _assert_gate_pattern(gates, log, "%s B=%d" % (loss, B))
-            st64 = O.LossState(rec_dist=rec_dist, steps_anneal=HP["reg_anneal"])
-            with O.gates(gates):
-                _, _, grads64, _ = O.train_iteration_grads(loss, hp, st64, O.clone_params(p_step, dtype=torch.float64,
-                                                                                         requires_grad=True),
-                                                           data.double(), eps.double())
-            for k, p in model.named_parameters():
-                check(p.grad, grads64[k], rtol=G_RTOL, atol_rel=G_ATOL, what="%s grad vs gate-matched fp64 %s" % (loss, k))
-        else:
-            _compare_grads(model, ref_grads, "%s step %d" % (loss, step))
+        np.testing.assert_allclose(out.item(), ref_loss.item(), rtol=2e-5, err_msg="loss step %d" % step)
+        check(buf.mu, ref_outs["mu"], what="mu")
+        check(buf.logvar, ref_outs["logvar"], what="logvar")
+        check(buf.z, ref_outs["z"], what="z")
+        check(buf.recon, ref_outs["recon"], what="recon")
+        # gradient reference = the fp64 oracle evaluated with the engine's ReLU on/off pattern; the pattern is checked
+        gates = engine_gates(model, B)
+        log = []
+        with torch.no_grad(), O.gates(None, record=log):
+            O.vae_forward(O.clone_params(p_step, dtype=torch.float64), data.double(), eps.double())
+        _assert_gate_pattern(gates, log, "%s B=%d step %d" % (loss, B, step))
+        st64 = O.LossState(rec_dist=rec_dist, steps_anneal=HP["reg_anneal"]); st64.n_train_steps = step
+        with O.gates(gates):
+            _, _, grads64, _ = O.train_iteration_grads(loss, hp, st64, O.clone_params(p_step, dtype=torch.float64,
+                                                                                     requires_grad=True),
+                                                       data.double(), eps.double())
+        for k, p in model.named_parameters():
+            check(p.grad, grads64[k], rtol=G_RTOL, atol_rel=G_ATOL, what="%s step %d grad vs gate-matched fp64 %s" % (loss, step, k))
         if step == 0:
             assert list(storer.keys()) == list(ref_logs.keys()), (list(storer.keys()), list(ref_logs.keys()))
             for k in ref_logs:
                 np.testing.assert_allclose(storer[k][0], ref_logs[k].item(), rtol=5e-5, atol=1e-6, err_msg=k)
         else:
             assert len(storer) == 0
-        for k, p in model.named_parameters():
-            d = (p.detach().cpu() - orc.params[k].detach()).abs().max().item()
-            assert d <= 2.5 * lr * (step + 1), "param %s after step %d: max diff %.3e" % (k, step, d)
+        for pc, (k, p) in zip(cpu, model.named_parameters()):
+            pc.grad = p.grad.detach().cpu().clone()
+        oc.step()
+        for pc, (k, p) in zip(cpu, model.named_parameters()):
+            d = (p.detach().cpu() - pc.detach()).abs()
+            tol = 2 * pc.detach().abs() * 2.0 ** -23 + 4e-6 * lr
+            assert bool((d <= tol).all()), "param %s after step %d: GPU Adam vs torch CPU Adam on the same gradients: max diff %.3e" % (k, step, d.max().item())
     assert loss_f.n_train_steps == 3
 
 
@@ -142,57 +131,59 @@ def test_factor_step_vs_oracle(img, B):
     for k, v in loss_f.discriminator.state_dict().items():
         assert torch.equal(v.cpu(), dparams[k]), k
     hp = dict(HP, n_data=n_data)
-    orc = O.OracleTrainer("factor", hp, img, 10, lr=lr, lr_disc=HP["lr_disc"], steps_anneal=HP["reg_anneal"],
-                          params=params, dparams=dparams)
+    # every step at the engine's CURRENT parameters (see test_fused_step_vs_oracle): gate-matched fp64 gradients at 1e-5 for
+    # the VAE and the discriminator, both optimizers against torch's CPU Adam on the engine's gradients
+    cpu = [p.detach().cpu().clone().requires_grad_(True) for p in model.parameters()]
+    dcpu = [p.detach().cpu().clone().requires_grad_(True) for p in loss_f.discriminator.parameters()]
+    oc = torch.optim.Adam(cpu, lr=lr)
+    ocd = torch.optim.Adam(dcpu, lr=HP["lr_disc"], betas=(0.5, 0.9))
     gen = torch.Generator().manual_seed(seed + 1)
     Bh = B // 2
     for step in range(3):
         data = torch.rand((B,) + tuple(img), generator=gen)
         eps1, eps2 = torch.randn(Bh, 10, generator=gen), torch.randn(Bh, 10, generator=gen)
         perms = torch.stack([torch.randperm(Bh, generator=gen) for _ in range(10)])
-        pre, dpre = O.clone_params(orc.params, requires_grad=True), O.clone_params(orc.dparams, requires_grad=True)
-        st = O.LossState(steps_anneal=HP["reg_anneal"]); st.n_train_steps = orc.state.n_train_steps
-        ref_loss, ref_logs, g, gd, outs = O.factor_iteration_grads(hp, st, pre, dpre, data, eps1, eps2, list(perms))
-        p_step, d_step = O.clone_params(orc.params), O.clone_params(orc.dparams)
-        orc.train_iteration(data, eps=eps1, eps2=eps2, perms=list(perms))
+        p_step = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
+        d_step = {k: p.detach().cpu().clone() for k, p in loss_f.discriminator.named_parameters()}
+        st = O.LossState(steps_anneal=HP["reg_anneal"]); st.n_train_steps = step
+        ref_loss, ref_logs, _, _, outs = O.factor_iteration_grads(hp, st, O.clone_params(p_step, requires_grad=True),
+                                                                  O.clone_params(d_step, requires_grad=True), data, eps1, eps2,
+                                                                  list(perms))
         storer = defaultdict(list)
         out = loss_f.call_optimize(dev(data), model, opt, storer, noise=(dev(eps1), dev(eps2), perms))
-        first = step == 0
-        np.testing.assert_allclose(out.item(), ref_loss.item(), rtol=2e-5 if first else 1e-3)
+        np.testing.assert_allclose(out.item(), ref_loss.item(), rtol=2e-5)
         buf = model.engine.buffers(B)
-        if first:
-            check(buf.z[:Bh], outs["z1"], what="z1")
-            check(buf.z[Bh:2 * Bh], outs["z2"], what="z2")
-        if first:
-            gates = engine_gates(model, B, splits=[slice(0, Bh), slice(Bh, 2 * Bh)], dec_rows=slice(0, Bh))
-            gates.update(discriminator_gates(loss_f.discriminator, 2 * Bh, Bh))
-            c64 = lambda p_: O.clone_params(p_, dtype=torch.float64, requires_grad=True)
-            args64 = lambda: (hp, O.LossState(steps_anneal=HP["reg_anneal"]), c64(p_step), c64(d_step), data.double(),
-                              eps1.double(), eps2.double(), list(perms))
-            log = []
-            with O.gates(None, record=log):
-                O.factor_iteration_grads(*args64())
-            _assert_gate_pattern(gates, log, "factor B=%d" % B)
-            with O.gates(gates):
-                _, _, g64, gd64, _ = O.factor_iteration_grads(*args64())
-            for k, p in model.named_parameters():
-                check(p.grad, g64[k], rtol=G_RTOL, atol_rel=G_ATOL, what="factor grad vs gate-matched fp64 " + k)
-            for k, p in loss_f.discriminator.named_parameters():
-                check(p.grad, gd64[k], rtol=G_RTOL, atol_rel=G_ATOL, what="factor disc grad vs gate-matched fp64 " + k)
-        else:
-            _compare_grads(model, g, "factor vae step %d" % step)
-            for k, p in loss_f.discriminator.named_parameters():
-                check_frac(p.grad, gd[k], 2e-2, 5e-3, 2e-2, "disc grad %s step %d" % (k, step))
+        check(buf.z[:Bh], outs["z1"], what="z1")
+        check(buf.z[Bh:2 * Bh], outs["z2"], what="z2")
+        gates = engine_gates(model, B, splits=[slice(0, Bh), slice(Bh, 2 * Bh)], dec_rows=slice(0, Bh))
+        gates.update(discriminator_gates(loss_f.discriminator, 2 * Bh, Bh))
+        c64 = lambda p_: O.clone_params(p_, dtype=torch.float64, requires_grad=True)
+
+        def args64():
+            st64 = O.LossState(steps_anneal=HP["reg_anneal"]); st64.n_train_steps = step
+            return (hp, st64, c64(p_step), c64(d_step), data.double(), eps1.double(), eps2.double(), list(perms))
+        log = []
+        with O.gates(None, record=log):
+            O.factor_iteration_grads(*args64())
+        _assert_gate_pattern(gates, log, "factor B=%d step %d" % (B, step))
+        with O.gates(gates):
+            _, _, g64, gd64, _ = O.factor_iteration_grads(*args64())
+        for k, p in model.named_parameters():
+            check(p.grad, g64[k], rtol=G_RTOL, atol_rel=G_ATOL, what="factor step %d grad vs gate-matched fp64 %s" % (step, k))
+        for k, p in loss_f.discriminator.named_parameters():
+            check(p.grad, gd64[k], rtol=G_RTOL, atol_rel=G_ATOL, what="factor step %d disc grad vs gate-matched fp64 %s" % (step, k))
         if step == 0:
             assert list(storer.keys()) == list(ref_logs.keys()), (list(storer.keys()), list(ref_logs.keys()))
             for k in ref_logs:
                 np.testing.assert_allclose(storer[k][0], ref_logs[k].item(), rtol=5e-5, atol=1e-6, err_msg=k)
-        for k, p in model.named_parameters():
-            d = (p.detach().cpu() - orc.params[k].detach()).abs().max().item()
-            assert d <= 2.5 * lr * (step + 1), "param %s: max diff %.3e" % (k, d)
-        for k, p in loss_f.discriminator.named_parameters():
-            d = (p.detach().cpu() - orc.dparams[k].detach()).abs().max().item()
-            assert d <= 2.5 * HP["lr_disc"] * (step + 1), "dparam %s: max diff %.3e" % (k, d)
+        for plist, mod, o_, lr_ in ((cpu, model, oc, lr), (dcpu, loss_f.discriminator, ocd, HP["lr_disc"])):
+            for pc, (k, p) in zip(plist, mod.named_parameters()):
+                pc.grad = p.grad.detach().cpu().clone()
+            o_.step()
+            for pc, (k, p) in zip(plist, mod.named_parameters()):
+                d = (p.detach().cpu() - pc.detach()).abs()
+                tol = 2 * pc.detach().abs() * 2.0 ** -23 + 4e-6 * lr_
+                assert bool((d <= tol).all()), "param %s after step %d: GPU Adam vs torch CPU Adam: max diff %.3e" % (k, step, d.max().item())
 
 
 GOLDEN = [("vae_mnist", "VAE", (1, 32, 32), 8, 2), ("betaB_mnist", "betaB", (1, 32, 32), 8, 2),

@@ -86,12 +86,34 @@ def test_flat_fused_adam_equals_adam_over_the_state_dict_views():
                 pc.copy_(pa.detach().cpu())
 
 
-@pytest.mark.parametrize("name,loss,img,B,n_data,lr,lr_disc", [
-    ("btcvae_celeba", "btcvae", (3, 64, 64), 1024, 202599, 5e-4, 1e-5),
-    ("factor_dsprites", "factor", (1, 64, 64), 256, 737280, 1e-4, 1e-4),
-    ("btcvae_b128", "btcvae", (3, 64, 64), 128, 202599, 5e-4, 1e-5),       # the per-GPU batch of the 8-GPU headline config
+def _update_agreement(p0, p_engine, p_oracle, what, lr, steps):
+    """The accumulated parameter update of the engine against the oracle's.  Element-wise bounds cannot be tight here: Adam
+    turns an ulp-level difference of a near-zero gradient entry into an O(lr) difference of that entry's update (see the
+    module docstring), but a wrong gradient of a whole layer (a missed term, a wrong mask, a stale buffer) rotates or
+    rescales the update vector -- so: cosine >= 0.99 between the two update vectors, norms within 3 %, and at most 2 % of
+    the entries further apart than lr (one flipped step)."""
+    u = (p_engine.double() - p0.double()).flatten()
+    v = (p_oracle.double() - p0.double()).flatten()
+    nv = v.norm().item()
+    if nv < 1e-9:                                    # an untouched tensor stays untouched
+        assert u.norm().item() < 1e-9, what
+        return
+    cos = float(torch.dot(u, v) / (u.norm() * v.norm() + 1e-300))
+    assert cos >= 0.99, "%s: update direction differs from the oracle's: cosine %.5f" % (what, cos)
+    assert abs(u.norm().item() - nv) <= 0.03 * nv, "%s: update norm %.4e vs the oracle's %.4e" % (what, u.norm().item(), nv)
+    far = ((u - v).abs() > lr).double().mean().item()
+    assert far <= 0.02, "%s: %.2f %% of the entries differ from the oracle's by more than lr after %d steps" % (what, 100 * far, steps)
+
+
+@pytest.mark.parametrize("name,loss,img,B,n_data,lr,lr_disc,steps", [
+    ("btcvae_celeba", "btcvae", (3, 64, 64), 1024, 202599, 5e-4, 1e-5, 10),
+    ("factor_dsprites", "factor", (1, 64, 64), 256, 737280, 1e-4, 1e-4, 10),
+    ("btcvae_b128", "btcvae", (3, 64, 64), 128, 202599, 5e-4, 1e-5, 10),   # the per-GPU batch of the 8-GPU headline config
+    # BASELINE configs[4]: the two-optimizer step with the 16 MB discriminator arena at tensor 2048 (the CPU oracle takes
+    # ~25 s per iteration at this size: 3 steps)
+    ("factor_celeba", "factor", (3, 64, 64), 2048, 202599, 1e-4, 1e-5, 3),
 ])
-def test_ten_step_trajectory_at_bench_batch(name, loss, img, B, n_data, lr, lr_disc):
+def test_ten_step_trajectory_at_bench_batch(name, loss, img, B, n_data, lr, lr_disc, steps):
     seed = 1234
     model, opt, loss_f = _native(loss, img, seed, n_data, lr, lr_disc, True)
     if name == "btcvae_b128":
@@ -102,10 +124,14 @@ def test_ten_step_trajectory_at_bench_batch(name, loss, img, B, n_data, lr, lr_d
     hp = dict(HP, n_data=n_data, lr_disc=lr_disc)
     orc = O.OracleTrainer(loss, hp, img, 10, lr=lr, lr_disc=lr_disc, steps_anneal=HP["reg_anneal"], params=params,
                           dparams=dparams)
+    p0 = {k: v.detach().clone() for k, v in orc.params.items()}
+    d0 = {k: v.detach().clone() for k, v in orc.dparams.items()} if loss == "factor" else {}
+    for k, p in model.named_parameters():            # both start from the same point (bit-identical initialisation)
+        assert torch.equal(p.detach().cpu(), p0[k]), k
     gen = torch.Generator().manual_seed(seed + 1)
     data_d = torch.empty((B,) + img, device=DEV)     # the batch keeps its address (plans are keyed on it)
     got, want = [], []
-    for step in range(10):
+    for step in range(steps):
         data = torch.rand((B,) + img, generator=gen)
         data_d.copy_(data)
         if loss == "factor":
@@ -123,9 +149,12 @@ def test_ten_step_trajectory_at_bench_batch(name, loss, img, B, n_data, lr, lr_d
     np.testing.assert_allclose(got, want, rtol=1e-3, err_msg="%s: loss trajectory" % name)
     np.testing.assert_allclose(got[0], want[0], rtol=1e-5, err_msg="%s: first loss" % name)
     assert want[-1] < want[0]                        # the workload actually trains
-    for k, p in model.named_parameters():            # parameters after 10 Adam steps: each update is <= ~lr in magnitude
-        d = (p.detach().cpu() - orc.params[k].detach()).abs().max().item()
-        assert d <= 2.5 * lr * 10, "%s: param %s after 10 steps: max diff %.3e" % (name, k, d)
+    for k, p in model.named_parameters():            # the accumulated Adam updates agree with the oracle's
+        _update_agreement(p0[k], p.detach().cpu(), orc.params[k].detach(), "%s: %s" % (name, k), lr, steps)
+    if loss == "factor":
+        for k, p in loss_f.discriminator.named_parameters():
+            ko = k if k in d0 else k.replace("_", ".")
+            _update_agreement(d0[ko], p.detach().cpu(), orc.dparams[ko].detach(), "%s: discriminator %s" % (name, k), lr_disc, steps)
 
 
 def test_flat_optimizer_with_the_autograd_path_is_refused():
