@@ -169,12 +169,17 @@ __global__ __launch_bounds__(256, (MODE == 1 && C == 3) ? 3 : 4) void k_down_thi
       if (act == DVAE_ACT_RELU) v = v > 0.f ? v : 0.f;
       if (MASK) v = mv[e] > 0.f ? v : 0.f;
       if (MODE == 2) {
-        const uint32_t lo = __builtin_amdgcn_readlane(word, sx0), hi = __builtin_amdgcn_readlane(word, sx0 + 4);
-        v = (((h ? hi : lo) >> i) & 1u) ? v : 0.f;
+        // the words of the two pixels ARE the lane mask of this register: lane l < 32 = channel l of pixel sx0 (bit l of its
+        // word), lane 32 + l = channel l of pixel sx0 + 4 -- two v_readlane and one v_cndmask on the scalar pair
+        const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(word, sx0 + 4) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane(word, sx0);
+        v = __builtin_amdgcn_inverse_ballot_w64(m) ? v : 0.f;
       }
       if (MODE == 3) {
         const unsigned long long b = __builtin_amdgcn_ballot_w64(v > 0.f);   // bit l = lane l: low half pixel sx0, high half sx0 + 4
-        word = i == sx0 ? (uint32_t)b : (i == sx0 + 4 ? (uint32_t)(b >> 32) : word);
+        // lane sx0 keeps the low word, lane sx0 + 4 the high one (constant one-hot lane masks: a scalar move + a v_cndmask each)
+        word = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull << sx0) ? (uint32_t)b : word;
+        word = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull << (sx0 + 4)) ? (uint32_t)(b >> 32) : word;
       }
       out[rowbase + sx * 32] = v;
     }

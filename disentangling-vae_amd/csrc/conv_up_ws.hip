@@ -176,6 +176,15 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
       const int m = pp / HS, l = pp % HS;
       ooff[mt] = ((2 * m + py) * HB + 2 * l + px) * 32 + i;
     }
+    // OUTBITS: lane L of `wordv` collects the bit plane word of big pixel bpix(L): L = mt * 32 + hh * 16 + e <-> D-fragment
+    // row e of M-tile mt, lane half hh
+    uint32_t wordv = 0;
+    int bpix = 0;
+    if (OUTBITS) {
+      const int e_ = lane & 15, hh = (lane >> 4) & 1, mt_ = lane >> 5;
+      const int pp = mt_ * 32 + 4 * hh + (e_ & 3) + 8 * (e_ >> 2);
+      bpix = (2 * (pp / HS) + py) * HB + 2 * (pp % HS) + px;
+    }
     struct Acc { f32x16 a0, a1; };
     // bias / activation of D-fragment rows [e0, e1) of a finished unit -> its output image (lanes 0-31 / 32-63 of a
     // store: two pixels x 32 channels)
@@ -190,16 +199,18 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
         ob[ooff[0] + d] = v0;
         ob[ooff[1] + d] = v1;
         if (OUTBITS) {
-          // output image `ob` is out0 + b * UPWS_OUT_FLOATS: its bit image is bimg + b * 256 (pixel index = float offset / 32).
-          // Lane 0 writes both words of a ballot: the upper lane half's pixel is 4 small = 8 big columns to the right
+          // one ballot per D-fragment row: its two words (lanes 0-31 / 32-63 = the 32 channels of two pixels) go to lanes
+          // mt * 32 + e and mt * 32 + 16 + e of `wordv` -- v_writelane_b32 from the scalar pair, no exec juggling and no
+          // branch inside the software-pipelined MFMA loop (s_nop: a VALU-written SGPR read by v_writelane)
           const unsigned long long b0 = __builtin_amdgcn_ballot_w64(v0 > 0.f), b1 = __builtin_amdgcn_ballot_w64(v1 > 0.f);
-          if (lane == 0) {
-            uint32_t* bi = bimg + ((ob - out0) >> 5) + (d >> 5);
-            bi[ooff[0] >> 5] = (uint32_t)b0; bi[(ooff[0] >> 5) + 8] = (uint32_t)(b0 >> 32);
-            bi[ooff[1] >> 5] = (uint32_t)b1; bi[(ooff[1] >> 5) + 8] = (uint32_t)(b1 >> 32);
-          }
+          asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)b0), "n"(e));
+          asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)(b0 >> 32)), "n"(16 + e));
+          asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)b1), "n"(32 + e));
+          asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)(b1 >> 32)), "n"(48 + e));
         }
       }
+      // the unit's 64 words of this wave: output image `ob` is out0 + b * UPWS_OUT_FLOATS, its bit image bimg + b * 256
+      if (OUTBITS && e1 == 16) bimg[((ob - out0) >> 5) + bpix] = wordv;
     };
     // One unit: 128 MFMAs into C from the input image `in`; the PREVIOUS unit's results P are finished (bias, ReLU, LDS
     // image `pob`) in the shadow of the first 8 MFMA groups -- the matrix core never waits for an epilogue.
@@ -254,6 +265,7 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
     __syncthreads();                                 // the last unit's image is visible to the memory waves
   } else {
     // ---------------------------------------------------------------- memory waves
+    const unsigned bofs = 4 * (ht & 7);
     f32x4 mk[MASK == 1 ? 8 : 1];
     uint32_t mw[MASK == 2 ? 8 : 1];                  // bit plane words of this thread's 8 chunks (chunk = 4 channels of a pixel)
     auto drain = [&](int u, int b) {
@@ -269,9 +281,14 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
           for (int x = 0; x < 4; ++x) v[x] = mk[j][x] > 0.f ? v[x] : 0.f;
         }
         if (MASK == 2) {
-          const uint32_t nib = mw[j] >> (4 * (ht & 7));          // channels 4 (ht & 7) .. + 3 of pixel (ht + 256 j) / 8
+          // channels 4 (ht & 7) .. + 3 of pixel (ht + 256 j) / 8: bit -> 0 / all-ones (v_bfe_i32 at a per-thread constant
+          // offset), then AND: two instructions per element, like the fp32 mask's compare + select
 #pragma unroll
-          for (int x = 0; x < 4; ++x) v[x] = ((nib >> x) & 1u) ? v[x] : 0.f;
+          for (int x = 0; x < 4; ++x) {
+            const int on = __builtin_amdgcn_sbfe((int)mw[j], bofs + x, 1);
+            const float f = v[x];
+            v[x] = __int_as_float(__float_as_int(f) & on);
+          }
         }
         if (!(abl & 1)) *reinterpret_cast<f32x4*>(dst + c) = v;
       }

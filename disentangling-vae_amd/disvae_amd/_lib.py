@@ -215,10 +215,25 @@ def _pack(ctype, v):
     return int(v) & 0xFFFFFFFFFFFFFFFF
 
 
+TRACE = None     # measurement hook (bench.py): {"names": set of entry points, "out": list} -> every matching launch is bracketed
+                 # by HIP events on ITS stream (the last argument) and appended as (name, args, start_event, end_event)
+
+
 def call(name, *args):
     """Call an int-returning entry point, raise on a non-zero status."""
     h = lib()
     fn = getattr(h, name)
+    if TRACE is not None and name in TRACE["names"] and _REC is None:
+        import torch
+        st = torch.cuda.ExternalStream(args[-1]) if args[-1] else torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        rc = fn(*args)
+        e1.record(st)
+        TRACE["out"].append((name, args, e0, e1))
+        if rc != 0:
+            raise DvaeHipError("%s failed (%d): %s" % (name, rc, h.dvae_last_error().decode()))
+        return
     if _REC is not None:
         # frozen copy of the launch: the arguments as 64-bit words (replayed by dvae_plan_run, one foreign call per run of
         # consecutive entry-point calls) when the entry point is replayable, else pre-converted to their ctypes

@@ -1,4 +1,5 @@
-"""Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite db) as a short table."""
+"""Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite db) as a short table.
+    python tools/prof_summary.py prof_results.db [steps]      (steps omitted: the number of k_stage_weights launches)"""
 import re
 import sqlite3
 import sys
@@ -26,6 +27,8 @@ def main(db, steps):
         a[0] += calls
         a[1] += total
     tot = sum(v[1] for v in agg.values())
+    if steps <= 0:                 # one k_stage_weights launch per training iteration (settle + warm-up + timed steps)
+        steps = max(1, agg.get("k_stage_weights", [1])[0])
     print("| kernel | calls | total us | avg us | %% | us/step (%d steps) |" % steps)
     print("|---|---|---|---|---|---|")
     for k, (calls, total) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -34,4 +37,4 @@ def main(db, steps):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)     # 0: infer the step count

@@ -170,7 +170,7 @@ if has prof; then
   echo "== rocprofv3 kernel stats"
   rm -rf gpurun_out/prof
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o prof -- python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in > "$REPO/gpurun_out/prof.log" 2>&1)
-  python tools/prof_summary.py gpurun_out/prof/prof_results.db 13 > gpurun_out/${TAG}_kernel_stats.md; head -n 30 gpurun_out/${TAG}_kernel_stats.md
+  python tools/prof_summary.py gpurun_out/prof/prof_results.db > gpurun_out/${TAG}_kernel_stats.md; head -n 30 gpurun_out/${TAG}_kernel_stats.md
   python tools/timeline.py gpurun_out/prof/prof_results.db > gpurun_out/${TAG}_timeline.md 2>&1; tail -n 2 gpurun_out/${TAG}_timeline.md
   rm -rf gpurun_out/prof
 fi
