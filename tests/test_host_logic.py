@@ -222,9 +222,9 @@ def test_unknown_replay_mode_is_reported(monkeypatch):
 
 
 def test_bench_reads_hbm_traffic_from_the_newest_pmc_summary(tmp_path, monkeypatch):
-    """roofline.traffic comes from the newest committed PMC summary: within a round the `_final_` summary is newer than
-    any `_runN_` one, a later round beats an earlier one; values = (fetch MB + write MB) averaged over the variants of
-    the kernel family (plain / masked)."""
+    """roofline traffic comes from the newest committed PMC summary THAT HAS THE ROW of the exact template variant: within a
+    round the `_final_` summary is newer than any `_runN_` one, a later round beats an earlier one; value = fetch MB + write MB
+    of that variant (no averaging over the plain / masked variants of a family)."""
     import importlib
     bench = importlib.import_module("bench")
     prof = tmp_path / "profiles"
@@ -235,11 +235,15 @@ def test_bench_reads_hbm_traffic_from_the_newest_pmc_summary(tmp_path, monkeypat
                                                           "| k_up32ws<16, false> | 1 | 50.0 | 130.0 | 0.6 |\n")
     (prof / "r01_run31_pmc_summary.md").write_text(head + "| k_up32ws<16, true> | 1 | 1.0 | 1.0 | 0.5 |\n")
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    bytes_, src = bench.pmc_traffic("k_up32ws<16")
+    bytes_, src = bench.pmc_traffic("k_up32ws<16, true>")
     assert src == os.path.join("profiles", "r02_final_pmc_summary.md")
-    assert abs(bytes_ - (310.0 + 180.0) / 2 * 1e6) < 1.0
+    assert abs(bytes_ - 310.0e6) < 1.0
+    assert abs(bench.pmc_traffic("k_up32ws<16, false>")[0] - 180.0e6) < 1.0
     (prof / "r03_run1_pmc_summary.md").write_text(head + "| k_up32ws<16, true> | 1 | 170.0 | 130.0 | 0.5 |\n")
-    assert bench.pmc_traffic("k_up32ws<16")[1] == os.path.join("profiles", "r03_run1_pmc_summary.md")
+    assert bench.pmc_traffic("k_up32ws<16, true>")[1] == os.path.join("profiles", "r03_run1_pmc_summary.md")
+    # a variant the newest summary does not list falls back to the newest one that does
+    assert bench.pmc_traffic("k_up32ws<16, false>")[1] == os.path.join("profiles", "r02_final_pmc_summary.md")
+    assert bench.pmc_traffic("k_up32ws<16") == (None, None)           # a prefix is not a row
     assert bench.pmc_traffic("k_no_such_kernel") == (None, None)
 
 
@@ -301,14 +305,18 @@ def test_bench_refuses_without_gpu_and_names_the_reason():
 
 
 def test_bench_workloads_are_the_baseline_configs():
-    """the four workloads of BASELINE.json (configs[1..4]) by shape, batch, loss and n_data"""
+    """the five workloads of BASELINE.json (configs[0..4]) by shape, batch, loss and n_data"""
     import json
     b = _bench_module()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = json.load(open(os.path.join(root, "BASELINE.json")))
-    assert set(b.CONFIGS) == {"btcvae_celeba", "factor_celeba", "btcvae_dsprites", "factor_dsprites"}
+    assert set(b.CONFIGS) == {"vae_mnist", "btcvae_celeba", "factor_celeba", "btcvae_dsprites", "factor_dsprites"}
+    assert sorted(c["baseline_config"] for c in b.CONFIGS.values()) == list(range(len(base["configs"])))
     for name, cfg in b.CONFIGS.items():
-        assert cfg["img"] == ((3, 64, 64) if "celeba" in name else (1, 64, 64)) or list(cfg["img"]) == ([3, 64, 64] if "celeba" in name else [1, 64, 64])
+        if name == "vae_mnist":                  # configs[0]: the reference's CPU-runnable plumbing case
+            assert tuple(cfg["img"]) == (1, 32, 32) and cfg["loss"] == "VAE" and cfg["batch"] == 64 and cfg["baseline_config"] == 0
+            continue
+        assert tuple(cfg["img"]) == ((3, 64, 64) if "celeba" in name else (1, 64, 64))
         assert cfg["loss"] == name.split("_")[0]
         assert cfg["n_data"] == (202599 if "celeba" in name else 737280)
         assert 1 <= cfg["baseline_config"] < len(base["configs"])
@@ -317,7 +325,7 @@ def test_bench_workloads_are_the_baseline_configs():
 
 
 def test_bench_pmc_traffic_parser(tmp_path, monkeypatch):
-    """`traffic` of the roofline entries = FETCH + WRITE megabytes of the newest committed PMC summary, per kernel prefix"""
+    """`traffic` of the roofline entries = FETCH + WRITE megabytes of the newest committed PMC summary, per template variant"""
     b = _bench_module()
     prof = tmp_path / "profiles"
     prof.mkdir()
@@ -326,9 +334,10 @@ def test_bench_pmc_traffic_parser(tmp_path, monkeypatch):
     (prof / "r03_final_pmc_summary.md").write_text(hdr + "| k_down32dma<16, false> | 1 | 160.0 | 33.6 | 0.6 |\n"
                                                    "| k_down32dma<16, true> | 1 | 193.6 | 33.6 | 0.5 |\n")
     monkeypatch.setattr(b, "ROOT", str(tmp_path))
-    val, src = b.pmc_traffic("k_down32dma<16")
+    val, src = b.pmc_traffic("k_down32dma<16, false>")
     assert src.endswith("r03_final_pmc_summary.md")
-    assert abs(val - ((160.0 + 33.6) + (193.6 + 33.6)) / 2 * 1e6) < 1.0
+    assert abs(val - (160.0 + 33.6) * 1e6) < 1.0
+    assert abs(b.pmc_traffic("k_down32dma<16, true>")[0] - (193.6 + 33.6) * 1e6) < 1.0
     assert b.pmc_traffic("k_nonexistent") == (None, None)
 
 
