@@ -203,6 +203,8 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
           // mt * 32 + e and mt * 32 + 16 + e of `wordv` -- v_writelane_b32 from the scalar pair, no exec juggling and no
           // branch inside the software-pipelined MFMA loop (s_nop: a VALU-written SGPR read by v_writelane)
           const unsigned long long b0 = __builtin_amdgcn_ballot_w64(v0 > 0.f), b1 = __builtin_amdgcn_ballot_w64(v1 > 0.f);
+          // (timing ablations, profiles/r04_v20_outbits_abl.txt, B = 1024: plain forward 75.5 us, + the 32 ballots 80.6,
+          // + the 64 v_writelane 87.3 -- 90.8 with lane-0 ds_write_b32 under an exec mask instead)
           asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)b0), "n"(e));
           asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)(b0 >> 32)), "n"(16 + e));
           asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)b1), "n"(32 + e));
