@@ -257,6 +257,21 @@ def record_py(fn, *args):
     return fn(*args)
 
 
+def record_on_stream(fn, *args):
+    """record_py for a torch op (or a torch.distributed collective) that goes to torch's CURRENT stream: the loss plugins
+    issue part of an iteration under ``with torch.cuda.stream(side)``, so a replay re-enters the stream that was current when
+    the op was recorded."""
+    if _REC is not None:
+        import torch
+        st = torch.cuda.current_stream()
+
+        def run():
+            with torch.cuda.stream(st):
+                fn(*args)
+        _REC.append(("p", run, (), None))
+    return fn(*args)
+
+
 def begin_record():
     global _REC
     _REC = []

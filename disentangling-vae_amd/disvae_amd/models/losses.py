@@ -16,7 +16,7 @@ import abc
 import torch
 
 from .. import _lib
-from .._lib import call, ptr, record_py
+from .._lib import call, ptr, record_on_stream, record_py
 from ..utils.math import log_importance_weights
 from .discriminator import Discriminator
 from ..graph import StepGraphs
@@ -161,7 +161,9 @@ class BaseLoss(abc.ABC):
         return model.engine.single_stream
 
     def _replay_mode(self, is_train, data):
-        if not (is_train and self._world()[0] == 1):
+        # (sharded batches replay too: the collectives and the torch ops around them are recorded plan entries -- C-ABI calls
+        # with the RCCL transport, host callables re-entering their stream with torch.distributed: disvae_amd/parallel.py)
+        if not is_train:
             return None
         if self.replay == "auto":
             return "plan" if data.numel() <= self.AUTO_PLAN_ELEMS else None
@@ -172,7 +174,7 @@ class BaseLoss(abc.ABC):
         batch pointer, the stream, and the few Python-side switches passed as scalars."""
         return (id(model), data.shape, data.data_ptr(), injected, _stream(), model.arena.flat.data_ptr(),
                 model.arena.grad.data_ptr(), _lib.ALLOC_GEN[0], self.rec_dist, getattr(self, "is_mss", None),
-                model.engine.single_stream, model.engine.eager_wgrad)
+                model.engine.single_stream, model.engine.eager_wgrad, id(self.comm), self.estimator)
 
     @abc.abstractmethod
     def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):
@@ -459,7 +461,7 @@ class _SingleOptimizerLoss(BaseLoss):
                         dmu_x, dlv_x = dmu_all, dlv_all
                     if world > ew:                # local estimator: its mean runs over B, the loss over B * world
                         for t_ in (dz_x, dmu_x, dlv_x):
-                            t_.mul_(1.0 / world)
+                            record_on_stream(t_.mul_, 1.0 / world)
         # decoder convT stack; its last layer also evaluates the reconstruction likelihood and dL/dlogit
         eng.decode_convs(buf, B, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         if self.KIND == _lib.LOSS_BTCVAE:
@@ -699,7 +701,8 @@ class FactorKLoss(BaseLoss):
         call("dvae_disc_losses", ptr(logits), Bh, ptr(sc.coef), ptr(sc.disc_sums), ptr(g_dtc), ptr(g_tc), s)
         if world > 1:
             # the CE / tc means run over the global half batch
-            g_dtc.mul_(1.0 / world); g_tc.mul_(1.0 / world)
+            record_on_stream(g_dtc.mul_, 1.0 / world)
+            record_on_stream(g_tc.mul_, 1.0 / world)
         if world > 1:          # off the critical path: first consumer is reparam_kl_bwd, after decode_backward's join
             call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), s)
             eng.fork_side()

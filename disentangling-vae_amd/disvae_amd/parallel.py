@@ -27,7 +27,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from ._lib import call, ptr
+from ._lib import call, ptr, record_on_stream
 
 
 class _Done:
@@ -47,23 +47,42 @@ class Comm:
         self._bufs = {}
 
     # ---- primitives --------------------------------------------------------------------------
+    # Every collective (and every torch op around one) is issued through _lib.record_on_stream / record_py: a recorded
+    # launch plan (disvae_amd/graph.py) then contains them and replays them in place, so the plan stays usable when the
+    # batch is sharded.
     def all_reduce(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        record_on_stream(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
         return t
 
     def all_reduce_async(self, t):
         """Start a sum-all-reduce of `t` (ordered after the work already enqueued on the current stream) and return a
         handle; ``handle.wait()`` orders the current stream after it.  Used to overlap the decoder half of the gradient
         arena (and the discriminator arena) with the rest of the backward pass."""
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        group = self.group
+
+        class _Pending:
+            work = None
+
+            def start(self_inner):
+                self_inner.work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+            def finish(self_inner):
+                self_inner.work.wait()
+
+            def wait(self_inner):
+                record_on_stream(self_inner.finish)
+
+        h = _Pending()
+        record_on_stream(h.start)
+        return h
 
     def all_gather_into(self, out, t):
         """out[world * n] <- concatenation of every rank's t[n] in rank order."""
-        dist.all_gather_into_tensor(out.view(-1), t.reshape(-1), group=self.group)
+        record_on_stream(lambda: dist.all_gather_into_tensor(out.view(-1), t.reshape(-1), group=self.group))
 
     def reduce_scatter_into(self, out, t):
         """out[n] <- this rank's chunk of the element-wise sum over ranks of t[world * n]."""
-        dist.reduce_scatter_tensor(out.view(-1), t.reshape(-1), op=dist.ReduceOp.SUM, group=self.group)
+        record_on_stream(lambda: dist.reduce_scatter_tensor(out.view(-1), t.reshape(-1), op=dist.ReduceOp.SUM, group=self.group))
 
     def broadcast(self, t, src=0):
         dist.broadcast(t, src=src, group=self.group)
@@ -104,11 +123,11 @@ class Comm:
             send = z.as_strided((3, B, D), (B * D, D, 1))
         else:
             send = self._buf("lat_send", (3, B, D), z)
-            torch.stack((z, mu, logvar), out=send)
+            record_on_stream(lambda: torch.stack((z, mu, logvar), out=send))
         recv = self._buf("lat_recv", (self.world_size, 3, B, D), z)
         self.all_gather_into(recv, send)
         glob = self._buf("lat_glob", (3, self.world_size * B, D), z)
-        glob.view(3, self.world_size, B, D).copy_(recv.permute(1, 0, 2, 3))
+        record_on_stream(glob.view(3, self.world_size, B, D).copy_, recv.permute(1, 0, 2, 3))
         return glob[0], glob[1], glob[2]
 
     def reduce_scatter_cols(self, dmu_all, dlv_all):
@@ -118,7 +137,7 @@ class Comm:
         B = dmu_all.shape[0] // W
         D = dmu_all.shape[1]
         send = self._buf("cols_send", (W, 2, B, D), dmu_all)
-        torch.stack((dmu_all.reshape(W, B, D), dlv_all.reshape(W, B, D)), dim=1, out=send)
+        record_on_stream(lambda: torch.stack((dmu_all.reshape(W, B, D), dlv_all.reshape(W, B, D)), dim=1, out=send))
         out = self._buf("cols_loc", (2, B, D), dmu_all)
         self.reduce_scatter_into(out, send)
         return out[0], out[1]

@@ -37,7 +37,9 @@ def _make(loss, lr):
     return model, opt, loss_f
 
 
-def _worker(rank, world, port, loss, q, backend="gloo", transport="torch", device=0):
+def _worker(rank, world, port, loss, q, backend="gloo", transport="torch", device=0, replay=None):
+    """replay="plan": three iterations on the same inputs -- the first one records the sharded step's launch plan (collectives
+    included), the next two replay it; every iteration is compared with the single-process eager step on the global batch."""
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import sys
@@ -52,47 +54,53 @@ def _worker(rank, world, port, loss, q, backend="gloo", transport="torch", devic
         gen = torch.Generator().manual_seed(5)
         data_g = torch.rand((world * Bl,) + IMG, generator=gen)
         D = 10
-        # ---- single-process reference on the global batch (every rank computes it; deterministic) ----
-        m0, o0, l0 = _make(loss, lr)
-        if loss == "factor":
-            half = world * Bl // 2
-            eps1, eps2 = torch.randn(half, D, generator=gen), torch.randn(half, D, generator=gen)
-            perms = torch.stack([torch.randperm(half, generator=gen) for _ in range(D)])
-            # global tensor = [data1 of all ranks ; data2 of all ranks]: rank r owns rows r*h..(r+1)*h of each half
-            out0 = l0.call_optimize(data_g.cuda(), m0, o0, defaultdict(list), noise=(eps1.cuda(), eps2.cuda(), perms))
-        else:
-            eps = torch.randn(world * Bl, D, generator=gen)
-            out0 = l0.fused_step(data_g.cuda(), m0, o0, defaultdict(list), eps=eps.cuda())
-        ref_loss = out0.item()
-        ref_grad = m0.arena.grad.clone()
-        ref_param = m0.arena.flat.clone()
-        # ---- sharded run ----
-        m1, o1, l1 = _make(loss, lr)
+        m0, o0, l0 = _make(loss, lr)             # single-process reference on the global batch (every rank computes it)
+        l0.replay = None
+        m1, o1, l1 = _make(loss, lr)             # the sharded run
+        l1.replay = replay
         if backend == "gloo":
             from ddp_util import HostStagedComm
             comm = parallel.data_parallel(m1, l1, comm=HostStagedComm())
         else:
             comm = parallel.data_parallel(m1, l1, transport=transport)
         assert comm.world_size == world
-        st = defaultdict(list)
         if loss == "factor":
+            half = world * Bl // 2
             hl = Bl // 2
             sl = slice(rank * hl, (rank + 1) * hl)
-            local = torch.cat((data_g[:half][sl], data_g[half:][sl]))
-            out1 = l1.call_optimize(local.cuda(), m1, o1, st, noise=(eps1[sl].cuda(), eps2[sl].cuda(), perms))
-            dref = l0.discriminator.arena
-            d1 = l1.discriminator.arena
-            derr = ((d1.grad - dref.grad).abs().max() / dref.grad.abs().max()).item()
-            assert derr < 2e-5, "disc grad err %.3e" % derr
-            assert (d1.flat - dref.flat).abs().max().item() <= 2.5 * HP["lr_disc"]
+            eps1, eps2 = torch.randn(half, D, generator=gen), torch.randn(half, D, generator=gen)
+            perms = torch.stack([torch.randperm(half, generator=gen) for _ in range(D)])
+            # global tensor = [data1 of all ranks ; data2 of all ranks]: rank r owns rows r*h..(r+1)*h of each half
+            g_in = (data_g.cuda(), (eps1.cuda(), eps2.cuda(), perms))
+            l_in = (torch.cat((data_g[:half][sl], data_g[half:][sl])).cuda(), (eps1[sl].cuda(), eps2[sl].cuda(), perms))
         else:
             sl = slice(rank * Bl, (rank + 1) * Bl)
-            out1 = l1.fused_step(data_g[sl].cuda(), m1, o1, st, eps=eps[sl].cuda())
-        err = ((m1.arena.grad - ref_grad).abs().max() / ref_grad.abs().max()).item()
-        assert err < 2e-5, "grad err %.3e" % err
-        assert abs(out1.item() - ref_loss) <= 2e-6 * abs(ref_loss), (out1.item(), ref_loss)
-        assert (m1.arena.flat - ref_param).abs().max().item() <= 2.5 * lr
-        assert st["loss"] and abs(st["loss"][0] - ref_loss) <= 2e-6 * abs(ref_loss)
+            eps = torch.randn(world * Bl, D, generator=gen)
+            g_in = (data_g.cuda(), eps.cuda())
+            l_in = (data_g[sl].cuda(), eps[sl].cuda())
+        for it in range(3 if replay else 1):
+            st = defaultdict(list)
+            if loss == "factor":
+                out0 = l0.call_optimize(g_in[0], m0, o0, defaultdict(list), noise=g_in[1])
+                out1 = l1.call_optimize(l_in[0], m1, o1, st, noise=l_in[1])
+                dref, d1 = l0.discriminator.arena, l1.discriminator.arena
+                derr = ((d1.grad - dref.grad).abs().max() / dref.grad.abs().max()).item()
+                assert derr < 2e-5, "iteration %d: disc grad err %.3e" % (it, derr)
+                assert (d1.flat - dref.flat).abs().max().item() <= 2.5 * HP["lr_disc"] * (it + 1)
+            else:
+                out0 = l0.fused_step(g_in[0], m0, o0, defaultdict(list), eps=g_in[1])
+                out1 = l1.fused_step(l_in[0], m1, o1, st, eps=l_in[1])
+            ref_loss = out0.item()
+            err = ((m1.arena.grad - m0.arena.grad).abs().max() / m0.arena.grad.abs().max()).item()
+            assert err < 2e-5 * (it + 1), "iteration %d: grad err %.3e" % (it, err)
+            assert abs(out1.item() - ref_loss) <= 2e-6 * (it + 1) * abs(ref_loss), (it, out1.item(), ref_loss)
+            assert (m1.arena.flat - m0.arena.flat).abs().max().item() <= 2.5 * lr * (it + 1)
+            if it == 0:
+                assert st["loss"] and abs(st["loss"][0] - ref_loss) <= 2e-6 * abs(ref_loss)
+        if replay:
+            # the first iteration allocates (workspace, gather buffers), which invalidates the plan it recorded: iteration 2
+            # records again, iteration 3 (at least) is a replay
+            assert l1._graphs.replays >= 1, l1._graphs.replays
         comm.close()
         q.put((rank, "ok"))
     except Exception:  # noqa
@@ -144,15 +152,34 @@ def test_sharded_step_over_rccl_on_all_visible_gpus(loss, transport):
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
+@pytest.mark.parametrize("loss", ["btcvae", "factor"])
+def test_sharded_step_replays_from_a_recorded_plan(loss):
+    """Two ranks (gloo, one GPU): the launch plan of the SHARDED step -- kernels, stream forks / joins and the collectives --
+    is recorded in iteration 1 and replayed in iterations 2 and 3; every iteration equals the single-process eager step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, loss, q, "gloo", "torch", 0, "plan")) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=280) for _ in range(world)]
+    for p_ in procs:
+        p_.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+@pytest.mark.parametrize("replay", [None, "plan"])
 @pytest.mark.parametrize("transport", ["torch", "rccl"])
 @pytest.mark.parametrize("loss", ["btcvae", "factor"])
-def test_rccl_call_sites_single_rank(loss, transport):
+def test_rccl_call_sites_single_rank(loss, transport, replay):
     """backend "nccl" (= RCCL) with ONE rank on the one GPU of the test box: the same collectives'
     call sites as on 8 GPUs (broadcast, list all_gather, sum all_reduce, async bucket all_reduce under
     the side-stream context) run through RCCL itself; results must equal the communicator-free step."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p_ = ctx.Process(target=_worker, args=(0, 1, _free_port(), loss, q, "nccl", transport))
+    p_ = ctx.Process(target=_worker, args=(0, 1, _free_port(), loss, q, "nccl", transport, 0, replay))
     p_.start()
     rank, msg = q.get(timeout=280)
     p_.join(timeout=60)
