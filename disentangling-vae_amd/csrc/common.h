@@ -133,6 +133,7 @@ int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* 
                         int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0);
 // thin paths (Cb in {1,3}, Cs == 32, big NCHW 64x64 / small NHWC 32x32)
 int launch_down_thin(const ConvArgs& a, hipStream_t s);
+int launch_down_thin_ws(const ConvArgs& a, hipStream_t s);   // conv_thin_ws.hip: fp32 images, wave-specialised; 1 if not covered
 int launch_up_thin(const ConvArgs& a, hipStream_t s);
 // fused convT3 + sigmoid + reconstruction loss (+ dL/dlogit); returns 1 if the shape is not covered
 int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int dist, const float* coef,

@@ -651,6 +651,7 @@ static bool thin_applicable(const ConvArgs& a) {
 int launch_down_thin(const ConvArgs& a, hipStream_t s) {
   if (!thin_applicable(a) || a.big_layout != DVAE_NCHW || a.out_layout != DVAE_NHWC) return 1;
   if (a.act != DVAE_ACT_NONE && a.act != DVAE_ACT_RELU) return 1;
+  if (launch_down_thin_ws(a, s) == 0) return 0;         // large batches: the wave-specialised kernel (conv_thin_ws.hip)
   const int n_units = a.N * 8;
   const int grid = n_units < 1536 ? n_units : 1536;     // 6 resident workgroups per CU
   if ((a.mask_bits && (a.mask || a.out_bits)) || (a.out_bits && a.mask)) return 1;

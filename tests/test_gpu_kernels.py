@@ -22,6 +22,7 @@ def _rand(*shape, seed=0, scale=1.0):
 CONV_CASES = [
     # N, Cin, H, x_layout                 (Cout = 32, y NHWC)
     (3, 1, 64, _lib.NCHW), (5, 3, 64, _lib.NCHW),          # conv1 (thin, MFMA K=16C)
+    (200, 3, 64, _lib.NCHW), (193, 1, 64, _lib.NCHW),      # conv1 at batches that take the wave-specialised kernel (conv_thin_ws.hip)
     (3, 32, 32, _lib.NHWC), (70, 32, 32, _lib.NHWC),       # conv2 (MFMA HS=16; 280 units > 256 workgroups)
     (5, 32, 16, _lib.NHWC), (6, 32, 8, _lib.NHWC), (9, 32, 8, _lib.NHWC),   # conv3 / conv_64 (tails)
     (2, 1, 32, _lib.NCHW),                                  # MNIST geometry -> generic kernel
@@ -70,6 +71,7 @@ CONVT_CASES = [
     (3, 4, 32, _lib.NHWC, _lib.ACT_RELU), (6, 4, 32, _lib.NHWC, _lib.ACT_RELU), (5, 8, 32, _lib.NHWC, _lib.ACT_RELU),
     (3, 16, 32, _lib.NHWC, _lib.ACT_RELU), (70, 16, 32, _lib.NHWC, _lib.ACT_RELU),
     (3, 32, 1, _lib.NCHW, _lib.ACT_SIGMOID), (5, 32, 3, _lib.NCHW, _lib.ACT_SIGMOID),
+    (200, 32, 3, _lib.NCHW, _lib.ACT_SIGMOID), (193, 32, 1, _lib.NCHW, _lib.ACT_SIGMOID),   # convT3: its input gradient on conv_thin_ws.hip
     (2, 16, 1, _lib.NCHW, _lib.ACT_SIGMOID),
 ]
 
