@@ -138,6 +138,8 @@ int launch_up_thin(const ConvArgs& a, hipStream_t s);
 // fused convT3 + sigmoid + reconstruction loss (+ dL/dlogit); returns 1 if the shape is not covered
 int launch_up_thin_recon(const ConvArgs& a, const float* target, float* g, int dist, const float* coef,
                          float* partials, hipStream_t s);
+int launch_wgrad_thin_ws(const float* big, const float* small, float* ws, int bias_from_big, int N, int Cb, int* grid_out,
+                         hipStream_t s);   // conv_thin_ws.hip: partial sums only; 1 if not covered
 int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big,
                       int N, int Cb, int Hs, float* ws, hipStream_t s);
 // uint8 input image x[N,C,64,64] (NCHW), converted on the fly with ToTensor's float(v)/255; return 1 if C is not 1 or 3

@@ -735,6 +735,15 @@ int launch_wgrad_thin_u8(const uint8_t* x, const float* small, float* dw, float*
 int launch_wgrad_thin(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N, int Cb,
                       int Hs, float* ws, hipStream_t s) {
   if (!(Cb == 1 || Cb == 3) || Hs != 32) return 1;
+  {                                                     // large batches: the wave-specialised kernel (conv_thin_ws.hip)
+    int wgrid = 0;
+    if (launch_wgrad_thin_ws(big, small, ws, bias_from_big, N, Cb, &wgrid, s) == 0) {
+      if (Cb == 1) hipLaunchKernelGGL(k_wgrad_thin_reduce<1>, dim3(WT_REDUCE_BLOCKS(1)), dim3(256), 0, s, ws, dw, db, bias_from_big, wgrid);
+      else hipLaunchKernelGGL(k_wgrad_thin_reduce<3>, dim3(WT_REDUCE_BLOCKS(3)), dim3(256), 0, s, ws, dw, db, bias_from_big, wgrid);
+      DVAE_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const int n_units = N * 8;
   int grid = n_units < WT_MAX_BLOCKS ? n_units : WT_MAX_BLOCKS;
   {

@@ -27,6 +27,7 @@
 // plane.  The accumulation order is k_down_thin's (one chain over k = 16 cb + 4 kh + kw): results are bit-identical to it.
 #include <type_traits>
 #include "common.h"
+#include "wgrad_reduce.h"
 
 #pragma clang diagnostic ignored "-Winline-asm"     // dma4 names m0 in its clobber list on purpose
 
@@ -389,6 +390,271 @@ int launch_down_thin_ws(const ConvArgs& a, hipStream_t s) {
   }
 #undef DVAE_DTW
   DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+// =====================================================================================================================
+// k_wgrad_thin_ws<C, BIAS_BIG>: the weight gradient of the thin ends (conv1: encoders.py:54 under training.py:157, dw[cs][cb]
+// [kh][kw] = sum over pixels of dy[n][sy][sx][cs] x[n][cb][2 sy - 1 + kh][2 sx - 1 + kw]; convT3: decoders.py:65, the same sum
+// with the roles of the tensors swapped by the caller) for fp32 images at 64x64, wave-specialised like k_down_thin_ws.
+// k_wgrad_thin (conv_thin.hip) took 58 us per launch at B = 1024 for 26 us of HBM reads (184 MB) and 31 us of matrix-core work
+// (it pads the 48 (cb, tap) columns to two 32-column tiles), one after the other (its waves load, stage and multiply in turn).
+// Here:
+//   * v_mfma_f32_16x16x4_f32: M = 16 cs x N = 16 taps of ONE input channel x K = 4 pixels: 2 x C tiles, nothing padded
+//     (48 instead of 64 MFMA-cycles per pixel pair), six independent accumulators per wave;
+//   * waves 0-3, compute: one small row of 32 pixels each = 8 steps of 4 pixels; per step one ds_read_b64 (the dy of channels
+//     2 i, 2 i + 1: the two M tiles interleave the channels so that a lane's pair is one 8-byte read) and C ds_read_b32 (x
+//     patch values), the NEXT unit's operands read under the current unit's MFMAs; no vector memory instruction at all;
+//   * waves 4-7, loaders: both tiles HBM -> LDS by LDS-DMA, 16 + 3 C transfers of 1 KB per unit, two units ahead in a ring of
+//     three stages; image rows outside the image are masked lanes over LDS zeros, the two columns outside the image are read
+//     from a zero zone by the lanes concerned (as in k_down_thin_ws);
+//   * the accumulators live in registers for the whole kernel; at the end the four waves' partial sums are added in a fixed
+//     order through LDS and written in k_wgrad_thin's partial-buffer layout, so k_wgrad_thin_reduce finishes the job.
+// Bias gradient partials: the sum of the small-side tensor per channel (conv1), or the per-column sums of the big side
+// (BIAS_BIG, convT3: the reduction uses the four taps that cover every pixel once) -- VALU adds on the operands already read.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int C, bool BIAS_BIG>
+struct ThinWgGeo {
+  static constexpr int PLANE = 768;                        // 3 transfers of 256 floats; rows 10, 11 are never written: zeros
+  static constexpr int ZZ = 640;
+  static constexpr int SM = 128 * 32;                      // small tile: 128 pixels x 32 channels
+  static constexpr int STAGE = SM + C * PLANE;
+  static constexpr int NS = 3;
+  static constexpr int NDMA = 16 + 3 * C;
+  static constexpr int TOTAL = NS * STAGE;
+  static constexpr int NACC = 2 * C * 4;                   // accumulator registers per lane
+  static_assert(4 * (NACC + 2 + C) * 64 <= TOTAL, "the final cross-wave reduction fits the stages");
+};
+
+template <int C, bool BIAS_BIG, int ABL = 0>
+__global__ __launch_bounds__(512, 4) void k_wgrad_thin_ws(const float* __restrict__ big, const float* __restrict__ small,
+                                                          float* __restrict__ ws, int N) {
+  using G = ThinWgGeo<C, BIAS_BIG>;
+  constexpr int NT32 = (16 * C + 31) / 32;                 // k_wgrad_thin's 32-column tiles (partial-buffer layout)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int part = slot & 7;
+  const int ipi = gridDim.x >> 3;
+  const int n0 = xcd + 8 * (slot >> 3);
+  const int sy0 = part * 4;
+  auto nxt = [](int b) { return b == 2 ? 0 : b + 1; };
+
+  for (int e = tid; e < G::NS * G::STAGE / 4; e += 512) reinterpret_cast<f32x4*>(smem)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  if (wv >= 4) {
+    // ---------------------------------------------------------------- loaders
+    // transfer d = lw + 4 k: d < 16: 1 KB block d of the small tile (contiguous in memory); d >= 16: big tile, channel plane
+    // (d - 16) / 3, block (d - 16) % 3 of its 10 rows (lane l: row 4 q + l / 16, columns 4 (l % 16) ..+3)
+    const int lw = wv - 4;
+    constexpr int NPFM = (G::NDMA + 3) / 4;
+    unsigned voff[NPFM];
+    unsigned long long lanes[NPFM];
+#pragma unroll
+    for (int k = 0; k < NPFM; ++k) {
+      const int d = lw + 4 * k;
+      voff[k] = 0u;
+      bool on = false;
+      if (d < 16) {
+        on = true;
+        voff[k] = (unsigned)(d * 1024 + lane * 16);
+      } else if (d < G::NDMA) {
+        const int c = (d - 16) / 3, q = (d - 16) - 3 * c;
+        const int r = 4 * q + (lane >> 4), col = 4 * (lane & 15);
+        const int by = 2 * sy0 - 1 + r;
+        on = r < 10 && by >= 0 && by < 64;
+        voff[k] = on ? (unsigned)((c * 64 + by) * 64 + col) * 4u : 0u;
+      }
+      lanes[k] = __builtin_amdgcn_ballot_w64(on);
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    const float* ibase = big + (long)n0 * C * 4096;                  // wave-uniform; + ipi images per issue
+    const float* sbase = small + (((long)n0 * 32 + sy0) * 32) * 32;
+    auto issue = [&](int buf) {
+      if (ABL & 4) return;
+      const unsigned base = lds0 + (unsigned)buf * (G::STAGE * 4u);
+#pragma unroll
+      for (int k = 0; k < NPFM; ++k) {
+        const int d = lw + 4 * k;                          // wave-uniform
+        if (d < 16) dma16s(sbase, voff[k], __builtin_amdgcn_readfirstlane(base + (unsigned)d * 1024u), lanes[k]);
+        else if (d < G::NDMA)
+          dma16s(ibase, voff[k], __builtin_amdgcn_readfirstlane(base + (unsigned)(G::SM + ((d - 16) / 3) * G::PLANE + ((d - 16) % 3) * 256) * 4u), lanes[k]);
+      }
+      ibase += (long)ipi * C * 4096;
+      sbase += (long)ipi * 32768;
+    };
+    auto wait_landed = [&](bool newest_in_flight) {        // all transfers but the newest tile's have landed
+      if (!newest_in_flight) { wait_vmcnt<0>(); return; }
+      // transfers per tile of this wave: the d = lw + 4 k below NDMA
+      if (lw == 0) wait_vmcnt<(G::NDMA + 3) / 4>();
+      else if (lw == 1) wait_vmcnt<(G::NDMA + 2) / 4>();
+      else if (lw == 2) wait_vmcnt<(G::NDMA + 1) / 4>();
+      else wait_vmcnt<G::NDMA / 4>();
+    };
+    int n = n0;
+    if (n < N) issue(0);
+    if (n + ipi < N) issue(1);
+    wait_landed(n + ipi < N);                              // tile(n0) has landed
+    thin_barrier();                                        // prologue barrier
+    int buf = 0;
+    for (; n < N; n += ipi) {
+      // the compute waves read tile(n + ipi) next (stage buf + 1); stage buf + 2 was released by the last barrier
+      const bool more = n + 2 * ipi < N;
+      if (more) issue(buf >= 1 ? buf - 1 : 2);
+      wait_landed(more);                                   // tile(n + ipi) has landed
+      thin_barrier();
+      buf = nxt(buf);
+    }
+    thin_barrier();                                        // final barrier: every tile is consumed
+    thin_barrier();                                        // the reduction's barriers (the loaders take part: s_barrier counts
+    thin_barrier();                                        // every wave of the workgroup)
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute waves: wave = small row sy0 + wv
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int kh = i16 >> 2, kw = i16 & 3;
+  // A (small side): pixel 4 t + kq of the row, channels 2 i16, 2 i16 + 1: float offset (wv * 32 + 4 t + kq) * 32 + 2 i16
+  const int aoff = (wv * 32 + kq) * 32 + 2 * i16;          // + 128 t
+  // B (big side), plane nt: row 2 wv + kh, column 2 (4 t + kq) - 1 + kw; lanes that would read column -1 (t = 0, kq = 0,
+  // kw = 0) or column 64 (t = 7, kq = 3, kw = 3) read the plane's zero zone instead
+  const int bmid = G::SM + (2 * wv + kh) * 64 + 2 * kq - 1 + kw;    // + 8 t
+  const int bfirst = (kq == 0 && kw == 0) ? G::SM + G::ZZ : bmid;
+  const int blast = (kq == 3 && kw == 3) ? G::SM + G::ZZ : bmid + 56;
+  f32x4 acc[2][C];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x2 sumS = {0.f, 0.f};
+  float sumB[C];
+#pragma unroll
+  for (int nt = 0; nt < C; ++nt) sumB[nt] = 0.f;
+  thin_barrier();                                          // prologue barrier: tile(n0) is in stage 0
+
+  // Operands: the NEXT unit's are read under the current unit's MFMAs, step for step (the barrier in front of a unit says
+  // that the next tile has landed).  A tile is therefore read completely one unit BEFORE its MFMAs run: the loaders refill
+  // the stage of tile u - 1 while unit u - 1 runs, which a shorter look-ahead (reading a tile during its own unit) would race with.
+  struct Ops {                                             // operands of one unit
+    f32x2 a[8];
+    float b[8][C];
+  };
+  auto read_step = [&](int buf, Ops& o, int t) {
+    const float* st = smem + buf * G::STAGE;
+    o.a[t] = *reinterpret_cast<const f32x2*>(st + aoff + 128 * t);
+#pragma unroll
+    for (int nt = 0; nt < C; ++nt) {
+      const int base = t == 0 ? bfirst : (t == 7 ? blast : bmid + 8 * t);
+      o.b[t][nt] = st[base + nt * G::PLANE];
+    }
+  };
+  // the 8 steps of the unit whose operands are in `oc`; every step refills its registers with the next unit's operands (stage
+  // `nbuf`; stale and unused if there is none)
+  auto unit = [&](Ops& oc, int nbuf) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): this unit's operands have returned (its tile is read)
+    thin_barrier();                                        // ... and the next tile has landed
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (BIAS_BIG) {
+#pragma unroll
+        for (int nt = 0; nt < C; ++nt) sumB[nt] += oc.b[t][nt];
+      } else {
+        sumS += oc.a[t];
+      }
+#pragma unroll
+      for (int nt = 0; nt < C; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          if (!(ABL & 2)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(oc.a[t][mt], oc.b[t][nt], acc[mt][nt], 0, 0, 0);
+      read_step(nbuf, oc, t);                              // into the registers this step has just freed
+      __builtin_amdgcn_sched_barrier(0);                   // keep the steps in this order
+    }
+  };
+  Ops oa;
+  int n = n0, buf = 0;
+  if (n < N) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) read_step(0, oa, t);
+    for (; n < N; n += ipi) {
+      unit(oa, nxt(buf));
+      buf = nxt(buf);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  thin_barrier();                                          // final barrier: every tile is consumed, the stages are free
+
+  // cross-wave reduction in a fixed order through LDS: red[wave][slot][lane], slot = (mt * C + nt) * 4 + r, then the two
+  // (one + C) bias partials
+  constexpr int NSLOT = G::NACC + 2 + C;
+  float* red = smem;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wv * NSLOT + (mt * C + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+  red[(wv * NSLOT + G::NACC + 0) * 64 + lane] = sumS[0];
+  red[(wv * NSLOT + G::NACC + 1) * 64 + lane] = sumS[1];
+#pragma unroll
+  for (int nt = 0; nt < C; ++nt) red[(wv * NSLOT + G::NACC + 2 + nt) * 64 + lane] = sumB[nt];
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  thin_barrier();
+  constexpr int STRIDE = NT32 * 1024 + 32 + NT32 * 32;     // k_wgrad_thin's partial block: [nt32][cs][32] + sumS[32] + sumB[nt32][32]
+  float* wsw = ws + (long)blockIdx.x * STRIDE;
+  const int t4 = tid;                                      // 256 compute threads
+  auto wsum = [&](int sl, int ln) {
+    return (red[(0 * NSLOT + sl) * 64 + ln] + red[(1 * NSLOT + sl) * 64 + ln]) + (red[(2 * NSLOT + sl) * 64 + ln] + red[(3 * NSLOT + sl) * 64 + ln]);
+  };
+  // D register r of lane (i16, kq), tile (mt, nt): row 4 kq + r -> cs = 2 (4 kq + r) + mt; column i16 -> tap i16 of channel nt
+  for (int idx = t4; idx < NT32 * 1024; idx += 256) {
+    const int nt32 = idx >> 10, cs = (idx >> 5) & 31, j = idx & 31;
+    const int nidx = nt32 * 32 + j;                        // cb * 16 + tap
+    float v = 0.f;
+    if (nidx < 16 * C) {
+      const int nt = nidx >> 4, tap = nidx & 15, mt = cs & 1, row = cs >> 1;
+      v = wsum((mt * C + nt) * 4 + (row & 3), (row >> 2) * 16 + tap);
+    }
+    wsw[idx] = v;
+  }
+  if (t4 < 32) {                                           // sumS[cs]: channel 2 i16 + q of lanes (i16, kq = 0..3)
+    const int i = t4 >> 1, q = t4 & 1;
+    wsw[NT32 * 1024 + t4] = BIAS_BIG ? 0.f : (wsum(G::NACC + q, i) + wsum(G::NACC + q, 16 + i)) + (wsum(G::NACC + q, 32 + i) + wsum(G::NACC + q, 48 + i));
+  }
+  if (t4 < NT32 * 32) {                                    // sumB[column nidx]
+    const int nidx = t4;
+    float v = 0.f;
+    if (BIAS_BIG && nidx < 16 * C) {
+      const int nt = nidx >> 4, tap = nidx & 15;
+      v = (wsum(G::NACC + 2 + nt, tap) + wsum(G::NACC + 2 + nt, 16 + tap)) + (wsum(G::NACC + 2 + nt, 32 + tap) + wsum(G::NACC + 2 + nt, 48 + tap));
+    }
+    wsw[NT32 * 1024 + 32 + nidx] = v;
+  }
+  thin_barrier();
+}
+
+// fp32 images only; writes gridDim.x = *grid_out partial blocks in k_wgrad_thin's layout; returns 1 if not covered
+int launch_wgrad_thin_ws(const float* big, const float* small, float* ws, int bias_from_big, int N, int Cb, int* grid_out, hipStream_t s) {
+  static const bool off = env_off("DVAE_THIN_WS");                   // A/B switch, debug builds only
+  static const int min_n = env_int("DVAE_THIN_WS_MIN_N", 192);
+  if (off || N < min_n || (Cb != 1 && Cb != 3)) return 1;
+  if (((uintptr_t)big | (uintptr_t)small) & 15) return 1;
+  const int grid = 512;
+  static_assert(512 <= WT_MAX_BLOCKS, "the partial buffer holds the grid");
+#define DVAE_WTW(C, BB)                                                                                                    \
+  do {                                                                                                                     \
+    constexpr int lds = ThinWgGeo<C, BB>::TOTAL * 4;                                                                       \
+    static DeviceOnce attr;                                                                                                \
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)k_wgrad_thin_ws<C, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    hipLaunchKernelGGL((k_wgrad_thin_ws<C, BB>), dim3(grid), dim3(512), lds, s, big, small, ws, N);                        \
+  } while (0)
+  if (Cb == 1) { if (bias_from_big) DVAE_WTW(1, true); else DVAE_WTW(1, false); }
+  else { if (bias_from_big) DVAE_WTW(3, true); else DVAE_WTW(3, false); }
+#undef DVAE_WTW
+  DVAE_CHECK_LAUNCH();
+  *grid_out = grid;
   return 0;
 }
 

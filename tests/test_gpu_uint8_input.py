@@ -62,7 +62,17 @@ def test_u8_kernels_equal_fp32_kernels_bitwise(N, C):
     dw8, db8, dw32, db32 = (torch.full(sh, 7.0, device=DEV) for sh in ((32, C, 4, 4), (32,), (32, C, 4, 4), (32,)))
     call("dvae_conv4s2_wgrad_u8", ptr(ud), ptr(dy), ptr(dw8), ptr(db8), N, C, 64, 64, 32, ptr(ws), s)
     call("dvae_conv4s2_wgrad", ptr(xd), _lib.NCHW, ptr(dy), _lib.NHWC, ptr(dw32), ptr(db32), N, C, 64, 64, 32, ptr(ws), s)
-    assert torch.equal(dw8, dw32) and torch.equal(db8, db32)
+    if N < 192:
+        assert torch.equal(dw8, dw32) and torch.equal(db8, db32)
+    else:
+        # large fp32 batches take the wave-specialised kernel (conv_thin_ws.hip: 16x16x4 tiles, another fixed summation order
+        # over the 1024 N pixels): the same sums, equal to fp32 rounding of a sum of that length
+        refw = torch.autograd.functional.vjp(lambda ww: F.conv2d(x.double(), ww, None, stride=2, padding=1),
+                                             w.cpu().double(), from_nhwc(dy, N, 32, 32, 32).double())[1]
+        for got in (dw8, dw32):
+            check(got, refw, what="conv1 weight gradient")
+        check(db32, dy.double().sum((0, 1, 2)), what="conv1 bias gradient")
+        check(db8, dy.double().sum((0, 1, 2)), what="conv1 bias gradient (u8)")
     # fused last decoder layer: the target is the input image
     a = dev(torch.relu(torch.rand(N, 32, 32, 32, generator=g) - 0.3))
     wt = dev((torch.rand(32, C, 4, 4, generator=g) - 0.5) * 0.4)
