@@ -271,17 +271,23 @@ def thin_kernel_rooflines(B, C, device):
     nb = bits.numel() * 4.0
     # (kernel row of the PMC summary, launch, algorithmic bytes, call): what the step launches -- conv1's forward emits the bit
     # plane of its output, convT3's input gradient is masked by convT2's
+    # batches >= 192 images take the wave-specialised kernels of conv_thin_ws.hip
+    big = B >= 192
+    k_fwd = ("k_down_thin_ws<%d, 3, 0>" if big else "k_down_thin<%d, 3, float>") % C
+    k_dg = ("k_down_thin_ws<%d, 2, 0>" if big else "k_down_thin<%d, 2, float>") % C
+    k_wgT = ("k_wgrad_thin_ws<%d, true, 0>" if big else "k_wgrad_thin<%d, float>") % C
+    k_wg1 = ("k_wgrad_thin_ws<%d, false, 0>" if big else "k_wgrad_thin<%d, float>") % C
     launches = [
-        ("k_down_thin<%d, 3, float>" % C, "conv1 fwd (emits the bit plane)", nx + na + nb,
+        (k_fwd, "conv1 fwd (emits the bit plane)", nx + na + nb,
          lambda: call("dvae_conv1_fwd_bits", ptr(x), 0, ptr(w), ptr(b32), ptr(ga1), ptr(bits), B, C, s)),
         ("k_up_thin_pk<%d, true, float>" % C, "convT3 fwd + sigmoid + likelihood + dL/dlogit (staged pair records)", na + 3 * nx,
          lambda: call("dvae_convT3_fwd_staged", ptr(a1), ptr(pairs), ptr(bc), ptr(x), 0, ptr(rec), ptr(g), 0, ptr(coef),
                       ptr(parts), B, C, s)),
-        ("k_down_thin<%d, 2, float>" % C, "convT3 dgrad (masked by the bit plane)", nx + na + nb,
+        (k_dg, "convT3 dgrad (masked by the bit plane)", nx + na + nb,
          lambda: call("dvae_convT3_dgrad_bits", ptr(x), ptr(wt), ptr(bits), ptr(ga1), B, C, s)),
-        ("k_wgrad_thin<%d, float>" % C, "convT3 wgrad (+reduce)", nx + na,
+        (k_wgT, "convT3 wgrad (+reduce)", nx + na,
          lambda: call("dvae_convT4s2_wgrad", ptr(a1), NH, ptr(x), NC, ptr(dw), ptr(dbc), B, 32, 32, 32, C, ptr(ws), s)),
-        ("k_wgrad_thin<%d, float>" % C, "conv1 wgrad (+reduce)", nx + na,
+        (k_wg1, "conv1 wgrad (+reduce)", nx + na,
          lambda: call("dvae_conv4s2_wgrad", ptr(x), NC, ptr(a1), NH, ptr(dw), ptr(db), B, C, 64, 64, 32, ptr(ws), s)),
     ]
     out = []
