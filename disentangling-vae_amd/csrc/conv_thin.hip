@@ -212,7 +212,14 @@ __global__ __launch_bounds__(128) void k_up_thin(const float* __restrict__ small
   const int m = tid >> 5, l = tid & 31;
   const float gs = FUSE ? coef[DVAE_C_INV_B] : 0.f;
   float lsum = 0.f;
-  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+  // Consecutive workgroups run on different XCDs (each with its own L2), and the 8 units of an image share halo rows: with the
+  // plain round-robin order they were fetched from HBM by two XCDs each (counter traffic 1.32x the algorithmic bytes).  When
+  // the grid is a multiple of 64, workgroup b = (xcd = b & 7, slot = b >> 3) takes part slot & 7 of image xcd + 8 (slot >> 3)
+  // + (grid / 8) k: the 8 parts of an image run at the same time on ONE XCD.
+  const bool xmap = (gridDim.x & 63) == 0;
+  const int upi = xmap ? 8 * (int)(gridDim.x >> 3) : (int)gridDim.x;           // units per persistent step
+  const int unit0 = xmap ? 8 * (int)((blockIdx.x & 7) + 8 * (blockIdx.x >> 6)) + (int)((blockIdx.x >> 3) & 7) : (int)blockIdx.x;
+  for (int unit = unit0; unit < n_units; unit += upi) {
     const int n = unit >> 3, sy0 = (unit & 7) * 4;
     __syncthreads();
     {
@@ -377,7 +384,14 @@ __global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ sm
   const int m = tid >> 5, l = tid & 31;
   const float gs = FUSE ? coef[DVAE_C_INV_B] : 0.f;
   float lsum = 0.f;
-  for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+  // Consecutive workgroups run on different XCDs (each with its own L2), and the 8 units of an image share halo rows: with the
+  // plain round-robin order they were fetched from HBM by two XCDs each (counter traffic 1.32x the algorithmic bytes).  When
+  // the grid is a multiple of 64, workgroup b = (xcd = b & 7, slot = b >> 3) takes part slot & 7 of image xcd + 8 (slot >> 3)
+  // + (grid / 8) k: the 8 parts of an image run at the same time on ONE XCD.
+  const bool xmap = (gridDim.x & 63) == 0;
+  const int upi = xmap ? 8 * (int)(gridDim.x >> 3) : (int)gridDim.x;           // units per persistent step
+  const int unit0 = xmap ? 8 * (int)((blockIdx.x & 7) + 8 * (blockIdx.x >> 6)) + (int)((blockIdx.x >> 3) & 7) : (int)blockIdx.x;
+  for (int unit = unit0; unit < n_units; unit += upi) {
     const int n = unit >> 3, sy0 = (unit & 7) * 4;
     __syncthreads();
     {

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
   float mS = -INFINITY, sS = 0.f, md[DM], sd[DM];
 #pragma unroll
   for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) { md[d] = -INFINITY; sd[d] = 0.f; }
+#pragma unroll 2
   for (int j = threadIdx.x; j < Bg; j += 256) {
     const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
     float S = 0.f;
@@ -191,30 +192,36 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
     }
     lse_push(mS, sS, S);
   }
-  // wave reduction of the (max, sum) pairs, then the 4 waves through LDS
+  // Reduction of the (max, sum) pairs: the wave's MAX first (max butterflies, no transcendental), every lane rescales its sum
+  // once, the sums are added; then the 4 waves through LDS, one thread per quantity (joint + D marginals).  (Merging (max, sum)
+  // pairs stage by stage cost two exponentials and a divergent branch per pair and stage -- 66 dependent merges per wave, then
+  // 33 more in ONE thread: the kernel spent most of its 30 us there.)
+  auto wave_lse = [&](float& m, float& sm) {
+    float M = m;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float m2 = __shfl_xor(mS, o, 64), s2 = __shfl_xor(sS, o, 64);
-    lse_merge(mS, sS, m2, s2);
+    for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+    sm = wave_sum(m > -INFINITY ? sm * __expf(m - M) : 0.f);   // (a lane, or a whole wave, without columns: m = M = -inf)
+    m = M;
+  };
+  wave_lse(mS, sS);
 #pragma unroll
-    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
-      m2 = __shfl_xor(md[d], o, 64); s2 = __shfl_xor(sd[d], o, 64);
-      lse_merge(md[d], sd[d], m2, s2);
-    }
-  }
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) wave_lse(md[d], sd[d]);
   if (lane == 0) {
     red[wv][0] = mS; red[wv][1] = sS;
 #pragma unroll
     for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) { red[wv][2 + 2 * d] = md[d]; red[wv][3 + 2 * d] = sd[d]; }
   }
+  __shared__ float fin[DM + 1];
+  __syncthreads();
+  const int q = threadIdx.x;                               // quantity: 0 = joint density, 1 + d = marginal d
+  if (q <= D) {
+    const float M = fmaxf(fmaxf(red[0][2 * q], red[1][2 * q]), fmaxf(red[2][2 * q], red[3][2 * q]));
+    const float sm = (red[0][2 * q + 1] * __expf(red[0][2 * q] - M) + red[1][2 * q + 1] * __expf(red[1][2 * q] - M)) +
+                     (red[2][2 * q + 1] * __expf(red[2][2 * q] - M) + red[3][2 * q + 1] * __expf(red[3][2 * q] - M));
+    fin[q] = M + logf(sm);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w2 = 1; w2 < 4; ++w2) {
-      lse_merge(mS, sS, red[w2][0], red[w2][1]);
-#pragma unroll
-      for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) lse_merge(md[d], sd[d], red[w2][2 + 2 * d], red[w2][3 + 2 * d]);
-    }
     float* rs = rowstats + (long)il * DVAE_ROWSTATS;
     float log_pz = 0.f, log_qzCx = 0.f, log_prod = 0.f;
 #pragma unroll
@@ -223,12 +230,12 @@ __global__ __launch_bounds__(256) void k_btcvae_fwd(const float* __restrict__ z,
       const float diff = zi[d] - m;
       log_qzCx += -0.5f * (LOG2PI + l) - 0.5f * (diff * diff * expf(-l));
       log_pz += -0.5f * LOG2PI - 0.5f * (zi[d] * zi[d]);
-      const float lse = md[d] + logf(sd[d]);
+      const float lse = fin[1 + d];
       rs[4 + d] = lse;
       log_prod += lse;
     }
     rs[0] = log_pz;
-    rs[1] = mS + logf(sS);
+    rs[1] = fin[0];
     rs[2] = log_prod;
     rs[3] = log_qzCx;
   }
@@ -258,6 +265,7 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_rows(const float* __restrict
   float zi[DM], lse[DM], g[DM];
 #pragma unroll
   for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) { zi[d] = z[(long)i * D + d]; lse[d] = rs[4 + d]; g[d] = 0.f; }
+#pragma unroll 2
   for (int j = lane; j < Bg; j += 64) {
     const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
     float ld[DM], r[DM];
@@ -311,6 +319,7 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_cols(const float* __restrict
   for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
     mj[d] = mu[(long)j * D + d]; lj[d] = lv[(long)j * D + d]; ivj[d] = expf(-lj[d]); gm[d] = 0.f; gl[d] = 0.f;
   }
+#pragma unroll 2
   for (int il = lane; il < Bl; il += 64) {
     const int i = row0 + il;
     const float* rs = rowstats + (long)il * DVAE_ROWSTATS;

@@ -7,6 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "disentangling-vae_amd")]
+import ctypes
 import torch
 from disvae_amd import _lib
 from disvae_amd._lib import call, ptr, NCHW, NHWC
@@ -40,7 +41,17 @@ for B in Bs:
     dw, db = torch.empty(32, C, 4, 4, device=dev), torch.empty(32, device=dev)
     dbc = torch.empty(C, device=dev)
     nx, na, nb = x.numel() * 4, a1.numel() * 4, bits.numel() * 4
+    # convT3 forward + likelihood on the staged pair records (what the step launches)
+    pairs = torch.empty(32 * _lib.thin_pair_floats(C), device=dev)
+    td = _lib.ThinImageDesc()
+    td.w, td.img_pairs, td.C = ptr(w), ptr(pairs), C
+    call("dvae_stage_weights", None, 0, None, 0, ctypes.addressof(td), None, None, s)
+    rec, g = torch.empty_like(x), torch.empty_like(x)
+    coef = torch.full((8,), 1.0 / B, device=dev)
+    parts = torch.empty(_lib.REC_NPART, device=dev)
+    bc = torch.zeros(C, device=dev)
     rows = [
+        ("convT3 fwd + likelihood", lambda: call("dvae_convT3_fwd_staged", ptr(a1), ptr(pairs), ptr(bc), ptr(x), 0, ptr(rec), ptr(g), 0, ptr(coef), ptr(parts), B, C, s), na + 3 * nx),
         ("conv1 fwd", lambda: call("dvae_conv4s2_fwd", ptr(x), NCHW, ptr(w), ptr(b), ptr(a1), NHWC, B, C, 64, 64, 32, 1, s), nx + na),
         ("conv1 fwd + bits", lambda: call("dvae_conv1_fwd_bits", ptr(x), 0, ptr(w), ptr(b), ptr(a1), ptr(bits), B, C, s), nx + na + nb),
         ("convT3 dgrad (bit mask)", lambda: call("dvae_convT3_dgrad_bits", ptr(x), ptr(w), ptr(bits), ptr(a1), B, C, s), nx + na + nb),
