@@ -442,6 +442,38 @@ int dvae_stream_order(void* earlier, void* later) {
   return 0;
 }
 
+static hipEvent_t* event_slot(int slot, const char* who) {
+  constexpr int NDEV = 32;
+  static hipEvent_t pool[NDEV][DVAE_EVENT_SLOTS];
+  static int made[NDEV] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= NDEV) { set_error("%s: no current device", who); return nullptr; }
+  if (slot < 0 || slot >= DVAE_EVENT_SLOTS) { set_error("%s: slot %d outside [0, %d)", who, slot, DVAE_EVENT_SLOTS); return nullptr; }
+  if (!made[d]) {
+    for (int k = 0; k < DVAE_EVENT_SLOTS; ++k)
+      if (hipEventCreateWithFlags(&pool[d][k], hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) {
+        set_error("%s: hipEventCreateWithFlags failed", who);
+        return nullptr;
+      }
+    made[d] = 1;
+  }
+  return &pool[d][slot];
+}
+
+int dvae_event_record(int slot, void* stream) {
+  hipEvent_t* ev = event_slot(slot, "dvae_event_record");
+  if (!ev) return -2;
+  if (hipEventRecord(*ev, (hipStream_t)stream) != hipSuccess) { set_error("dvae_event_record: %s", hipGetErrorString(hipGetLastError())); return -2; }
+  return 0;
+}
+
+int dvae_event_wait(int slot, void* stream) {
+  hipEvent_t* ev = event_slot(slot, "dvae_event_wait");
+  if (!ev) return -2;
+  if (hipStreamWaitEvent((hipStream_t)stream, *ev, 0) != hipSuccess) { set_error("dvae_event_wait: %s", hipGetErrorString(hipGetLastError())); return -2; }
+  return 0;
+}
+
 int dvae_add(const float* a, const float* b, float* out, long n, void* stream) {
   DVAE_CHECK_ARG(a && b && out && n > 0);
   return launch_add(a, b, out, n, (hipStream_t)stream);

@@ -89,6 +89,8 @@ SIGNATURES = {
     "dvae_comm_group_end": [],
     "dvae_add": [_p, _p, _p, _l, _p],
     "dvae_stream_order": [_p, _p],
+    "dvae_event_record": [_i, _p],
+    "dvae_event_wait": [_i, _p],
     "dvae_plan_op": [ctypes.c_char_p],
     "dvae_plan_run": [_p, _i],
 }

@@ -59,6 +59,8 @@ def linear_annealing(init, fin, step, annealing_steps):
 
 from ..engine import _stream  # noqa: E402
 
+_EV_ESTIMATOR = 0     # dvae_event_record / dvae_event_wait slot: "the btcvae estimator and the scalar loss of this step are final"
+
 
 class _Scratch:
     """Small device buffers shared by the loss kernels of one loss object."""
@@ -464,9 +466,20 @@ class _SingleOptimizerLoss(BaseLoss):
                             record_on_stream(t_.mul_, 1.0 / world)
         # decoder convT stack; its last layer also evaluates the reconstruction likelihood and dL/dlogit
         eng.decode_convs(buf, B, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
-        if self.KIND == _lib.LOSS_BTCVAE:
+        # Single-process btcvae training: nothing on this stream needs the estimator (or the scalar loss) before the FC chain's
+        # input gradients, a whole convT backward later -- the estimator's backward kernels run past the end of the decoder
+        # forward, and joining here left this stream idle for ~20 us plus the epilogue (profiles/r04_v35_btcvae_celeba_timeline.md).
+        # The epilogue goes to the side stream behind them, an event slot marks the lot, fc_chain() waits for the slot.
+        late_join = (self.KIND == _lib.LOSS_BTCVAE and world == 1 and is_train and not eng.single_stream
+                     and knob("DVAE_LATE_JOIN", "1") != "0")
+        if self.KIND == _lib.LOSS_BTCVAE and not late_join:
             eng._join_side()
-        if world > 1:
+        if late_join:
+            eng.fork_side()                       # the reconstruction partials of this stream are final for the side stream
+            call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), B, None, Bg,
+                 ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), eng._side_raw())
+            call("dvae_event_record", _EV_ESTIMATOR, eng._side_raw())
+        elif world > 1:
             call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
             # the global loss sums are first needed by the latent glue of the backward FC chain (a whole convT backward
             # later): their all-reduce and the scalar epilogue leave the critical path; an event marks them final
@@ -486,6 +499,8 @@ class _SingleOptimizerLoss(BaseLoss):
         def fc_chain():        # the six FC input gradients + the reparameterisation / KL backward in ONE launch
             if world > 1:
                 self._wait_scalars(sc)
+            if late_join:
+                call("dvae_event_wait", _EV_ESTIMATOR, s)
             eng.fc_chain_bwd(buf, eps, dz_x, None, dmu_x, dlv_x, sc.scal, sc.coef, B)
 
         # single process: one join, at the end of the backward pass, and ONE grouped launch for all six FC weight

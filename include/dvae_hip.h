@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DVAE_VERSION 106
+#define DVAE_VERSION 107
 
 /* latent dimensions the fused kernels cover (the reference's --latent-dim is 10 in every experiment of
  * hyperparam.ini): reparameterisation / KL / scalar slots, the FC chain and the beta-TCVAE estimator up to 16.
@@ -359,6 +359,13 @@ int dvae_add(const float* a, const float* b, float* out, long n, void* stream);
  * its fork / join primitive: an event recorded with a DEVICE-scope release (hipEventReleaseToDevice: no system-scope cache
  * flush, the two streams share the device) from a small internal pool, then hipStreamWaitEvent.  Capturable.            */
 int dvae_stream_order(void* earlier, void* later);
+/* The same in two halves, for a consumer that is enqueued much later than the producer: dvae_event_record marks the work
+ * enqueued on `stream` so far in slot `slot` (0 <= slot < DVAE_EVENT_SLOTS, per device); dvae_event_wait makes the work enqueued
+ * on `stream` afterwards wait for the slot's LAST mark.  (The btcvae step: the estimator's backward kernels and the scalar
+ * loss epilogue stay on the side stream until the FC chain's input gradients need them, a whole convT backward later.)   */
+#define DVAE_EVENT_SLOTS 16
+int dvae_event_record(int slot, void* stream);
+int dvae_event_wait(int slot, void* stream);
 
 /* ---- recorded launch lists (new; host-side overhead only) ------------------------------------------------------------
  * A training iteration at a fixed batch size repeats the same entry-point calls with the same arguments; the host records

@@ -3,7 +3,23 @@ set -u
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 mkdir -p gpurun_out
-TAG=${TAG:-r04_v38}
-timeout 300 python -m pytest "tests/test_gpu_kernels.py::test_btcvae_fwd_bwd" "tests/test_gpu_kernels.py::test_btcvae_kat_reference_values" tests/test_gpu_step.py -m gpu -q --timeout=300 --no-header 2>&1 | tail -n 4 | cut -c1-300 | tee gpurun_out/${TAG}_pytest.txt
-for r in 1 2; do timeout 200 python tools/kbench.py 1024 2>&1 | grep btcvae; done | tee gpurun_out/${TAG}_btcvae.txt
-timeout 200 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('btcvae_celeba', d['value'], d['ms_per_step'])" | tee -a gpurun_out/${TAG}_btcvae.txt
+TAG=${TAG:-r04_v39}
+timeout 900 python -m pytest tests/test_gpu_step.py tests/test_gpu_timed_config.py tests/test_gpu_bench_sizes.py tests/test_gpu_fused_core.py -m gpu -q --timeout=300 --no-header -x 2>&1 | tail -n 6 | cut -c1-300 | tee gpurun_out/${TAG}_pytest.txt
+BA="--steps 150 --warmup 25 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
+line() { python -c "
+import sys, json
+t = sys.stdin.read()
+try:
+    d = json.loads(t); print('$1', d['value'], d['ms_per_step'])
+except Exception:
+    print('$1 FAILED:', t[-300:])"; }
+{
+for rep in 1 2 3; do
+  DVAE_DEBUG=1 DVAE_LATE_JOIN=0 timeout 200 python bench.py $BA 2>&1 | tail -n 1 | line "rep$rep B=1024 join after the decoder forward"
+  timeout 200 python bench.py $BA 2>&1 | tail -n 1 | line "rep$rep B=1024 late join"
+done
+DVAE_DEBUG=1 DVAE_LATE_JOIN=0 timeout 200 python bench.py --batch 128 $BA 2>&1 | tail -n 1 | line "B=128 join after the decoder forward"
+timeout 200 python bench.py --batch 128 $BA 2>&1 | tail -n 1 | line "B=128 late join"
+DVAE_DEBUG=1 DVAE_LATE_JOIN=0 timeout 200 python bench.py --config btcvae_dsprites $BA 2>&1 | tail -n 1 | line "btcvae_dsprites join after the decoder forward"
+timeout 200 python bench.py --config btcvae_dsprites $BA 2>&1 | tail -n 1 | line "btcvae_dsprites late join"
+} | tee gpurun_out/${TAG}_late_join_ab.txt
