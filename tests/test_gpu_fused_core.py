@@ -333,3 +333,28 @@ def test_convT3_forward_on_staged_pair_records(N, C):
         check(g1, g0.cpu(), rtol=1e-4, atol_rel=2e-6, what="fused dL/dlogit dist %d" % dist)
         check(p1.sum(), p0.sum().cpu(), rtol=1e-5, what="fused loss sum dist %d" % dist)
         assert torch.equal(r2, r1) and torch.equal(g2, g1) and torch.equal(p2, p1), "uint8 target == ToTensor(target), dist %d" % dist
+
+
+def test_event_slots_order_a_late_consumer_after_marked_work():
+    """dvae_event_record / dvae_event_wait (include/dvae_hip.h): work enqueued after the wait runs after everything that was
+    enqueued on the other stream before the record -- and NOT after what was enqueued there later.  A chain of dependent adds
+    on the side stream (each launch reads the previous result), a mark, MORE side work, then a consumer on the current stream
+    that waits for the mark only."""
+    n = 1 << 24
+    side = torch.cuda.Stream()
+    a = torch.zeros(n, device=DEV)
+    one = torch.ones(n, device=DEV)
+    out = torch.empty(n, device=DEV)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        a.zero_()
+        torch.cuda.synchronize()
+        for _ in range(20):                                    # a += 1, twenty times, on the side stream
+            call("dvae_add", ptr(a), ptr(one), ptr(a), n, side.cuda_stream)
+        call("dvae_event_record", 5, side.cuda_stream)
+        call("dvae_event_wait", 5, stream())
+        call("dvae_add", ptr(a), ptr(one), ptr(out), n, stream())       # must see all twenty additions
+        torch.cuda.synchronize()
+        assert torch.equal(out, torch.full_like(out, 21.0)), (rep, out[:4], out[-4:])
+    with pytest.raises(_lib.DvaeHipError):
+        call("dvae_event_record", 99, stream())
