@@ -725,9 +725,16 @@ class FactorKLoss(BaseLoss):
                 self.comm.all_reduce(sc.packed)
                 call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), _stream())
                 self._mark_scalars(sc)
-        else:
+        late_epi = world == 1 and not eng.single_stream and knob("DVAE_LATE_JOIN", "1") != "0"
+        if world == 1:
+            # the scalar epilogue (13 us) is first needed by the FC chain's input gradients, after the discriminator's and the
+            # decoder's backward passes: it runs on the side stream, an event slot marks it (as in the btcvae step)
+            if late_epi:
+                eng.fork_side()
             call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), klb, D, None, 0, ptr(sc.disc_sums),
-                 Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), s)
+                 Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), eng._side_raw() if late_epi else s)
+            if late_epi:
+                call("dvae_event_record", _EV_ESTIMATOR, eng._side_raw())
         # discriminator backward of d_tc_loss (weight grads + dz), losses.py:303-304
         dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
         pending = []
@@ -740,6 +747,8 @@ class FactorKLoss(BaseLoss):
             # dz_a: quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1); dz_b: the tc term through D
             if world > 1:
                 self._wait_scalars(sc)
+            if late_epi:
+                call("dvae_event_wait", _EV_ESTIMATOR, s)
             eng.fc_chain_bwd(buf, eps1, dz_a, dz_b, None, None, sc.scal, sc.coef, Bh)
 
         eng.decode_backward(buf.z, buf, n=Bh, join=world > 1, defer_fc_wgrad=world == 1, fc_chain=fc_chain)   # single process: joined at the end of encode_backward
