@@ -16,8 +16,8 @@
 //     nothing else ride in the chain's issue shadow.  No vector memory instruction at all after the prologue.
 //   * waves 4-5, loaders: the next tiles HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KB per instruction: a wave that
 //     shares its SIMD with MFMA-streaming waves issues one instruction per 40-60 cycles, so a loader may cost ~30 per unit),
-//     two tiles ahead in a ring of three stages; lanes whose row lies outside the image are masked off and find the zeros
-//     the stage was initialised with.
+//     three tiles ahead in a ring of four stages (a ring of three measured the same: profiles/r04_v30_thin_ab.txt); lanes whose
+//     row lies outside the image are masked off and find the zeros the stage was initialised with.
 //   * waves 6-7, drainers: output stage -> HBM, 16 bytes per lane, every 8 lanes one full 128-byte line; their stores are
 //     the only thing that ever waits for the memory system, and nothing waits for them.
 //   * one s_barrier per unit: "tile u + 1 has landed; tile u is read; output stage u - 1 is written; stage u - 2 is drained".
@@ -29,11 +29,9 @@
 #include "common.h"
 #include "wgrad_reduce.h"
 
-#pragma clang diagnostic ignored "-Winline-asm"     // dma4 names m0 in its clobber list on purpose
+#pragma clang diagnostic ignored "-Winline-asm"     // dma16s names m0 in its clobber list on purpose
 
 namespace dvae {
-
-__device__ __attribute__((aligned(16))) float k_thin_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 template <int C, int MODE>
 struct ThinWsGeo {
