@@ -235,6 +235,7 @@ class VAEEngine:
         #          early as the data allows (profiles/r03_v2_timeline_b128.md: backward pass 287 us against ~150 us of
         #          dependent work).  Set per step by the loss plugins (BaseLoss._streams).
         self.eager_wgrad = False
+        self._fork_hook = None
         # 64x64 images with 1 / 3 channels: the forward kernels of conv1 and convT2 also emit the sign bits of their outputs and
         # the input-gradient kernels of conv2 and convT3 read those instead of the 32x32x32 fp32 activations (dvae_*_bits)
         self.mask_bits = self.is64 and c in (1, 3) and knob("DVAE_MASK_BITS", "1") != "0"   # (A/B knob: DVAE_DEBUG=1 only)
@@ -311,6 +312,24 @@ class VAEEngine:
         if self.single_stream:
             return
         call("dvae_stream_order", _stream(), self._side.cuda_stream)
+        hook, self._fork_hook = self._fork_hook, None
+        if hook is not None:
+            hook()
+
+    def at_next_fork(self, fn):
+        """Side-stream work that needs everything enqueued on the current stream SO FAR but is not urgent: `fn()` is called
+        right after the next fork_side() instead of paying for a fork of its own (each costs the current stream ~6 us)."""
+        if knob("DVAE_FORK_HOOK", "1") == "0":      # A/B (DVAE_DEBUG=1): a fork of its own, right here
+            self._fork_hook = None
+            self.fork_side()
+            fn()
+            return
+        self._fork_hook = fn                   # (a hook left behind by a step that raised is dropped, not run)
+
+    def flush_fork_hook(self):
+        """A consumer of the deferred side-stream work is about to be enqueued: if no fork has happened yet, fork now."""
+        if self._fork_hook is not None:
+            self.fork_side()
 
     @property
     def side_stream(self):

@@ -475,10 +475,11 @@ class _SingleOptimizerLoss(BaseLoss):
         if self.KIND == _lib.LOSS_BTCVAE and not late_join:
             eng._join_side()
         if late_join:
-            eng.fork_side()                       # the reconstruction partials of this stream are final for the side stream
-            call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), B, None, Bg,
-                 ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), eng._side_raw())
-            call("dvae_event_record", _EV_ESTIMATOR, eng._side_raw())
+            def epilogue():                       # after the next fork (the backward pass's first): no fork of its own
+                call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), B, None, Bg,
+                     ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), eng._side_raw())
+                call("dvae_event_record", _EV_ESTIMATOR, eng._side_raw())
+            eng.at_next_fork(epilogue)
         elif world > 1:
             call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
             # the global loss sums are first needed by the latent glue of the backward FC chain (a whole convT backward
@@ -500,6 +501,7 @@ class _SingleOptimizerLoss(BaseLoss):
             if world > 1:
                 self._wait_scalars(sc)
             if late_join:
+                eng.flush_fork_hook()
                 call("dvae_event_wait", _EV_ESTIMATOR, s)
             eng.fc_chain_bwd(buf, eps, dz_x, None, dmu_x, dlv_x, sc.scal, sc.coef, B)
 
@@ -729,12 +731,16 @@ class FactorKLoss(BaseLoss):
         if world == 1:
             # the scalar epilogue (13 us) is first needed by the FC chain's input gradients, after the discriminator's and the
             # decoder's backward passes: it runs on the side stream, an event slot marks it (as in the btcvae step)
-            if late_epi:
-                eng.fork_side()
-            call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), klb, D, None, 0, ptr(sc.disc_sums),
-                 Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), eng._side_raw() if late_epi else s)
-            if late_epi:
-                call("dvae_event_record", _EV_ESTIMATOR, eng._side_raw())
+            def epilogue(stream):
+                call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), klb, D, None, 0,
+                     ptr(sc.disc_sums), Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), stream)
+            if late_epi:                          # after the next fork (the backward pass's first): no fork of its own
+                def deferred():
+                    epilogue(eng._side_raw())
+                    call("dvae_event_record", _EV_ESTIMATOR, eng._side_raw())
+                eng.at_next_fork(deferred)
+            else:
+                epilogue(s)
         # discriminator backward of d_tc_loss (weight grads + dz), losses.py:303-304
         dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
         pending = []
@@ -748,6 +754,7 @@ class FactorKLoss(BaseLoss):
             if world > 1:
                 self._wait_scalars(sc)
             if late_epi:
+                eng.flush_fork_hook()
                 call("dvae_event_wait", _EV_ESTIMATOR, s)
             eng.fc_chain_bwd(buf, eps1, dz_a, dz_b, None, None, sc.scal, sc.coef, Bh)
 
