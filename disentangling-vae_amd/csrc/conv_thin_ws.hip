@@ -404,7 +404,7 @@ int launch_down_thin_ws(const ConvArgs& a, hipStream_t s) {
 //     2 i, 2 i + 1: the two M tiles interleave the channels so that a lane's pair is one 8-byte read) and C ds_read_b32 (x
 //     patch values), the NEXT unit's operands read under the current unit's MFMAs; no vector memory instruction at all;
 //   * waves 4-7, loaders: both tiles HBM -> LDS by LDS-DMA, 16 + 3 C transfers of 1 KB per unit, two units ahead in a ring of
-//     three stages; image rows outside the image are masked lanes over LDS zeros, the two columns outside the image are read
+//     three stages (one workgroup per CU: see the launcher); image rows outside the image are masked lanes over LDS zeros, the two columns outside the image are read
 //     from a zero zone by the lanes concerned (as in k_down_thin_ws);
 //   * the accumulators live in registers for the whole kernel; at the end the four waves' partial sums are added in a fixed
 //     order through LDS and written in k_wgrad_thin's partial-buffer layout, so k_wgrad_thin_reduce finishes the job.
@@ -639,7 +639,11 @@ int launch_wgrad_thin_ws(const float* big, const float* small, float* ws, int bi
   static const int min_n = env_int("DVAE_THIN_WS_MIN_N", 192);
   if (off || N < min_n || (Cb != 1 && Cb != 3)) return 1;
   if (((uintptr_t)big | (uintptr_t)small) & 15) return 1;
-  const int grid = 512;
+  // ONE workgroup per CU (the LDS of two would fit): alone the kernel takes the same 34 us either way, but two leave 6 KB of LDS
+  // per CU and the small kernels of the other stream's critical path then wait for the whole launch (k_down32<4> ran 56 us
+  // beside it); with one, the training step is 12 us shorter (profiles/r04_v44_thin_wgrad_grid.txt)
+  static const int grid_dbg = env_int("DVAE_THIN_WGRAD_GRID", 256);  // debug builds: 512 = two workgroups per CU
+  const int grid = grid_dbg == 512 ? 512 : 256;
   static_assert(512 <= WT_MAX_BLOCKS, "the partial buffer holds the grid");
 #define DVAE_WTW(C, BB)                                                                                                    \
   do {                                                                                                                     \
