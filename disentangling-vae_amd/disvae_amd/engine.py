@@ -265,6 +265,7 @@ class VAEEngine:
             _lib.note_alloc()
             self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
             self._ws_side = torch.empty(n, dtype=torch.float32, device=self.device)
+            # (a high-priority side stream measured the same step time: profiles/r04_v45_side_priority.txt)
             self._side = torch.cuda.Stream(device=self.device)
         return b
 
