@@ -359,3 +359,20 @@ def test_bench_cpu_baseline_leg_runs_the_port_and_calibrates_threads_once(monkey
     assert r1["kind"] == "port" and r1["unit"] == "images/s" and r1["value"] > 0 and r1["cores"] == r2["cores"]
     assert max(seen) <= 64 or max(seen) <= (os.cpu_count() or 1)
     assert len(seen) - n_probe == 1, "the second leg re-uses the calibrated thread count"
+
+
+@pytest.mark.parametrize("script", ["thin_ws_index_math.py", "gemm_dma_index_math.py"])
+def test_kernel_addressing_emulations(script):
+    """tools/emu/*: lane-level numpy emulations of the LDS-DMA kernels' addressing (workgroup -> tile maps, per-lane transfer
+    sources and masks, operand reads, MFMA lane layouts, epilogue / partial-buffer slots) against numpy references -- run
+    here so that they stay runnable, and (thin kernels) with the layout constants checked against the source."""
+    import re
+    import runpy
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ns = runpy.run_path(os.path.join(root, "tools", "emu", script), run_name="__main__")
+    if script.startswith("thin_ws"):
+        # the emulation's layout constants are the kernels' (csrc/conv_thin_ws.hip: ThinWsGeo / ThinWgGeo)
+        src = open(os.path.join(root, "disentangling-vae_amd", "csrc", "conv_thin_ws.hip")).read()
+        planes = [int(v) for v in re.findall(r"static constexpr int PLANE = (\d+);", src)]
+        zz = [int(v) for v in re.findall(r"static constexpr int ZZ = (\d+);", src)]
+        assert planes == [ns["PLANE_D"], ns["PLANE_W"]] and zz == [ns["ZZ"], ns["ZZ"]], (planes, zz)
