@@ -68,7 +68,11 @@ def main():
         name = re.sub(r"\(.*", "", names.get(mangled, mangled)).replace("void ", "").replace("dvae::", "")
         if want and want not in name:
             continue
-        i1 = next(i for i in range(i0, len(lines)) if "s_endpgm" in lines[i])
+        # the function's end label (a kernel may hold several s_endpgm: wave roles that return early); data symbols have none
+        nxt_start = starts[idx + 1][0] if idx + 1 < len(starts) else len(lines)
+        i1 = next((i for i in range(i0, nxt_start) if lines[i].startswith(".Lfunc_end")), None)
+        if i1 is None:
+            continue
         body = [re.sub(r"\s*;.*$", "", l.strip()) for l in lines[i0 + 1:i1]]
         body = [l for l in body if l and not l.startswith(".") and not l.startswith(";") and not l.endswith(":")]
         seq = "".join(classify(l) for l in body)
