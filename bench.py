@@ -80,17 +80,24 @@ def flops_per_image_factor(C):
 
 
 # ---------------------------------------------------------------------------------- roofline
+def pmc_file_order(f):
+    """Sort key of a profiles/ file name: round first, then the visit tag -- "finalN" visits follow every "runN" / "vN" visit of
+    their round (r02_run6 < r02_final < r03_run1; r04_v35 < r04_final < r04_final3), then the tag's own number."""
+    b = os.path.basename(f)
+    m = re.match(r"r(\d+)_(final|run|v)(\d*)_", b)
+    if not m:
+        nums = [int(x) for x in re.findall(r"\d+", b)]
+        return [nums[0] if nums else 0, 0, 0]
+    return [int(m.group(1)), 1 if m.group(2) == "final" else 0, int(m.group(3) or 0)]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the kernel row `kernel` (the exact template variant, e.g. "k_up32ws<16, 2, false>") at B = 1024
     (64x64x3) from the newest committed rocprofv3 PMC summary under profiles/ that has that row (tools/pmc_collect.sh ->
     tools/pmc_summary.py: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md
     section HBM prescribes for 16-byte coalesced streaming reads on gfx950).  Read from a file committed by an earlier GPU
     visit, not measured in this run.  Returns (bytes, file) or (None, None)."""
-    def order(f):                                    # r02_run6_... < r02_final_... < r03_run1_...
-        b = os.path.basename(f)
-        nums = [int(x) for x in re.findall(r"\d+", b)]
-        return [nums[0] if nums else 0, 1 if "_final_" in b else 0] + nums[1:]
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.md")), key=order)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.md")), key=pmc_file_order)
     for f in reversed(files):
         for l in open(f).read().splitlines():
             cells = [c.strip() for c in l.strip("|").split("|")]
@@ -363,9 +370,10 @@ def cpu_baseline_port(cfg, B, iters=6, warm=2):
 
     med, threads, ncpu = _time_cpu(make, img, B, iters, warm)
     return {"value": round(B / med, 1), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "oracle (torch-CPU restatement of reference Trainer._train_iteration), %s 64x64x%d B=%d, "
+            "batch": B,
+            "sample": "oracle (torch-CPU restatement of reference Trainer._train_iteration), %s %dx%dx%d B=%d, "
                       "median of %d iterations after %d warm-ups, %.0f ms/iter, %d threads (best of a sweep) on a "
-                      "%d-CPU host" % (loss, img[0], B, iters, warm, med * 1e3, threads, ncpu)}
+                      "%d-CPU host" % (loss, img[1], img[2], img[0], B, iters, warm, med * 1e3, threads, ncpu)}
 
 
 REFERENCE_DIR = os.environ.get("DVAE_REFERENCE", "/root/reference")
@@ -408,9 +416,10 @@ def cpu_baseline_reference(cfg, B, iters=6, warm=2):
 
     med, threads, ncpu = _time_cpu(make, img, B, iters, warm)
     return {"value": round(B / med, 1), "unit": "images/s", "cores": threads, "kind": "reference",
-            "sample": "the reference's own Trainer._train_iteration (%s, unmodified, torch CPU), %s 64x64x%d B=%d, "
+            "batch": B,
+            "sample": "the reference's own Trainer._train_iteration (%s, unmodified, torch CPU), %s %dx%dx%d B=%d, "
                       "median of %d iterations after %d warm-ups, %.0f ms/iter, %d threads (best of a sweep) on a "
-                      "%d-CPU host" % (REFERENCE_DIR, loss, img[0], B, iters, warm, med * 1e3, threads, ncpu)}
+                      "%d-CPU host" % (REFERENCE_DIR, loss, img[1], img[2], img[0], B, iters, warm, med * 1e3, threads, ncpu)}
 
 
 def cpu_baseline(cfg, B, iters=6, warm=2):
@@ -500,7 +509,8 @@ def make_optimizer(model, lr):
 def time_leg(cfg, B, device, steps, warmup, drop_in=False, replay=None):
     """One single-GPU leg: fresh seed-1234 model, resident synthetic batch, `warmup` untimed + `steps` timed iterations
     between two synchronisations.  drop_in: driven the way INTEGRATION.md tells a reference user to -- optim.Adam over
-    model.parameters() (main.py:208 verbatim) and Trainer._train_iteration, i.e. one loss.item() host sync per iteration
+    model.parameters() (main.py:208 verbatim); "epoch": through Trainer._train_epoch (what Trainer.__call__ runs, one host
+    sync per epoch without a progress bar), True: Trainer._train_iteration, i.e. one loss.item() host sync per iteration
     (training.py:164; what is_progress_bar=True needs).  Returns (ms per step, final loss)."""
     import logging
     from disvae_amd.models.vae import init_specific_model
@@ -517,6 +527,24 @@ def time_leg(cfg, B, device, steps, warmup, drop_in=False, replay=None):
     data = torch.rand((B,) + tuple(cfg["img"]), device=device, generator=gen)
     torch.cuda.manual_seed(1234)
     storer = defaultdict(list)
+    if drop_in == "epoch":
+        # Trainer.__call__'s inner loop (training.py:104-135) over a loader of resident batches, no progress bar
+        # (main.py --no-progress-bar): the mean epoch loss is the one host sync
+        class Resident:
+            def __init__(self, n):
+                self.n = n
+
+            def __len__(self):
+                return self.n
+
+            def __iter__(self):
+                return iter([(data, 0)] * self.n)
+        trainer._train_epoch(Resident(warmup), storer, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = trainer._train_epoch(Resident(steps), storer, 1)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, float(loss)
     step = trainer._train_iteration if drop_in else trainer._train_iteration_async
     for _ in range(warmup):
         step(data, storer)
@@ -550,8 +578,119 @@ def extra_config(name, device, steps, warmup, with_cpu, with_parity):
         out["roofline_kernels"] = disc_kernel_rooflines(B, device)     # the discriminator's GEMMs at this config's row counts
     mark("configs:%s:cpu" % name)
     if with_cpu:
-        # bounded sample: at most 256 images per CPU iteration (the oracle's factor iteration at tensor 2048 is ~25 s)
-        out["cpu_baseline"] = cpu_baseline(cfg, min(B, 256), iters=3, warm=1)
+        # the workload's own tensor (factor_celeba: 2048 images per CPU iteration, 1 warm-up + 2 timed; "batch" says so)
+        out["cpu_baseline"] = cpu_baseline(cfg, B, iters=3 if B <= 256 else 2, warm=1)
+    return out
+
+
+SHARD_WORLD = 8       # BASELINE configs[3]: "b=1024 ... DDP over 8xMI355X" = 128 images per GPU
+
+
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def shard_legs(device, steps, warmup, with_parity, with_roofline):
+    """BASELINE configs[3] as ONE of its eight ranks runs it, on this one GPU: 128 images per step through the SHARDED code
+    path of the btcvae step (disvae_amd.parallel: packed latent all-gather, the rank's 128 rows of the 1024-column B x B
+    estimator, packed column-gradient reduce-scatter, loss-sum all-reduce, the gradient arena all-reduced in two spans under
+    the backward pass).  The seven absent peers are stood in for by parallel.MirroredWorldComm (identical shards: every
+    collective goes through a real one-rank RCCL communicator -- torch.distributed's, then the C-ABI's dvae_comm_* -- and is
+    completed by replication / scaling), so the leg times the rank's own kernels, launches and RCCL call sites; what it
+    cannot contain is the xGMI transfer time of the 2 MB + 120 KB + 80 KB a real step exchanges.  Beside them: the same
+    128 images as a single-process step (no communicator)."""
+    import logging
+    import torch.distributed as dist
+    from disvae_amd.models.vae import init_specific_model
+    from disvae_amd.models.losses import get_loss_f
+    from disvae_amd.training import Trainer
+    from disvae_amd import parallel
+    cfg = dict(CONFIGS["btcvae_celeba"])
+    Bg = cfg["batch"]
+    B = Bg // SHARD_WORLD
+    C = cfg["img"][0]
+    flops = flops_per_image_train(C) * B
+    out = {"name": "btcvae_celeba_shard", "baseline_config": 3, "loss": "btcvae", "img": list(cfg["img"]), "global_batch": Bg,
+           "batch_per_gpu": B, "world_emulated": SHARD_WORLD, "steps": steps, "warmup": warmup, "unit": "images/s",
+           "what": "one rank of eight: the sharded btcvae step at 128 images per GPU (global 1024-column estimator, packed "
+                   "collectives through a one-rank RCCL communicator completed by MirroredWorldComm); value = images/s of "
+                   "THIS rank, xGMI transfer time not included"}
+
+    def leg(transport):
+        torch.manual_seed(1234)
+        model = init_specific_model("Burgess", cfg["img"], 10).to(device)
+        opt = make_optimizer(model, cfg["lr"])
+        loss_f = get_loss_f("btcvae", n_data=cfg["n_data"], device=device, lr_disc=cfg["lr_disc"], **HP)
+        trainer = Trainer(model, opt, loss_f, device=device, logger=logging.getLogger("bench"), save_dir="/tmp/dvae_bench_shard",
+                          is_progress_bar=False)
+        model.train()
+        comm = None
+        if transport is not None:
+            inner = parallel.RcclComm() if transport == "rccl" else parallel.Comm()
+            comm = parallel.data_parallel(model, loss_f, comm=parallel.MirroredWorldComm(inner, SHARD_WORLD, 0))
+        gen = torch.Generator(device=device).manual_seed(1234)
+        data = torch.rand((B,) + tuple(cfg["img"]), device=device, generator=gen)
+        torch.cuda.manual_seed(1234)
+        storer = defaultdict(list)
+        for _ in range(20 + warmup):
+            trainer._train_iteration_async(data, storer)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = trainer._train_iteration_async(data, storer)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        final = float(loss.item())
+        if comm is not None:
+            comm.close()
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"ms_per_step": round(ms, 4), "value": round(B / (ms * 1e-3), 1), "step_tflops": round(tf, 2),
+                "step_frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "final_loss": round(final, 4),
+                "replay": loss_f._replay_mode(True, data) or "eager"}
+
+    mark("configs:shard:single")
+    out["single_process"] = leg(None)
+    mark("configs:shard:ddp")
+    own_group = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            parallel.init_process_group_from_env("nccl")
+            own_group = True
+        out["transports"] = {t: leg(t) for t in ("torch", "rccl")}
+        a, b = out["transports"]["torch"]["ms_per_step"], out["transports"]["rccl"]["ms_per_step"]
+        out["transports_rel_diff"] = round(abs(a - b) / min(a, b), 4)
+        # the headline numbers of the leg = the default transport's
+        out.update({k: out["transports"]["torch"][k] for k in ("ms_per_step", "value", "step_tflops", "step_frac_of_fp32_peak")})
+        out["node_value_at_this_rate"] = round(out["value"] * SHARD_WORLD, 1)
+    except Exception as e:                       # a box whose RCCL cannot initialise still gets the rest of the line
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    finally:
+        if own_group and dist.is_initialized():
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+    mark("configs:shard:parity")
+    if with_parity:
+        # the kernels of the shard's size (batch-sized variants: the thin convolutions, the FC chain, replayed launch plan)
+        # against the oracle: the first iteration of a single-process 128-image step
+        pc = parity_check(dict(cfg, batch=B), B, device)
+        out["parity_check"] = {k: pc[k] for k in ("ok", "loss_rel_err", "worst_grad_err_over_max_abs_grad_vs_gate_matched_fp64",
+                                                  "units_gated_differently_than_fp64", "batch", "seconds")}
+        out["parity_check"]["sharded_path"] = ("tests/test_gpu_ddp.py: sharded == global-batch step (2 ranks), mirrored world == "
+                                               "tiled single-process step at these sizes")
+    mark("configs:shard:rooflines")
+    if with_roofline:
+        out["roofline_kernels"] = kernel_rooflines(B, device) + thin_kernel_rooflines(B, C, device)
     return out
 
 
@@ -599,6 +738,8 @@ def main():
                     "workloads (they run by default with N = 1 and the default workload)")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop-in leg (Adam(model.parameters()) + a host "
                     "sync per iteration)")
+    ap.add_argument("--shard-legs", action="store_true", help="only the btcvae_celeba_shard legs (one rank of eight at 128 "
+                    "images per GPU: single process, torch transport, rccl transport), print them, exit")
     ap.add_argument("--cpu-reference", action="store_true", help="no GPU needed: time the unmodified reference Trainer "
                     "(where /root/reference exists) and the oracle's port of it on this host, print both, exit")
     args = ap.parse_args()
@@ -625,6 +766,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+
+    if args.shard_legs:
+        print(json.dumps(shard_legs(device, steps=args.steps, warmup=args.warmup, with_parity=not args.no_parity_check,
+                                    with_roofline=not args.no_roofline)), flush=True)
+        return
 
     name = args.config or ("factor_celeba" if args.loss == "factor" else "btcvae_celeba")
     cfg = dict(CONFIGS[name])
@@ -794,11 +940,20 @@ def main():
     mark("drop_in")
     if world == 1 and not args.no_drop_in:
         d_steps = min(args.steps, 50)
-        d_ms, _ = time_leg(cfg, B, device, d_steps, min(args.warmup, 10), drop_in=True)
+        d_ms, _ = time_leg(cfg, B, device, d_steps, min(args.warmup, 10), drop_in="epoch")
+        p_ms, _ = time_leg(cfg, B, device, d_steps, min(args.warmup, 10), drop_in=True)
         out["drop_in"] = {"ms_per_step": round(d_ms, 4), "value": round(B / (d_ms * 1e-3), 1), "steps": d_steps,
-                          "optimizer": "torch.optim.Adam(model.parameters(), lr) (main.py:208 verbatim, not fused, 28 tensors)",
-                          "host_sync": "loss.item() every iteration (Trainer._train_iteration, training.py:164)",
-                          "over_timed_configuration": round(d_ms / ms, 3)}
+                          "driven_as": "INTEGRATION.md / main.py:204-224 verbatim: optim.Adam(model.parameters(), lr) handed to "
+                                       "Trainer(..., is_progress_bar=False), one epoch of Trainer._train_epoch over a loader of "
+                                       "resident batches",
+                          "optimizer": "torch.optim.Adam(model.parameters(), lr) (main.py:208 verbatim, 28 tensors); the Trainer "
+                                       "switches a stock Adam to torch's fused multi-tensor kernel (training.fuse_plain_adam)",
+                          "host_sync": "one per epoch (the mean epoch loss, training.py:135)",
+                          "over_timed_configuration": round(d_ms / ms, 3),
+                          "with_progress_bar": {"ms_per_step": round(p_ms, 4), "value": round(B / (p_ms * 1e-3), 1),
+                                                "host_sync": "loss.item() every iteration (Trainer._train_iteration, "
+                                                             "training.py:164: what tqdm's postfix needs)",
+                                                "over_timed_configuration": round(p_ms / ms, 3)}}
     mark("cpu_baseline")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, B)
@@ -808,6 +963,8 @@ def main():
         out["configs"] = [extra_config(n, device, steps=min(args.steps, 30), warmup=min(args.warmup, 10),
                                        with_cpu=not args.no_cpu_baseline, with_parity=not args.no_parity_check)
                           for n in ("vae_mnist", "btcvae_dsprites", "factor_dsprites", "factor_celeba")]
+        out["configs"].append(shard_legs(device, steps=max(min(args.steps, 100), 30), warmup=min(args.warmup, 10),
+                                         with_parity=not args.no_parity_check, with_roofline=not args.no_roofline))
     mark("end")
     out["timing_s"] = {a[0]: round(b[1] - a[1], 1) for a, b in zip(_MARKS[:-1], _MARKS[1:])}
     out["bench_wall_s"] = round(time.time() - t_main, 1)     # this process, main() entry to the line below (imports excluded)

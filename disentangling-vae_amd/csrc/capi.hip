@@ -1,5 +1,6 @@
 // extern "C" surface of libdvae_hip.so (see include/dvae_hip.h): argument checking and
 // dispatch between the tuned gfx950 kernels and the shape-generic HIP kernels.
+#include <mutex>
 #include <stdarg.h>
 #include <stdlib.h>
 #include "common.h"
@@ -446,6 +447,8 @@ static hipEvent_t* event_slot(int slot, const char* who) {
   constexpr int NDEV = 32;
   static hipEvent_t pool[NDEV][DVAE_EVENT_SLOTS];
   static int made[NDEV] = {};
+  static std::mutex mu;                       // lazy pool creation: callers may come from several host threads
+  std::lock_guard<std::mutex> lock(mu);
   int d = 0;
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= NDEV) { set_error("%s: no current device", who); return nullptr; }
   if (slot < 0 || slot >= DVAE_EVENT_SLOTS) { set_error("%s: slot %d outside [0, %d)", who, slot, DVAE_EVENT_SLOTS); return nullptr; }

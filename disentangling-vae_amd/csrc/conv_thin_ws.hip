@@ -341,7 +341,7 @@ int launch_down_thin_ws(const ConvArgs& a, hipStream_t s) {
   if (off || a.N < min_n || a.mask) return 1;
   if (a.mask_bits && (a.out_bits || a.bias || a.act != DVAE_ACT_NONE)) return 1;   // MODE 2 is a bare masked input gradient
   if (a.out_bits && a.act != DVAE_ACT_RELU) return 1;                               // MODE 3 = conv1 forward: bias + ReLU + bits
-  if ((uintptr_t)a.big & 15) return 1;
+  if (((uintptr_t)a.big | (uintptr_t)a.out) & 15) return 1;          // tiles by 16-byte LDS-DMA, output in 16-byte stores
   uint32_t* bits = a.mask_bits ? const_cast<uint32_t*>(a.mask_bits) : a.out_bits;
   if (bits && ((uintptr_t)bits & 15)) return 1;
 #define DVAE_DTW(C, MODE)                                                                                                   \

@@ -530,7 +530,7 @@ bool try_gdma_wgrad(const float* x, const float* dy, float* dw, float* db, int M
   static const bool off = env_off("DVAE_GEMM_DMA");    // A/B switch, debug builds only
   if (off || M < 64 || N % 4 || K % 4) return false;
   if ((long)((N + 63) / 64) * ((K + 63) / 64) < 128) return false;     // few output tiles: the VAE's own FC layers (k_fcw32 / grouped)
-  if ((((uintptr_t)x | (uintptr_t)dy) & 15) != 0) return false;
+  if ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) != 0) return false;   // dw: 8-byte f32x2 stores at dw + row * K + col
   if ((long)64 * (N > K ? N : K) * 4 >= (1L << 31)) return false;
   constexpr int KS = 64, D = 3;
   const size_t lds = (size_t)(D + 1) * 2 * KS * 64 * sizeof(float);

@@ -85,7 +85,7 @@ static inline bool aligned16(const void* a, const void* b = nullptr, const void*
 // true if the launch was taken
 bool try_narrow_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int act, hipStream_t s) {
   static const bool off = env_off("DVAE_NARROW");     // A/B switch, debug builds only
-  if (off || N > NARROW_MAX || K < 256 || K % 4 || !aligned16(x, w)) return false;
+  if (off || N > NARROW_MAX || K < 256 || K % 4 || !aligned16(x, w)) return false;    // (y: scalar stores)
   hipLaunchKernelGGL(k_narrow_out_fwd, dim3((M + 3) / 4), dim3(256), 0, s, x, w, b, y, M, K, N, act);
   return true;
 }

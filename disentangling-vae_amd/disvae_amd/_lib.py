@@ -186,6 +186,18 @@ def lib():
     return _lib
 
 
+EVENT_SLOTS = 16              # DVAE_EVENT_SLOTS
+_next_slot = [0]
+
+
+def next_event_slot():
+    """dvae_event_record / dvae_event_wait slot for one loss object: handed out round-robin so that two trainers on one
+    device (different streams, different host threads) do not wait on each other's marks."""
+    s = _next_slot[0] % EVENT_SLOTS
+    _next_slot[0] += 1
+    return s
+
+
 ALLOC_GEN = [0]   # bumped whenever the engine (re)allocates device buffers: recorded plans hold raw pointers
 
 
@@ -212,8 +224,12 @@ def _pack(ctype, v):
         return 0
     if ctype is ctypes.c_float:
         return ctypes.c_uint32.from_buffer_copy(ctypes.c_float(v)).value
-    if isinstance(v, bytes):
-        raise DvaeHipError("byte-string arguments cannot be recorded")
+    if ctype not in (_p, _i, _l):
+        # dvae_plan_run decodes pointers / integers by value and every floating-point parameter from an fp32 bit pattern: a
+        # double (or any other type) would replay silently truncated
+        raise DvaeHipError("arguments of type %s cannot be recorded in a launch plan" % getattr(ctype, "__name__", ctype))
+    if isinstance(v, (bytes, float)):
+        raise DvaeHipError("%s argument for a %s parameter cannot be recorded" % (type(v).__name__, ctype.__name__))
     return int(v) & 0xFFFFFFFFFFFFFFFF
 
 
@@ -242,6 +258,8 @@ def call(name, *args):
         op = _OPS.get(name)
         if op is None:
             op = _OPS[name] = h.dvae_plan_op(name.encode())
+        if len(args) != len(fn.argtypes):
+            raise DvaeHipError("%s takes %d arguments, got %d" % (name, len(fn.argtypes), len(args)))
         if op >= 0 and len(args) <= PLAN_MAX_ARGS:
             _REC.append(("c", op, tuple(_pack(t, a) for t, a in zip(fn.argtypes, args)), name))
         else:

@@ -325,7 +325,7 @@ class VAEEngine:
             self.fork_side()
             fn()
             return
-        self._fork_hook = fn                   # (a hook left behind by a step that raised is dropped, not run)
+        self._fork_hook = fn                   # (the loss plugins clear a hook left behind by a step that raised)
 
     def flush_fork_hook(self):
         """A consumer of the deferred side-stream work is about to be enqueued: if no fork has happened yet, fork now."""

@@ -59,8 +59,6 @@ def linear_annealing(init, fin, step, annealing_steps):
 
 from ..engine import _stream  # noqa: E402
 
-_EV_ESTIMATOR = 0     # dvae_event_record / dvae_event_wait slot: "the btcvae estimator and the scalar loss of this step are final"
-
 
 class _Scratch:
     """Small device buffers shared by the loss kernels of one loss object."""
@@ -128,13 +126,15 @@ class BaseLoss(abc.ABC):
         # Python; "plan" = recorded launch list (the same launches on the same streams, bit-identical
         # results); "graph" = hipGraph; "auto" (default) = plan while the iteration is launch-bound
         # (batch tensor <= AUTO_PLAN_ELEMS elements: measured cross-over), eager
-        # above.  Single-process only (collectives stay eager)
+        # above.  Sharded steps replay too: collectives are recorded plan entries (parallel.py)
         mode = knob("DVAE_REPLAY", "auto")
         if mode not in ("plan", "graph", "eager", "auto"):
             raise ValueError("DVAE_REPLAY={!r}: expected one of auto, eager, plan, graph".format(mode))
         self.replay = {"plan": "plan", "graph": "graph", "eager": None, "auto": "auto"}[mode]
         self._graphs = StepGraphs()
         self._static = {}
+        # dvae_event_record / dvae_event_wait slot of this loss object: "the estimator and the scalar loss of this step are final"
+        self._ev_slot = _lib.next_event_slot()
 
     def _static_buf(self, name, like):
         """Persistent device buffer with the shape/dtype of `like`, refreshed with its contents."""
@@ -418,6 +418,7 @@ class _SingleOptimizerLoss(BaseLoss):
     def _device_step(self, data, model, sc, eps, is_train):
         """Forward + loss + backward as one stream of launches; no host-dependent values."""
         eng = model.engine
+        eng._fork_hook = None                  # a hook left behind by a step that raised is dropped, not run (nor recorded)
         B, D = data.shape[0], model.latent_dim
         world, rank = self._world()
         Bg = B * world
@@ -478,7 +479,7 @@ class _SingleOptimizerLoss(BaseLoss):
             def epilogue():                       # after the next fork (the backward pass's first): no fork of its own
                 call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), B, None, Bg,
                      ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), eng._side_raw())
-                call("dvae_event_record", _EV_ESTIMATOR, eng._side_raw())
+                call("dvae_event_record", self._ev_slot, eng._side_raw())
             eng.at_next_fork(epilogue)
         elif world > 1:
             call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
@@ -502,7 +503,7 @@ class _SingleOptimizerLoss(BaseLoss):
                 self._wait_scalars(sc)
             if late_join:
                 eng.flush_fork_hook()
-                call("dvae_event_wait", _EV_ESTIMATOR, s)
+                call("dvae_event_wait", self._ev_slot, s)
             eng.fc_chain_bwd(buf, eps, dz_x, None, dmu_x, dlv_x, sc.scal, sc.coef, B)
 
         # single process: one join, at the end of the backward pass, and ONE grouped launch for all six FC weight
@@ -671,6 +672,7 @@ class FactorKLoss(BaseLoss):
         """Training iteration of FactorVAE as one stream of launches (no host-dependent values):
         VAE forward on both halves, discriminator on (z1, z_perm), both backward passes."""
         eng = model.engine
+        eng._fork_hook = None                  # a hook left behind by a step that raised is dropped, not run (nor recorded)
         disc = self.discriminator
         D = model.latent_dim
         B = data.size(0)
@@ -737,7 +739,7 @@ class FactorKLoss(BaseLoss):
             if late_epi:                          # after the next fork (the backward pass's first): no fork of its own
                 def deferred():
                     epilogue(eng._side_raw())
-                    call("dvae_event_record", _EV_ESTIMATOR, eng._side_raw())
+                    call("dvae_event_record", self._ev_slot, eng._side_raw())
                 eng.at_next_fork(deferred)
             else:
                 epilogue(s)
@@ -755,7 +757,7 @@ class FactorKLoss(BaseLoss):
                 self._wait_scalars(sc)
             if late_epi:
                 eng.flush_fork_hook()
-                call("dvae_event_wait", _EV_ESTIMATOR, s)
+                call("dvae_event_wait", self._ev_slot, s)
             eng.fc_chain_bwd(buf, eps1, dz_a, dz_b, None, None, sc.scal, sc.coef, Bh)
 
         eng.decode_backward(buf.z, buf, n=Bh, join=world > 1, defer_fc_wgrad=world == 1, fc_chain=fc_chain)   # single process: joined at the end of encode_backward

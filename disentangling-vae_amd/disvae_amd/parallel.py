@@ -220,6 +220,67 @@ class RcclComm(Comm):
             self._h = None
 
 
+class MirroredWorldComm(Comm):
+    """Measurement and test aid, NOT a transport: one process stands in for rank `rank` of `world_size` ranks whose peers
+    hold IDENTICAL shards (same images, same noise).  Every collective first runs through the wrapped one-rank communicator
+    `inner` (``Comm`` or ``RcclComm``: the real call sites, RCCL launches and stream ordering of the data-parallel step) and is
+    then completed with what the absent peers would have contributed: all-gather -> the shard replicated `world_size`
+    times, sum-all-reduce / reduce-scatter -> `world_size` x the local term.  The loss plugins then run the whole sharded
+    code path at the shard's real sizes (B local rows of a world_size * B column estimator, packed exchanges, two gradient
+    spans) on ONE GPU: ``bench.py``'s shard legs time it, ``tests/test_gpu_ddp.py`` holds it to the single-process step on
+    the shard tiled `world_size` times (exact for every term that is symmetric in the ranks: everything except the
+    minibatch-stratified weights' one exception cell, math.py:72, and FactorVAE's global permutation)."""
+
+    def __init__(self, inner, world_size, rank=0):
+        if inner.world_size != 1:
+            raise ValueError("MirroredWorldComm wraps a one-rank communicator")
+        if not (0 <= int(rank) < int(world_size)):
+            raise ValueError("rank %r outside world_size %r" % (rank, world_size))
+        self.inner = inner
+        self.group = inner.group
+        self.world_size = int(world_size)
+        self.rank = int(rank)
+        self._bufs = {}
+
+    def all_reduce(self, t):
+        self.inner.all_reduce(t)
+        record_on_stream(t.mul_, float(self.world_size))
+        return t
+
+    def all_reduce_async(self, t):
+        h = self.inner.all_reduce_async(t)
+        W = float(self.world_size)
+
+        class _Handle:
+            def wait(self_inner):
+                h.wait()
+                record_on_stream(t.mul_, W)
+
+        return _Handle()
+
+    def all_gather_into(self, out, t):
+        rows = out.view(self.world_size, -1)
+        self.inner.all_gather_into(rows[0], t)
+        if self.world_size > 1:
+            record_on_stream(rows[1:].copy_, rows[0:1].expand(self.world_size - 1, -1))
+
+    def reduce_scatter_into(self, out, t):
+        self.inner.reduce_scatter_into(out, t.view(self.world_size, -1)[self.rank])
+        record_on_stream(out.mul_, float(self.world_size))
+
+    def broadcast(self, t, src=0):
+        return self.inner.broadcast(t, src=0)
+
+    def group_start(self):
+        self.inner.group_start()
+
+    def group_end(self):
+        self.inner.group_end()
+
+    def close(self):
+        self.inner.close()
+
+
 def init_process_group_from_env(backend=None):
     """Rendezvous from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun-style)."""
     if dist.is_initialized():

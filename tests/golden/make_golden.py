@@ -2,7 +2,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [--latent | --metrics | --bench-size]
 
 The reference is imported unmodified with the two import shims of SURVEY.md section 8c
 (stub ``imageio``; ``numpy.product = numpy.prod``).  Noise is recorded by wrapping
@@ -99,7 +99,7 @@ def kats(losses, dmath):
     return out
 
 
-def run_case(ref, loss_name, img_size, batch, n_steps, seed, n_data, lr, rec_dist="bernoulli", latent_dim=10):
+def run_case(ref, loss_name, img_size, batch, n_steps, seed, n_data, lr, rec_dist="bernoulli", latent_dim=10, absmax=False):
     """Run the reference Trainer._train_iteration n_steps times; record everything."""
     disvae, losses, vae, discriminator, dmath, training = ref
     torch.manual_seed(seed)
@@ -143,8 +143,12 @@ def run_case(ref, loss_name, img_size, batch, n_steps, seed, n_data, lr, rec_dis
         for k, p in model.named_parameters():
             out["step%d/grad_digest/%s" % (step, k)] = tensor_digest(p.grad)
             out["step%d/param_digest/%s" % (step, k)] = tensor_digest(p)
+            if absmax:         # scale of the element-wise bound two fp32 arithmetics are held to (ReLU gates at rounding level)
+                out["step%d/grad_absmax/%s" % (step, k)] = np.float64(p.grad.abs().max().item())
         if loss_name == "factor":
             for k, p in loss_f.discriminator.named_parameters():
+                if absmax:
+                    out["step%d/dgrad_absmax/%s" % (step, k)] = np.float64(p.grad.abs().max().item())
                 out["step%d/dgrad_digest/%s" % (step, k)] = tensor_digest(p.grad)
                 out["step%d/dparam_digest/%s" % (step, k)] = tensor_digest(p)
     # full small tensors for the last forward (eval-mode forward on the last batch)
@@ -210,6 +214,17 @@ def main():
         return
     ref = import_reference()
     _, losses, vae, discriminator, dmath, training = ref
+    if "--bench-size" in sys.argv:    # step 0 of the two dsprites BASELINE workloads at their own batch (digests + noise only)
+        for name, loss, img, b, steps, seed, n_data, lr in [
+                ("btcvae_dsprites_b256", "btcvae", (1, 64, 64), 256, 1, 1234, 737280, 5e-4),
+                ("factor_dsprites_b256", "factor", (1, 64, 64), 256, 1, 1234, 737280, 1e-4)]:
+            out = run_case(ref, loss, img, b, steps, seed, n_data, lr, absmax=True)
+            drop = ("eval/",) + (("step0/randn0",) if loss == "factor" else ())     # factor: the wasted full-batch draw (Q4)
+            for k in [k_ for k_ in out if k_.startswith(drop)]:          # [256, 10] tensors nobody replays: keep the file small
+                del out[k]
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "loss", [out["step%d/loss" % s] for s in range(steps)], os.path.getsize(os.path.join(HERE, name + ".npz")), "bytes")
+        return
     if "--latent" in sys.argv:        # latent dimensions other than the default 10 (main.py -z): only these files are written
         for name, loss, img, b, steps, seed, n_data, lr, zdim in [
                 ("btcvae_z16_dsprites", "btcvae", (1, 64, 64), 8, 2, 4321, 737280, 5e-4, 16),

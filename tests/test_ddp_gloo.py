@@ -119,3 +119,50 @@ def test_data_parallel_exchange_world2():
         p_.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def _worker_mirrored(port, q):
+    """MirroredWorldComm over a ONE-rank gloo group: what the absent peers of an identical-shard world would contribute."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.set_num_threads(1)
+    from disvae_amd import parallel
+    parallel.init_process_group_from_env("gloo")
+    try:
+        W, B, D = 4, 3, 5
+        for rank in (0, 2):
+            comm = parallel.MirroredWorldComm(parallel.Comm(), W, rank)
+            assert (comm.world_size, comm.rank) == (W, rank)
+            z = torch.arange(B * D, dtype=torch.float32).view(B, D)
+            zg, mug, lvg = comm.all_gather_latents(z, z + 100, z + 200)
+            assert zg.shape == (W * B, D)
+            assert torch.equal(zg, z.repeat(W, 1)) and torch.equal(mug, (z + 100).repeat(W, 1)) and torch.equal(lvg, (z + 200).repeat(W, 1))
+            rows = comm.all_gather_rows(z + 7)
+            assert torch.equal(rows, (z + 7).repeat(W, 1))
+            a = torch.arange(W * B * D, dtype=torch.float32).view(-1, D)
+            da, db = comm.reduce_scatter_cols(a, 2 * a)
+            sl = slice(rank * B, (rank + 1) * B)
+            assert torch.equal(da, W * a[sl]) and torch.equal(db, 2 * W * a[sl])
+            t = comm.all_reduce(torch.ones(6))
+            assert (t == W).all()
+            u = torch.full((5,), 3.0)
+            h = comm.all_reduce_async(u)
+            h.wait()
+            assert (u == 3.0 * W).all()
+        with pytest.raises(ValueError):
+            parallel.MirroredWorldComm(parallel.Comm(), 4, 4)
+        q.put((0, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((0, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mirrored_world_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_worker_mirrored, args=(_free_port(), q))
+    p_.start()
+    rank, msg = q.get(timeout=240)
+    p_.join(timeout=60)
+    assert msg == "ok", msg

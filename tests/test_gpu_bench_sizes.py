@@ -282,3 +282,51 @@ def test_4x4_end_nchw_persistent(N):
     call("dvae_convT4s2_wgrad", ptr(dev(xa)), _lib.NCHW, ptr(nhwc(dy)), _lib.NHWC, ptr(dw), ptr(db), N, C, 4, 4, C, ptr(ws), stream())
     check(dw, wr.grad, rtol=K_RTOL, atol_rel=K_ATOL, what="N=%d convT wgrad <- NCHW x" % N)
     check(db, br.grad, rtol=K_RTOL, atol_rel=K_ATOL, what="N=%d convT bias grad" % N)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# against numbers RECORDED FROM THE REAL REFERENCE at a bench size (tests/golden/make_golden.py --bench-size)
+REF_REC_GRAD_BOUND = 6e-4     # two fp32 arithmetics on the same step differ by up to 3e-4 of max|g| EACH from fp64 (ReLU units
+                              # within rounding of zero gate differently: tools/fp32_vs_fp64_oracle.py, decoder.convT2.weight)
+
+
+@pytest.mark.parametrize("name,loss", [("btcvae_dsprites_b256", "btcvae"), ("factor_dsprites_b256", "factor")])
+def test_step0_vs_reference_recorded_numbers_at_batch_256(name, loss):
+    """BASELINE configs[1] / configs[2] at their own batch: the first training iteration of the native engine against what the
+    unmodified reference's Trainer._train_iteration produced on the same seed, batch and recorded noise -- initial weights bit
+    for bit, loss and logged scalars to 1e-5, every gradient tensor's digest (24 sampled entries, sum, abs-sum) to the bound
+    two fp32 arithmetics can be held to: 6e-4 of the tensor's max|g| per entry (REF_REC_GRAD_BOUND), 1e-3 of the abs-sum for
+    the sums.  The 1e-5 gradient bar proper is the gate-matched fp64 oracle's (tests above)."""
+    from golden_util import load, tensor_digest
+    g = load(name)
+    img, B = (1, 64, 64), 256
+    seed = int(g["seed"])
+    model, opt, loss_f = _native(loss, img, seed, int(g["n_data"]), float(g["lr"]), 1e-4)
+    for k, v in model.state_dict().items():
+        np.testing.assert_array_equal(tensor_digest(v)[2:], g["init_digest/" + k][2:], err_msg=k)
+    data = torch.rand((B,) + img, generator=torch.Generator().manual_seed(seed + 1))
+    storer = defaultdict(list)
+    if loss == "factor":
+        for k, v in loss_f.discriminator.state_dict().items():
+            np.testing.assert_array_equal(tensor_digest(v)[2:], g["dinit_digest/" + k][2:], err_msg=k)
+        noise = (dev(torch.from_numpy(g["step0/randn1"])), dev(torch.from_numpy(g["step0/randn2"])), torch.from_numpy(g["step0/perms"]))
+        out = loss_f.call_optimize(dev(data), model, opt, storer, noise=noise)
+    else:
+        out = loss_f.fused_step(dev(data), model, opt, storer, eps=dev(torch.from_numpy(g["step0/randn0"])))
+    np.testing.assert_allclose(out.item(), g["step0/loss"], rtol=1e-5)
+    assert set(storer) == {k.split("/")[-1] for k in g if k.startswith("step0/storer/")}
+    for k, v in storer.items():
+        np.testing.assert_allclose(v[0], g["step0/storer/" + k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+    def digests(named, prefix):
+        for k, p in named:
+            got, want = tensor_digest(p.grad), g["step0/%s_digest/%s" % (prefix, k)]
+            amax = float(g["step0/%s_absmax/%s" % (prefix, k)])
+            err = np.abs(got[2:] - want[2:]).max()
+            record_stat("%s %s vs reference-recorded digest %s" % (name, prefix, k), err / amax, err / (REF_REC_GRAD_BOUND * amax))
+            assert err <= REF_REC_GRAD_BOUND * amax, (name, k, err, amax)
+            assert abs(got[0] - want[0]) <= 1e-3 * want[1] and abs(got[1] - want[1]) <= 1e-3 * want[1], (name, k, got[:2], want[:2])
+
+    digests(model.named_parameters(), "grad")
+    if loss == "factor":
+        digests(loss_f.discriminator.named_parameters(), "dgrad")

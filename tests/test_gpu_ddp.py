@@ -259,3 +259,74 @@ def test_local_estimator_is_rank_average(loss):
         p_.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", "rank %d: %s" % (rank, msg)
+
+
+def _worker_mirrored(port, loss, q, transport, replay, world_emulated, Bl):
+    """ONE rank (RCCL, backend nccl) standing in for rank 0 of `world_emulated` ranks with identical shards
+    (parallel.MirroredWorldComm): the whole sharded code path at world > 1 -- packed gather / scatter, loss-sum all-reduce, the
+    gradient spans all-reduced asynchronously under the backward pass, through the product transports -- must equal the
+    single-process eager step on the shard tiled world_emulated times.  Exact for terms that are symmetric in the ranks: the
+    beta-TCVAE estimator with uniform weights (is_mss=False; the stratified weights' one exception cell, math.py:72, lives in
+    the last rank's row block only) and the VAE / betaH losses."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for p in (root, os.path.join(root, "disentangling-vae_amd"), os.path.join(root, "tests")):
+            sys.path.insert(0, p)
+        from disvae_amd import parallel
+        torch.cuda.set_device(0)
+        parallel.init_process_group_from_env("nccl")
+        W, D, lr = world_emulated, 10, 5e-4
+        gen = torch.Generator().manual_seed(11)
+        shard = torch.rand((Bl,) + IMG, generator=gen)
+        eps = torch.randn(Bl, D, generator=gen)
+        m0, o0, l0 = _make(loss, lr)             # single process, eager, on the tiled global batch
+        l0.replay = None
+        m1, o1, l1 = _make(loss, lr)             # the mirrored shard
+        l1.replay = replay
+        if loss == "btcvae":
+            l0.is_mss = l1.is_mss = False
+        inner = parallel.RcclComm() if transport == "rccl" else parallel.Comm()
+        comm = parallel.data_parallel(m1, l1, comm=parallel.MirroredWorldComm(inner, W, 0))
+        assert comm.world_size == W and l1._world() == (W, 0)
+        g_data, g_eps = shard.repeat(W, 1, 1, 1).cuda(), eps.repeat(W, 1).cuda()
+        l_data, l_eps = shard.cuda(), eps.cuda()
+        for it in range(4 if replay else 1):
+            st = defaultdict(list)
+            out0 = l0.fused_step(g_data, m0, o0, defaultdict(list), eps=g_eps)
+            out1 = l1.fused_step(l_data, m1, o1, st, eps=l_eps)
+            ref_loss = out0.item()
+            err = ((m1.arena.grad - m0.arena.grad).abs().max() / m0.arena.grad.abs().max()).item()
+            assert err < 2e-5 * (it + 1), "iteration %d: grad err %.3e" % (it, err)
+            assert abs(out1.item() - ref_loss) <= 2e-6 * (it + 1) * abs(ref_loss), (it, out1.item(), ref_loss)
+            assert (m1.arena.flat - m0.arena.flat).abs().max().item() <= 2.5 * lr * (it + 1)
+            if it == 0:
+                assert st["loss"] and abs(st["loss"][0] - ref_loss) <= 2e-6 * abs(ref_loss)
+        if replay:
+            assert l1._graphs.replays >= 2, l1._graphs.replays
+        comm.close()
+        q.put((0, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((0, traceback.format_exc()))
+    finally:
+        try:
+            torch.distributed.destroy_process_group()
+        except Exception:
+            pass
+
+
+@pytest.mark.parametrize("replay", [None, "plan"])
+@pytest.mark.parametrize("transport", ["torch", "rccl"])
+@pytest.mark.parametrize("loss,world_emulated,Bl", [("btcvae", 8, 16), ("VAE", 4, 12)])
+def test_mirrored_world_runs_the_sharded_path_on_one_gpu(loss, world_emulated, Bl, transport, replay):
+    """The data-parallel step at world_size > 1 through RCCL on the ONE GPU of the test box (see _worker_mirrored); with
+    replay="plan" iterations 3 and 4 are replays of the recorded sharded launch plan, NCCL collectives included."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_worker_mirrored, args=(_free_port(), loss, q, transport, replay, world_emulated, Bl))
+    p_.start()
+    rank, msg = q.get(timeout=280)
+    p_.join(timeout=60)
+    assert msg == "ok", msg

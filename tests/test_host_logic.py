@@ -245,6 +245,17 @@ def test_bench_reads_hbm_traffic_from_the_newest_pmc_summary(tmp_path, monkeypat
     assert bench.pmc_traffic("k_up32ws<16, false>")[1] == os.path.join("profiles", "r02_final_pmc_summary.md")
     assert bench.pmc_traffic("k_up32ws<16") == (None, None)           # a prefix is not a row
     assert bench.pmc_traffic("k_no_such_kernel") == (None, None)
+    # a numbered final visit beats every vNN / runNN visit of its round whatever the numbers (round 4: r04_v35 was picked
+    # over r04_final3), a later numbered final beats an earlier one, the next round's first visit beats them all
+    (prof / "r04_v35_pmc_summary.md").write_text(head + "| k_up_thin_pk<3, true, float> | 1 | 240.0 | 104.3 | 0.0 |\n")
+    (prof / "r04_final3_pmc_summary.md").write_text(head + "| k_up_thin_pk<3, true, float> | 1 | 186.3 | 100.7 | 0.0 |\n")
+    (prof / "r04_final2_pmc_summary.md").write_text(head + "| k_up_thin_pk<3, true, float> | 1 | 200.0 | 100.0 | 0.0 |\n")
+    bytes_, src = bench.pmc_traffic("k_up_thin_pk<3, true, float>")
+    assert src == os.path.join("profiles", "r04_final3_pmc_summary.md") and abs(bytes_ - 287.0e6) < 1.0
+    (prof / "r05_v2_pmc_summary.md").write_text(head + "| k_up_thin_pk<3, true, float> | 1 | 190.0 | 100.0 | 0.0 |\n")
+    assert bench.pmc_traffic("k_up_thin_pk<3, true, float>")[1] == os.path.join("profiles", "r05_v2_pmc_summary.md")
+    names = ["r02_run6_x.md", "r02_final_x.md", "r03_run1_x.md", "r04_v35_x.md", "r04_final_x.md", "r04_final2_x.md", "r05_v1_x.md"]
+    assert sorted(reversed(names), key=bench.pmc_file_order) == names
 
 
 def test_device_image_loader_draws_batches_like_the_reference_dataloader():

@@ -172,6 +172,38 @@ def test_factor_cases(name, img):
                                 what="%s step%d dparam %s" % (name, s, k))
 
 
+@pytest.mark.parametrize("name,loss", [("btcvae_dsprites_b256", "btcvae"), ("factor_dsprites_b256", "factor")])
+def test_bench_size_cases(name, loss):
+    """Step 0 of the two dsprites BASELINE workloads at their OWN batch (256), recorded from the real reference with
+    `make_golden.py --bench-size`: the oracle reproduces the reference at a bench size too (same bounds as the small cases)."""
+    g = load(name)
+    img, B = (1, 64, 64), 256
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    params = O.init_vae_params(img, 10)
+    dparams = O.init_disc_params(10) if loss == "factor" else None
+    hp = dict(HP, n_data=int(g["n_data"]))
+    tr = O.OracleTrainer(loss, hp, img, 10, lr=float(g["lr"]), lr_disc=HP["lr_disc"], steps_anneal=HP["reg_anneal"],
+                         params=params, dparams=dparams)
+    data = torch.rand((B,) + img, generator=torch.Generator().manual_seed(seed + 1))
+    if loss == "factor":
+        perms = [torch.from_numpy(p) for p in g["step0/perms"]]
+        assert len(perms) == 10 and perms[0].numel() == B // 2
+        loss_val, logs = tr.train_iteration(data, eps=torch.from_numpy(g["step0/randn1"]), eps2=torch.from_numpy(g["step0/randn2"]),
+                                            perms=perms)
+    else:
+        loss_val, logs = tr.train_iteration(data, eps=torch.from_numpy(g["step0/randn0"]))
+    np.testing.assert_allclose(loss_val, g["step0/loss"], rtol=2e-6)
+    for k in logs:
+        np.testing.assert_allclose(logs[k].item(), g["step0/storer/" + k], rtol=1e-5, atol=1e-6, err_msg=k)
+    for k, p in tr.params.items():
+        assert_digest_close(tensor_digest(p.grad), g["step0/grad_digest/" + k], rtol=2e-5, what="%s grad %s" % (name, k))
+        assert_digest_close(tensor_digest(p), g["step0/param_digest/" + k], rtol=2e-5, what="%s param %s" % (name, k))
+    if loss == "factor":
+        for k, p in tr.dparams.items():
+            assert_digest_close(tensor_digest(p.grad), g["step0/dgrad_digest/" + k], rtol=2e-5, what="%s dgrad %s" % (name, k))
+
+
 def test_eval_forward_matches_golden():
     """eval-mode forward (z = mu) after the golden training steps."""
     g = load("btcvae_dsprites")
