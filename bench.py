@@ -527,6 +527,7 @@ def time_leg(cfg, B, device, steps, warmup, drop_in=False, replay=None):
     data = torch.rand((B,) + tuple(cfg["img"]), device=device, generator=gen)
     torch.cuda.manual_seed(1234)
     storer = defaultdict(list)
+    settle_rounds(lambda: trainer._train_iteration_async(data, storer))       # untimed: the leg may follow seconds of CPU work
     if drop_in == "epoch":
         # Trainer.__call__'s inner loop (training.py:104-135) over a loader of resident batches, no progress bar
         # (main.py --no-progress-bar): the mean epoch loss is the one host sync
@@ -583,6 +584,7 @@ def extra_config(name, device, steps, warmup, with_cpu, with_parity):
     return out
 
 
+DEFAULT_TRANSPORT = {"auto": "rccl"}.get(os.environ.get("DVAE_COMM", "auto"), os.environ.get("DVAE_COMM", "auto"))
 SHARD_WORLD = 8       # BASELINE configs[3]: "b=1024 ... DDP over 8xMI355X" = 128 images per GPU
 
 
@@ -595,7 +597,28 @@ def _free_port():
     return port
 
 
-def shard_legs(device, steps, warmup, with_parity, with_roofline):
+def settle_rounds(step_fn, max_rounds=12, tol=0.015, min_round_ms=40.0):
+    """Untimed settle phase: rounds of >= 5 steps and >= `min_round_ms` each until two consecutive rounds agree within `tol`
+    (clocks, caches and the allocator reach their steady state: a leg that follows seconds of CPU work starts on an idle-clocked
+    GPU).  Returns the ms per step of each round."""
+    rounds, n = [], 5
+    for _ in range(max_rounds):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(n):
+            step_fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - ts) * 1e3
+        rounds.append(dt / n)
+        if dt < min_round_ms:
+            n = min(int(n * min_round_ms / max(dt, 1e-3)) + 1, 400)
+            continue
+        if len(rounds) >= 2 and abs(rounds[-1] - rounds[-2]) <= tol * rounds[-1]:
+            break
+    return rounds
+
+
+def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single", "torch", "rccl")):
     """BASELINE configs[3] as ONE of its eight ranks runs it, on this one GPU: 128 images per step through the SHARDED code
     path of the btcvae step (disvae_amd.parallel: packed latent all-gather, the rank's 128 rows of the 1024-column B x B
     estimator, packed column-gradient reduce-scatter, loss-sum all-reduce, the gradient arena all-reduced in two spans under
@@ -637,7 +660,8 @@ def shard_legs(device, steps, warmup, with_parity, with_roofline):
         data = torch.rand((B,) + tuple(cfg["img"]), device=device, generator=gen)
         torch.cuda.manual_seed(1234)
         storer = defaultdict(list)
-        for _ in range(20 + warmup):
+        rounds = settle_rounds(lambda: trainer._train_iteration_async(data, storer))
+        for _ in range(warmup):
             trainer._train_iteration_async(data, storer)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -651,10 +675,11 @@ def shard_legs(device, steps, warmup, with_parity, with_roofline):
         tf = flops / (ms * 1e-3) / 1e12
         return {"ms_per_step": round(ms, 4), "value": round(B / (ms * 1e-3), 1), "step_tflops": round(tf, 2),
                 "step_frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "final_loss": round(final, 4),
-                "replay": loss_f._replay_mode(True, data) or "eager"}
+                "replay": loss_f._replay_mode(True, data) or "eager", "settle_ms_per_step": [round(x, 4) for x in rounds]}
 
     mark("configs:shard:single")
-    out["single_process"] = leg(None)
+    if "single" in which:
+        out["single_process"] = leg(None)
     mark("configs:shard:ddp")
     own_group = False
     try:
@@ -665,12 +690,15 @@ def shard_legs(device, steps, warmup, with_parity, with_roofline):
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
             parallel.init_process_group_from_env("nccl")
             own_group = True
-        out["transports"] = {t: leg(t) for t in ("torch", "rccl")}
-        a, b = out["transports"]["torch"]["ms_per_step"], out["transports"]["rccl"]["ms_per_step"]
-        out["transports_rel_diff"] = round(abs(a - b) / min(a, b), 4)
-        # the headline numbers of the leg = the default transport's
-        out.update({k: out["transports"]["torch"][k] for k in ("ms_per_step", "value", "step_tflops", "step_frac_of_fp32_peak")})
-        out["node_value_at_this_rate"] = round(out["value"] * SHARD_WORLD, 1)
+        out["transports"] = {t: leg(t) for t in ("torch", "rccl") if t in which}
+        if len(out["transports"]) == 2:
+            a, b = out["transports"]["torch"]["ms_per_step"], out["transports"]["rccl"]["ms_per_step"]
+            out["transports_rel_diff"] = round(abs(a - b) / min(a, b), 4)
+        if out["transports"]:
+            # the headline numbers of the leg = the default transport's
+            first = out["transports"].get(DEFAULT_TRANSPORT) or list(out["transports"].values())[0]
+            out.update({k: first[k] for k in ("ms_per_step", "value", "step_tflops", "step_frac_of_fp32_peak")})
+            out["node_value_at_this_rate"] = round(out["value"] * SHARD_WORLD, 1)
     except Exception as e:                       # a box whose RCCL cannot initialise still gets the rest of the line
         out["error"] = "%s: %s" % (type(e).__name__, e)
     finally:
@@ -729,15 +757,17 @@ def main():
                     "collectives, barriers) even with ONE rank: exercises the N>1 path of this script on a single GPU")
     ap.add_argument("--estimator", default="global", choices=["global", "local"],
                     help="scope of the batch-coupled estimators under data parallelism (disvae_amd.parallel.data_parallel)")
-    ap.add_argument("--transport", default=None, choices=["torch", "rccl"],
-                    help="collectives of the data-parallel step: torch.distributed (nccl = RCCL; default) or the C-ABI's "
-                         "dvae_comm_* (RCCL enqueued by libdvae_hip.so); DVAE_COMM sets the default")
+    ap.add_argument("--transport", default=None, choices=["auto", "torch", "rccl"],
+                    help="collectives of the data-parallel step: the C-ABI's dvae_comm_* (RCCL enqueued by libdvae_hip.so: "
+                         "rccl), torch.distributed (nccl = RCCL: torch) or auto (default: rccl after a verified round trip on "
+                         "every rank, else torch); DVAE_COMM sets the default")
     ap.add_argument("--replay", default=None, choices=["auto", "eager", "plan", "graph"],
                     help="how the launches of an iteration are issued (disvae_amd/graph.py)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the short legs of the other three BASELINE "
                     "workloads (they run by default with N = 1 and the default workload)")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop-in leg (Adam(model.parameters()) + a host "
                     "sync per iteration)")
+    ap.add_argument("--shard-which", default="single,torch,rccl", help="subset of the shard legs (profiling)")
     ap.add_argument("--shard-legs", action="store_true", help="only the btcvae_celeba_shard legs (one rank of eight at 128 "
                     "images per GPU: single process, torch transport, rccl transport), print them, exit")
     ap.add_argument("--cpu-reference", action="store_true", help="no GPU needed: time the unmodified reference Trainer "
@@ -768,8 +798,13 @@ def main():
     device = torch.device("cuda", local_rank)
 
     if args.shard_legs:
-        print(json.dumps(shard_legs(device, steps=args.steps, warmup=args.warmup, with_parity=not args.no_parity_check,
-                                    with_roofline=not args.no_roofline)), flush=True)
+        res = shard_legs(device, steps=args.steps, warmup=args.warmup, with_parity=not args.no_parity_check,
+                         with_roofline=not args.no_roofline, which=tuple(args.shard_which.split(",")))
+        try:                                     # RCCL's banner goes through C stdio: out before the result line
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
         return
 
     name = args.config or ("factor_celeba" if args.loss == "factor" else "btcvae_celeba")
@@ -839,15 +874,7 @@ def main():
         for _ in range(20):
             trainer._train_iteration_async(data, storer)
     else:
-        for _ in range(12):
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(5):
-                trainer._train_iteration_async(data, storer)
-            torch.cuda.synchronize()
-            settle.append((time.perf_counter() - ts) / 5 * 1e3)
-            if len(settle) >= 2 and abs(settle[-1] - settle[-2]) <= 0.015 * settle[-1]:
-                break
+        settle = settle_rounds(lambda: trainer._train_iteration_async(data, storer), min_round_ms=0.0)
     for _ in range(args.warmup):
         trainer._train_iteration_async(data, storer)
     # HIP events on the compute stream (torch's current stream = the stream the engine launches on) at the
@@ -911,7 +938,7 @@ def main():
                                   "+RCCL collectives" if world > 1 else ""),
                    "name": name, "dataset_shape": dset, "batch_per_gpu": B, "global_batch": B_global,
                    "parallelism": "dp%d" % world, "estimator": args.estimator if ddp else None,
-                   "transport": (args.transport or os.environ.get("DVAE_COMM", "torch")) if ddp else None,
+                   "transport": ("rccl" if type(comm).__name__ == "RcclComm" else "torch") if ddp else None,
                    "final_loss": round(final_loss, 4)},
         "hip_event_ms_per_step": {"segments": [round(x, 4) for x in seg_ms], "median": round(sorted(seg_ms)[len(seg_ms) // 2], 4),
                                   "note": "HIP events on the compute stream of rank 0 around %d equal segments of the timed "

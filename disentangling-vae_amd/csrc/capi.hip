@@ -482,4 +482,14 @@ int dvae_add(const float* a, const float* b, float* out, long n, void* stream) {
   return launch_add(a, b, out, n, (hipStream_t)stream);
 }
 
+int dvae_axpby(float* out, const float* a, float alpha, const float* b, float beta, long n, void* stream) {
+  DVAE_CHECK_ARG(out && a && n > 0);
+  return launch_axpby(out, a, alpha, b, beta, n, (hipStream_t)stream);
+}
+
+int dvae_swap_outer(const float* src, float* dst, int A, int Bn, long inner, void* stream) {
+  DVAE_CHECK_ARG(src && dst && src != dst && A > 0 && Bn > 0 && inner > 0);
+  return launch_swap_outer(src, dst, A, Bn, inner, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -224,6 +224,8 @@ int launch_loss_epilogue(int kind, const float* rec_partials, const float* kl_di
                          hipStream_t s);
 int launch_set_coef(float* coef, const float* v, hipStream_t s);
 int launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);
+int launch_axpby(float* out, const float* a, float alpha, const float* b, float beta, long n, hipStream_t s);
+int launch_swap_outer(const float* src, float* dst, int A, int Bn, long inner, hipStream_t s);
 
 bool use_generic_only();  // DVAE_FORCE_GENERIC=1 (on-device reference path of the parity tests, still HIP)
 

@@ -558,6 +558,24 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
     out[i] = a[i] + b[i];
 }
 
+// out = alpha * a (+ beta * b): the means over the global batch and the mirrored-world completions of the data-parallel step
+__global__ void k_axpby(float* __restrict__ out, const float* __restrict__ a, float alpha, const float* __restrict__ b,
+                        float beta, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = b ? alpha * a[i] + beta * b[i] : alpha * a[i];
+}
+
+// src[A][Bn][inner] -> dst[Bn][A][inner]: the packed exchanges of the sharded beta-TCVAE step (an all-gather delivers
+// [world][3][B*D], the estimator reads [3][world*B*D]; its column gradients [2][world][B*D] leave as [world][2][B*D])
+__global__ void k_swap_outer(const float* __restrict__ src, float* __restrict__ dst, int A, int Bn, long inner) {
+  const long n = (long)A * Bn * inner;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long e = i % inner, ab = i / inner;
+    const int b = (int)(ab % Bn), a = (int)(ab / Bn);
+    dst[((long)b * A + a) * inner + e] = src[i];
+  }
+}
+
 // ---- launchers -------------------------------------------------------------------------------
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                           const float* coef, int B, int D, hipStream_t s) {
@@ -708,6 +726,21 @@ int launch_set_coef(float* coef, const float* v, hipStream_t s) {
 int launch_add(const float* a, const float* b, float* out, long n, hipStream_t s) {
   long g = (n + 255) / 256; if (g > 2048) g = 2048;
   hipLaunchKernelGGL(k_add, dim3(g), dim3(256), 0, s, a, b, out, n);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_axpby(float* out, const float* a, float alpha, const float* b, float beta, long n, hipStream_t s) {
+  long g = (n + 255) / 256; if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, s, out, a, alpha, b, beta, n);
+  DVAE_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_swap_outer(const float* src, float* dst, int A, int Bn, long inner, hipStream_t s) {
+  const long n = (long)A * Bn * inner;
+  long g = (n + 255) / 256; if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_swap_outer, dim3(g), dim3(256), 0, s, src, dst, A, Bn, inner);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

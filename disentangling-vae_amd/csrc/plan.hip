@@ -54,6 +54,7 @@ static const PlanOp OPS[] = {
     DVAE_OP(dvae_reduce_sum), DVAE_OP(dvae_recon_loss), DVAE_OP(dvae_sigmoid_bwd), DVAE_OP(dvae_btcvae_fwd),
     DVAE_OP(dvae_btcvae_bwd), DVAE_OP(dvae_permute_dims), DVAE_OP(dvae_disc_losses), DVAE_OP(dvae_latent_entropy),
     DVAE_OP(dvae_loss_pack), DVAE_OP(dvae_loss_finalize), DVAE_OP(dvae_loss_epilogue), DVAE_OP(dvae_set_coef), DVAE_OP(dvae_add),
+    DVAE_OP(dvae_axpby), DVAE_OP(dvae_swap_outer),
     DVAE_OP(dvae_stream_order), DVAE_OP(dvae_event_record), DVAE_OP(dvae_event_wait), DVAE_OP(dvae_comm_allreduce), DVAE_OP(dvae_comm_allgather), DVAE_OP(dvae_comm_reducescatter),
     DVAE_OP(dvae_comm_broadcast), DVAE_OP(dvae_comm_group_start), DVAE_OP(dvae_comm_group_end),
 };

@@ -88,6 +88,8 @@ SIGNATURES = {
     "dvae_comm_group_start": [],
     "dvae_comm_group_end": [],
     "dvae_add": [_p, _p, _p, _l, _p],
+    "dvae_axpby": [_p, _p, ctypes.c_float, _p, ctypes.c_float, _l, _p],
+    "dvae_swap_outer": [_p, _p, _i, _i, _l, _p],
     "dvae_stream_order": [_p, _p],
     "dvae_event_record": [_i, _p],
     "dvae_event_wait": [_i, _p],

@@ -20,6 +20,7 @@ from .._lib import call, ptr, record_on_stream, record_py
 from ..utils.math import log_importance_weights
 from .discriminator import Discriminator
 from ..graph import StepGraphs
+from ..parallel import scale_, copy_flat_
 from .._debug import knob
 
 LOSSES = ["VAE", "betaH", "betaB", "factor", "btcvae"]  # losses.py:17
@@ -73,7 +74,6 @@ class _Scratch:
         self.packed = f(_lib.NPACK)
         self.partials = f(_lib.REC_NPART)
         self.kl_dim = f(_lib.KL_FLOATS)   # DVAE_KL_FLOATS: per-dim KL + per-workgroup partial blocks
-        self.scal_ready = None            # event: the (all-reduced) loss scalars of the step are final (sharded batches)
         self.disc_sums = f(4)
         self.log_w = f(4)
         self._log_w_key = None
@@ -195,17 +195,6 @@ class BaseLoss(abc.ABC):
         if self._scratch is None or self._scratch.device != device:
             self._scratch = _Scratch(device)
         return self._scratch
-
-    @staticmethod
-    def _mark_scalars(sc):
-        """(sharded batches, on the side stream) the all-reduced loss scalars are final from here on."""
-        if sc.scal_ready is None:
-            sc.scal_ready = torch.cuda.Event()
-        record_py(sc.scal_ready.record, torch.cuda.current_stream())
-
-    @staticmethod
-    def _wait_scalars(sc):
-        record_py(torch.cuda.current_stream().wait_event, sc.scal_ready)
 
     def _rec_code(self):
         if self.rec_dist not in _lib.REC:
@@ -434,28 +423,27 @@ class _SingleOptimizerLoss(BaseLoss):
         # the FC core in one launch: lin1 -> lin2 -> mu_logvar -> reparameterise (+ KL partial blocks) -> lin1 -> lin2 -> lin3
         eng.fc_chain_fwd(buf, eps, sc.kl_dim, B)
         klb = eng.kl_blocks(B)            # single process: the one-launch loss epilogue finishes the KL partials
-        if world > 1:
-            call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, s)
-        rowstats = None
-        dz_x = dmu_x = dlv_x = None
-        if self.KIND == _lib.LOSS_BTCVAE:
-            # the B x B estimator (forward AND backward: it needs z, mu, logvar and the coefficients only)
-            # runs on the side stream while the decoder forward occupies the current one
+        lat = {"rowstats": None, "dz": None, "dmu": None, "dlv": None}
+        btc = self.KIND == _lib.LOSS_BTCVAE
+
+        def estimator():
+            # the B x B estimator (forward AND backward: it needs z, mu, logvar and the coefficients only) on the side stream
+            # while the decoder forward occupies the current one
             ew, er = self._est_world()            # the estimator's view of the sharding (local mode: one shard = one batch)
             Be = B * ew
-            eng.fork_side()
             with torch.cuda.stream(eng.side_stream):
                 ss = _stream()
                 zg, mug, lvg = buf.z, buf.mu, buf.logvar
                 if ew > 1:
                     zg, mug, lvg = self.comm.all_gather_latents(buf.z, buf.mu, buf.logvar)
-                rowstats = sc.latent("rowstats", B, _lib.ROWSTATS)
+                rowstats = lat["rowstats"] = sc.latent("rowstats", B, _lib.ROWSTATS)
                 tc_tmp = sc.latent("tc_tmp", 3 * D, Be)
                 call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Be, D, er * B, B, int(self.is_mss), ptr(sc.log_w),
                      ptr(tc_tmp), ptr(rowstats), ss)
                 if is_train:
                     dz_x = sc.latent("dz_tc", B, D)
-                    dmu_all, dlv_all = sc.latent("dmu_all", Be, D), sc.latent("dlv_all", Be, D)
+                    cols = sc.latent("dcols_all", 2 * Be, D)         # (dmu, dlogvar) of ALL columns: two slabs of one buffer
+                    dmu_all, dlv_all = cols[:Be], cols[Be:]
                     call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Be, D, er * B, B,
                          int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(tc_tmp), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), ss)
                     if ew > 1:
@@ -464,34 +452,48 @@ class _SingleOptimizerLoss(BaseLoss):
                         dmu_x, dlv_x = dmu_all, dlv_all
                     if world > ew:                # local estimator: its mean runs over B, the loss over B * world
                         for t_ in (dz_x, dmu_x, dlv_x):
-                            record_on_stream(t_.mul_, 1.0 / world)
+                            scale_(t_, 1.0 / world)
+                    lat["dz"], lat["dmu"], lat["dlv"] = dz_x, dmu_x, dlv_x
+
+        fuse = (data, self._rec_code(), sc.coef, sc.partials)
+        if btc:
+            eng.fork_side()
+        if btc and world == 1:
+            estimator()
         # decoder convT stack; its last layer also evaluates the reconstruction likelihood and dL/dlogit
-        eng.decode_convs(buf, B, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
-        # Single-process btcvae training: nothing on this stream needs the estimator (or the scalar loss) before the FC chain's
-        # input gradients, a whole convT backward later -- the estimator's backward kernels run past the end of the decoder
-        # forward, and joining here left this stream idle for ~20 us plus the epilogue (profiles/r04_v35_btcvae_celeba_timeline.md).
-        # The epilogue goes to the side stream behind them, an event slot marks the lot, fc_chain() waits for the slot.
-        late_join = (self.KIND == _lib.LOSS_BTCVAE and world == 1 and is_train and not eng.single_stream
-                     and knob("DVAE_LATE_JOIN", "1") != "0")
-        if self.KIND == _lib.LOSS_BTCVAE and not late_join:
+        eng.decode_convs(buf, B, fuse_loss=fuse)
+        if btc and world > 1:
+            # sharded: this stream's launches are issued FIRST -- the exchanges make the side stream's part long to issue, and
+            # at a hundred images per GPU the host is what the critical path would wait for
+            estimator()
+        rowstats = lat["rowstats"]
+        # Nothing on this stream needs the estimator (or the scalar loss) before the FC chain's input gradients, a whole convT
+        # backward later -- the estimator's backward kernels run past the end of the decoder forward, and joining here left
+        # this stream idle for ~20 us plus the epilogue (profiles/r04_v35_btcvae_celeba_timeline.md).  The epilogue goes to the
+        # side stream behind them, an event slot marks the lot, fc_chain() waits for the slot.  Sharded batches (any loss):
+        # the all-reduce of the packed loss sums sits between the two halves of the epilogue, on the side stream as well.
+        late_join = (is_train and not eng.single_stream and (btc or world > 1) and knob("DVAE_LATE_JOIN", "1") != "0")
+        if btc and not late_join:
             eng._join_side()
         if late_join:
             def epilogue():                       # after the next fork (the backward pass's first): no fork of its own
-                call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), B, None, Bg,
-                     ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), eng._side_raw())
-                call("dvae_event_record", self._ev_slot, eng._side_raw())
+                ss = eng._side_raw()
+                if world == 1:
+                    call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), B, None, Bg,
+                         ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), ss)
+                else:
+                    call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, ss)
+                    call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), ss)
+                    with torch.cuda.stream(eng.side_stream):
+                        self.comm.all_reduce(sc.packed)
+                    call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), ss)
+                call("dvae_event_record", self._ev_slot, ss)
             eng.at_next_fork(epilogue)
         elif world > 1:
+            call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, s)
             call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
-            # the global loss sums are first needed by the latent glue of the backward FC chain (a whole convT backward
-            # later): their all-reduce and the scalar epilogue leave the critical path; an event marks them final
-            eng.fork_side()
-            with torch.cuda.stream(eng.side_stream):
-                self.comm.all_reduce(sc.packed)
-                call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), _stream())
-                self._mark_scalars(sc)
-            if not is_train:
-                eng._join_side()
+            self.comm.all_reduce(sc.packed)
+            call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), s)
         else:
             call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), B, None, Bg,
                  ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), s)
@@ -499,19 +501,20 @@ class _SingleOptimizerLoss(BaseLoss):
             return
 
         def fc_chain():        # the six FC input gradients + the reparameterisation / KL backward in ONE launch
-            if world > 1:
-                self._wait_scalars(sc)
             if late_join:
                 eng.flush_fork_hook()
                 call("dvae_event_wait", self._ev_slot, s)
-            eng.fc_chain_bwd(buf, eps, dz_x, None, dmu_x, dlv_x, sc.scal, sc.coef, B)
+            eng.fc_chain_bwd(buf, eps, lat["dz"], None, lat["dmu"], lat["dlv"], sc.scal, sc.coef, B)
 
-        # single process: one join, at the end of the backward pass, and ONE grouped launch for all six FC weight
-        # gradients (issued by encode_backward); sharded: the decoder's gradients are all-reduced early, so they are final here
-        eng.decode_backward(buf.z, buf, join=world > 1, defer_fc_wgrad=world == 1, fc_chain=fc_chain)
+        # one join, at the end of the backward pass.  Single process: ONE grouped launch for all six FC weight gradients
+        # (issued by encode_backward).  Sharded: the decoder's three are launched with the decoder's conv weight gradients --
+        # every kernel that writes a decoder gradient goes to the side stream, so the all-reduce of the decoder span is ordered
+        # behind the SIDE stream and overlaps the encoder backward; this stream never waits for it before the end
+        eng.decode_backward(buf.z, buf, join=False, defer_fc_wgrad=world == 1, fc_chain=fc_chain)
         pending = []
-        if world > 1:      # decoder gradients are final: their all-reduce overlaps the encoder backward
-            pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
+        if world > 1:
+            with torch.cuda.stream(eng.side_stream):
+                pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
         eng.encode_backward(data, buf, fc_chain=True)
         if world > 1:
             pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))
@@ -698,13 +701,11 @@ class FactorKLoss(BaseLoss):
         # decoder only for data1
         eng.fc_chain_fwd(buf, eps12, sc.kl_dim, 2 * Bh, n_kl=Bh, n_dec=Bh)
         klb = eng.kl_blocks(2 * Bh)
-        if world > 1:
-            call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, s)
         eng.decode_convs(buf, Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         off = Bh
         # z_perm: permute across the (global) half batch, losses.py:287
         zin = sc.latent("disc_in", 2 * Bh, D)
-        record_py(zin[:Bh].copy_, buf.z[:Bh])
+        copy_flat_(zin[:Bh], buf.z[:Bh])
         z2 = buf.z[off:off + Bh]
         ew, er = self._est_world()                # scope of permute_dims: global half batch, or this shard ("local")
         if ew > 1:
@@ -713,36 +714,38 @@ class FactorKLoss(BaseLoss):
             z2g = z2
         zperm_g = sc.latent("zperm_g", Bh * ew, D)
         call("dvae_permute_dims", ptr(z2g.contiguous()), ptr(perms), ptr(zperm_g), Bh * ew, D, s)
-        record_py(zin[Bh:].copy_, zperm_g[er * Bh:(er + 1) * Bh])
+        copy_flat_(zin[Bh:], zperm_g[er * Bh:(er + 1) * Bh])
         logits = disc.forward_raw(zin, 2 * Bh)                        # D(z1) and D(z_perm) in one pass
         g_dtc = sc.latent("g_dtc", 2 * Bh, 2)
         g_tc = sc.latent("g_tc", Bh, 2)
         call("dvae_disc_losses", ptr(logits), Bh, ptr(sc.coef), ptr(sc.disc_sums), ptr(g_dtc), ptr(g_tc), s)
         if world > 1:
             # the CE / tc means run over the global half batch
-            record_on_stream(g_dtc.mul_, 1.0 / world)
-            record_on_stream(g_tc.mul_, 1.0 / world)
-        if world > 1:          # off the critical path: first consumer is reparam_kl_bwd, after decode_backward's join
-            call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), s)
-            eng.fork_side()
-            with torch.cuda.stream(eng.side_stream):
-                self.comm.all_reduce(sc.packed)
-                call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), _stream())
-                self._mark_scalars(sc)
-        late_epi = world == 1 and not eng.single_stream and knob("DVAE_LATE_JOIN", "1") != "0"
-        if world == 1:
-            # the scalar epilogue (13 us) is first needed by the FC chain's input gradients, after the discriminator's and the
-            # decoder's backward passes: it runs on the side stream, an event slot marks it (as in the btcvae step)
-            def epilogue(stream):
+            scale_(g_dtc, 1.0 / world)
+            scale_(g_tc, 1.0 / world)
+
+        # the scalar epilogue (13 us; sharded: KL finish + pack + all-reduce of the packed sums + finalize) is first needed by
+        # the FC chain's input gradients, after the discriminator's and the decoder's backward passes: it runs on the side
+        # stream, an event slot marks it (as in the btcvae step)
+        def epilogue(on_side):
+            stream = eng._side_raw() if on_side else s
+            if world == 1:
                 call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), klb, D, None, 0,
                      ptr(sc.disc_sums), Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), stream)
-            if late_epi:                          # after the next fork (the backward pass's first): no fork of its own
-                def deferred():
-                    epilogue(eng._side_raw())
-                    call("dvae_event_record", self._ev_slot, eng._side_raw())
-                eng.at_next_fork(deferred)
-            else:
-                epilogue(s)
+                return
+            call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, stream)
+            call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), stream)
+            with torch.cuda.stream(eng.side_stream if on_side else torch.cuda.current_stream()):
+                self.comm.all_reduce(sc.packed)
+            call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), stream)
+        late_epi = not eng.single_stream and knob("DVAE_LATE_JOIN", "1") != "0"
+        if late_epi:                          # after the next fork (the backward pass's first): no fork of its own
+            def deferred():
+                epilogue(True)
+                call("dvae_event_record", self._ev_slot, eng._side_raw())
+            eng.at_next_fork(deferred)
+        else:
+            epilogue(False)
         # discriminator backward of d_tc_loss (weight grads + dz), losses.py:303-304
         dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
         pending = []
@@ -753,16 +756,17 @@ class FactorKLoss(BaseLoss):
 
         def fc_chain():
             # dz_a: quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1); dz_b: the tc term through D
-            if world > 1:
-                self._wait_scalars(sc)
             if late_epi:
                 eng.flush_fork_hook()
                 call("dvae_event_wait", self._ev_slot, s)
             eng.fc_chain_bwd(buf, eps1, dz_a, dz_b, None, None, sc.scal, sc.coef, Bh)
 
-        eng.decode_backward(buf.z, buf, n=Bh, join=world > 1, defer_fc_wgrad=world == 1, fc_chain=fc_chain)   # single process: joined at the end of encode_backward
-        if world > 1:      # decoder gradients are final: overlapped with the encoder backward
-            pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
+        # one join, at the end of encode_backward; sharded: the decoder span's all-reduce is ordered behind the side stream
+        # (every decoder gradient is written there) and overlaps the encoder backward
+        eng.decode_backward(buf.z, buf, n=Bh, join=False, defer_fc_wgrad=world == 1, fc_chain=fc_chain)
+        if world > 1:
+            with torch.cuda.stream(eng.side_stream):
+                pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
         eng.encode_backward(data, buf, n=Bh, fc_chain=True)
         if world > 1:
             pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))

@@ -17,7 +17,8 @@ Two transports with the same interface:
   * ``Comm``      -- torch.distributed collectives (backend "nccl" == RCCL over xGMI on ROCm; "gloo" for CPU tests);
   * ``RcclComm``  -- the collectives of libdvae_hip.so's C-ABI (``dvae_comm_*``: RCCL enqueued on the caller's HIP
                      stream, no torch types in the data path); torch.distributed is then only the rendezvous that ships
-                     the 128-byte RCCL unique id.  Select with ``data_parallel(..., transport="rccl")`` / DVAE_COMM=rccl.
+                     the 128-byte RCCL unique id.  The default on GPU process groups (``transport="auto"``, verified
+                     with a round trip); ``data_parallel(..., transport="torch")`` / DVAE_COMM=torch selects the other.
 Gather / scatter buffers are allocated once per shape and reused.
 """
 import ctypes
@@ -33,6 +34,45 @@ from ._lib import call, ptr, record_on_stream
 class _Done:
     def wait(self):
         return None
+
+
+def _raw_stream():
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+# Element-wise glue around the collectives.  Device tensors go through the C-ABI (dvae_axpby / dvae_swap_outer): one foreign
+# call that lands in a recorded launch plan's C segment -- a torch op costs the host 10-20 us per replay (stream guard +
+# dispatch), which at 128 images per GPU is what the step is bound by.  CPU tensors (the gloo tests) use torch.
+def scale_(t, alpha):
+    """t *= alpha."""
+    if t.is_cuda:
+        call("dvae_axpby", ptr(t), ptr(t), float(alpha), None, 0.0, t.numel(), _raw_stream())
+    else:
+        record_on_stream(t.mul_, float(alpha))
+
+
+def add_scaled_(out, b, beta):
+    """out += beta * b (same number of elements, both contiguous)."""
+    if out.is_cuda:
+        call("dvae_axpby", ptr(out), ptr(out), 1.0, ptr(b), float(beta), out.numel(), _raw_stream())
+    else:
+        record_on_stream(lambda: out.view(-1).add_(b.reshape(-1), alpha=float(beta)))
+
+
+def copy_flat_(out, src):
+    """out <- src (same number of elements, both contiguous)."""
+    if out.is_cuda:
+        call("dvae_axpby", ptr(out), ptr(src), 1.0, None, 0.0, out.numel(), _raw_stream())
+    else:
+        record_on_stream(lambda: out.view(-1).copy_(src.reshape(-1)))
+
+
+def swap_outer_(dst, src, A, Bn, inner):
+    """dst [Bn][A][inner] <- src [A][Bn][inner] (contiguous buffers)."""
+    if dst.is_cuda:
+        call("dvae_swap_outer", ptr(src), ptr(dst), A, Bn, inner, _raw_stream())
+    else:
+        record_on_stream(lambda: dst.view(Bn, A, inner).copy_(src.reshape(A, Bn, inner).permute(1, 0, 2)))
 
 
 class Comm:
@@ -127,7 +167,7 @@ class Comm:
         recv = self._buf("lat_recv", (self.world_size, 3, B, D), z)
         self.all_gather_into(recv, send)
         glob = self._buf("lat_glob", (3, self.world_size * B, D), z)
-        record_on_stream(glob.view(3, self.world_size, B, D).copy_, recv.permute(1, 0, 2, 3))
+        swap_outer_(glob, recv, self.world_size, 3, B * D)
         return glob[0], glob[1], glob[2]
 
     def reduce_scatter_cols(self, dmu_all, dlv_all):
@@ -137,7 +177,12 @@ class Comm:
         B = dmu_all.shape[0] // W
         D = dmu_all.shape[1]
         send = self._buf("cols_send", (W, 2, B, D), dmu_all)
-        record_on_stream(lambda: torch.stack((dmu_all.reshape(W, B, D), dlv_all.reshape(W, B, D)), dim=1, out=send))
+        if (dmu_all.is_contiguous() and dlv_all.is_contiguous()
+                and dlv_all.data_ptr() == dmu_all.data_ptr() + dmu_all.numel() * dmu_all.element_size()
+                and dmu_all.untyped_storage().data_ptr() == dlv_all.untyped_storage().data_ptr()):
+            swap_outer_(send, dmu_all, 2, W, B * D)     # the pair are consecutive slabs of one buffer = [2][W][B*D]
+        else:
+            record_on_stream(lambda: torch.stack((dmu_all.reshape(W, B, D), dlv_all.reshape(W, B, D)), dim=1, out=send))
         out = self._buf("cols_loc", (2, B, D), dmu_all)
         self.reduce_scatter_into(out, send)
         return out[0], out[1]
@@ -186,14 +231,14 @@ class RcclComm(Comm):
 
     def all_reduce_async(self, t):
         """The collective goes to a communication stream forked from the current one; wait() joins it back."""
-        cur = torch.cuda.current_stream()
-        _lib.record_py(self._side.wait_stream, cur)
-        call("dvae_comm_allreduce", self._h, ptr(t), t.numel(), self._side.cuda_stream)
-        side = self._side
+        side = self._side.cuda_stream
+        call("dvae_stream_order", self._s(), side)
+        call("dvae_comm_allreduce", self._h, ptr(t), t.numel(), side)
+        s_ = self._s
 
         class _Handle:
             def wait(self_inner):
-                _lib.record_py(torch.cuda.current_stream().wait_stream, side)
+                call("dvae_stream_order", side, s_())
 
         return _Handle()
 
@@ -213,6 +258,14 @@ class RcclComm(Comm):
     def group_end(self):
         call("dvae_comm_group_end")
 
+    def self_test(self):
+        """One round trip through the communicator: a sum-all-reduce of ones must come back as world_size."""
+        t = torch.ones(64, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+        self.all_reduce(t)
+        torch.cuda.synchronize()
+        if not bool((t == float(self.world_size)).all()):
+            raise _lib.DvaeHipError("dvae_comm self test: all-reduce of ones returned %r" % t[:4].tolist())
+
     def close(self):
         if getattr(self, "_h", None):
             torch.cuda.synchronize()
@@ -225,7 +278,8 @@ class MirroredWorldComm(Comm):
     hold IDENTICAL shards (same images, same noise).  Every collective first runs through the wrapped one-rank communicator
     `inner` (``Comm`` or ``RcclComm``: the real call sites, RCCL launches and stream ordering of the data-parallel step) and is
     then completed with what the absent peers would have contributed: all-gather -> the shard replicated `world_size`
-    times, sum-all-reduce / reduce-scatter -> `world_size` x the local term.  The loss plugins then run the whole sharded
+    times, sum-all-reduce -> `world_size` x the local term, reduce-scatter -> the local chunk + (`world_size` - 1) x a
+    peer-bound chunk.  The loss plugins then run the whole sharded
     code path at the shard's real sizes (B local rows of a world_size * B column estimator, packed exchanges, two gradient
     spans) on ONE GPU: ``bench.py``'s shard legs time it, ``tests/test_gpu_ddp.py`` holds it to the single-process step on
     the shard tiled `world_size` times (exact for every term that is symmetric in the ranks: everything except the
@@ -244,29 +298,36 @@ class MirroredWorldComm(Comm):
 
     def all_reduce(self, t):
         self.inner.all_reduce(t)
-        record_on_stream(t.mul_, float(self.world_size))
+        scale_(t, self.world_size)
         return t
 
     def all_reduce_async(self, t):
         h = self.inner.all_reduce_async(t)
-        W = float(self.world_size)
+        W = self.world_size
 
         class _Handle:
             def wait(self_inner):
                 h.wait()
-                record_on_stream(t.mul_, W)
+                scale_(t, W)
 
         return _Handle()
 
     def all_gather_into(self, out, t):
         rows = out.view(self.world_size, -1)
         self.inner.all_gather_into(rows[0], t)
-        if self.world_size > 1:
-            record_on_stream(rows[1:].copy_, rows[0:1].expand(self.world_size - 1, -1))
+        k = 1
+        while k < self.world_size:               # replicate by doubling: log2(world) copies
+            m = min(k, self.world_size - k)
+            copy_flat_(rows[k:k + m], rows[0:m])
+            k += m
 
     def reduce_scatter_into(self, out, t):
-        self.inner.reduce_scatter_into(out, t.view(self.world_size, -1)[self.rank])
-        record_on_stream(out.mul_, float(self.world_size))
+        # this rank's chunk of its OWN send buffer carries terms no peer holds (the row-role gradients of its rows); every
+        # peer's contribution to the chunk equals what this rank sends to a peer's chunk
+        chunks = t.view(self.world_size, -1)
+        self.inner.reduce_scatter_into(out, chunks[self.rank])
+        if self.world_size > 1:
+            add_scaled_(out, chunks[(self.rank + 1) % self.world_size], self.world_size - 1)
 
     def broadcast(self, t, src=0):
         return self.inner.broadcast(t, src=0)
@@ -292,6 +353,31 @@ def init_process_group_from_env(backend=None):
     dist.init_process_group(backend=backend)
 
 
+def _auto_comm(group):
+    """RcclComm where it demonstrably works on every rank, else Comm (see data_parallel)."""
+    if not torch.cuda.is_available() or dist.get_backend(group) != "nccl":
+        return Comm(group)
+    comm, err = None, None
+    try:
+        comm = RcclComm(group)
+        comm.self_test()
+    except Exception as e:       # noqa: a missing librccl symbol, a failed ncclCommInitRank, a wrong sum
+        err = e
+    flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 1:
+        return comm
+    import warnings
+    warnings.warn("disvae_amd.parallel: the C-ABI RCCL transport failed its round trip on at least one rank (%s): every rank "
+                  "falls back to torch.distributed collectives" % (err if err is not None else "another rank"), RuntimeWarning)
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:   # noqa
+            pass
+    return Comm(group)
+
+
 def data_parallel(model, loss_f, group=None, estimator="global", transport=None, comm=None):
     """Attach a communicator to a native loss plugin (and make every rank start from rank 0's
     weights).  After this, ``loss_f.fused_step`` / ``call_optimize`` treat their input as this
@@ -303,15 +389,20 @@ def data_parallel(model, loss_f, group=None, estimator="global", transport=None,
     reduce-scatter and B x (world B) estimator work per rank.  "local": over each rank's shard -- what the
     reference computes under DistributedDataParallel (gradient all-reduce only); a different estimator.
 
-    transport: "torch" (default; torch.distributed collectives, nccl == RCCL) or "rccl" (the C-ABI's dvae_comm_*);
-    DVAE_COMM overrides the default.  comm: a ready communicator object (tests)."""
+    transport: "rccl" (the C-ABI's dvae_comm_*: every collective is an entry of the recorded launch plan, no Python
+    between the launches of a step), "torch" (torch.distributed collectives, nccl == RCCL) or "auto" (default; DVAE_COMM
+    overrides): "rccl" where the process group runs on GPUs, after a verified round trip on EVERY rank -- one rank's failure
+    sends all of them to "torch" with a warning; "torch" on CPU groups (gloo).  comm: a ready communicator object (tests)."""
     if estimator not in ("global", "local"):
         raise ValueError("estimator must be 'global' or 'local'")
     if comm is None:
-        transport = transport or os.environ.get("DVAE_COMM", "torch")
-        if transport not in ("torch", "rccl"):
-            raise ValueError("transport must be 'torch' or 'rccl', got %r" % (transport,))
-        comm = RcclComm(group) if transport == "rccl" else Comm(group)
+        transport = transport or os.environ.get("DVAE_COMM", "auto")
+        if transport not in ("torch", "rccl", "auto"):
+            raise ValueError("transport must be 'auto', 'torch' or 'rccl', got %r" % (transport,))
+        if transport == "auto":
+            comm = _auto_comm(group)
+        else:
+            comm = RcclComm(group) if transport == "rccl" else Comm(group)
     loss_f.comm = comm
     loss_f.estimator = estimator
     comm.broadcast(model.arena.flat)

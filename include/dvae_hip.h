@@ -352,6 +352,16 @@ int dvae_set_coef(float* coef, float c0, float c1, float c2, float c3, float c4,
 /* out[i] = a[i] + b[i] (n elements), helper for merging latent gradients (quirk Q1).       */
 int dvae_add(const float* a, const float* b, float* out, long n, void* stream);
 
+/* ---- glue of the data-parallel step (new: the reference is single-process; disvae_amd/parallel.py) -------------------
+ * out[i] = alpha * a[i] + beta * b[i] (b may be NULL: out = alpha * a; out may alias a or b): the 1 / world factors of means
+ * over the global batch.                                                                                              */
+int dvae_axpby(float* out, const float* a, float alpha, const float* b, float beta, long n, void* stream);
+/* dst[j][i][:] = src[i][j][:] for src [A][Bn][inner] floats: the packed exchanges of the sharded beta-TCVAE step -- an
+ * all-gather of every rank's (z, mu, logvar) delivers [world][3][B*D] where the estimator (losses.py:523-544 over the
+ * GLOBAL batch) reads three [world*B, D] tensors; its column gradients (dmu, dlogvar) [2][world][B*D] leave through a
+ * reduce-scatter as [world][2][B*D].                                                                                  */
+int dvae_swap_outer(const float* src, float* dst, int A, int Bn, long inner, void* stream);
+
 /* ---- stream ordering (new; the reference is one stream of ATen ops) -----------------------------------------------
  * Work enqueued on `later` after this call runs after everything enqueued on `earlier` before it (both hipStream_t of the
  * current device).  The native training step issues its weight-gradient kernels on a second stream beside the chain of

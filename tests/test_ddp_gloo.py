@@ -141,7 +141,8 @@ def _worker_mirrored(port, q):
             a = torch.arange(W * B * D, dtype=torch.float32).view(-1, D)
             da, db = comm.reduce_scatter_cols(a, 2 * a)
             sl = slice(rank * B, (rank + 1) * B)
-            assert torch.equal(da, W * a[sl]) and torch.equal(db, 2 * W * a[sl])
+            nx = slice(((rank + 1) % W) * B, ((rank + 1) % W + 1) * B)      # what this rank sends to a peer = what a peer sends here
+            assert torch.equal(da, a[sl] + (W - 1) * a[nx]) and torch.equal(db, 2 * (a[sl] + (W - 1) * a[nx]))
             t = comm.all_reduce(torch.ones(6))
             assert (t == W).all()
             u = torch.full((5,), 3.0)

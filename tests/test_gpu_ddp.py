@@ -292,16 +292,43 @@ def _worker_mirrored(port, loss, q, transport, replay, world_emulated, Bl):
         assert comm.world_size == W and l1._world() == (W, 0)
         g_data, g_eps = shard.repeat(W, 1, 1, 1).cuda(), eps.repeat(W, 1).cuda()
         l_data, l_eps = shard.cuda(), eps.cuda()
+        if loss == "factor":
+            # FactorVAE's global permutation is not symmetric in the ranks: no tiled single-process twin.  The sharded
+            # two-optimizer step (z2 all-gather, discriminator arena all-reduced under the VAE backward, late epilogue) must
+            # run, replay and stay finite and deterministic: two mirrored models fed the same noise agree bit for bit
+            m2, o2, l2 = _make(loss, 1e-4)
+            l2.replay = None
+            m1, o1, l1 = _make(loss, 1e-4)
+            l1.replay = replay
+            comm2 = parallel.data_parallel(m2, l2, comm=parallel.MirroredWorldComm(inner, W, 0))
+            comm = parallel.data_parallel(m1, l1, comm=parallel.MirroredWorldComm(inner, W, 0))
+            h = Bl // 2
+            noise = (torch.randn(h, D, generator=gen).cuda(), torch.randn(h, D, generator=gen).cuda(),
+                     torch.stack([torch.randperm(h * W, generator=gen) for _ in range(D)]))
+            for it in range(4 if replay else 1):
+                out2 = l2.call_optimize(l_data, m2, o2, defaultdict(list), noise=noise)
+                out1 = l1.call_optimize(l_data, m1, o1, defaultdict(list), noise=noise)
+                assert torch.isfinite(out1).all() and torch.isfinite(m1.arena.grad).all()
+                assert out1.item() == out2.item(), (it, out1.item(), out2.item())
+                assert torch.equal(m1.arena.grad, m2.arena.grad) and torch.equal(l1.discriminator.arena.grad, l2.discriminator.arena.grad)
+            if replay:
+                assert l1._graphs.replays >= 2, l1._graphs.replays
+            comm.close()
+            q.put((0, "ok"))
+            return
         for it in range(4 if replay else 1):
             st = defaultdict(list)
+            # every iteration starts from the twin's weights: the comparison stays a one-step one (two Adam trajectories drift
+            # apart at 1e-4 of max|g| within three steps, which would hide a replay that is off by that much)
+            m1.arena.flat.copy_(m0.arena.flat)
             out0 = l0.fused_step(g_data, m0, o0, defaultdict(list), eps=g_eps)
             out1 = l1.fused_step(l_data, m1, o1, st, eps=l_eps)
             ref_loss = out0.item()
             err = ((m1.arena.grad - m0.arena.grad).abs().max() / m0.arena.grad.abs().max()).item()
-            assert err < 2e-5 * (it + 1), "iteration %d: grad err %.3e" % (it, err)
-            assert abs(out1.item() - ref_loss) <= 2e-6 * (it + 1) * abs(ref_loss), (it, out1.item(), ref_loss)
-            assert (m1.arena.flat - m0.arena.flat).abs().max().item() <= 2.5 * lr * (it + 1)
+            assert err < 2e-5, "iteration %d: grad err %.3e" % (it, err)
+            assert abs(out1.item() - ref_loss) <= 2e-6 * abs(ref_loss), (it, out1.item(), ref_loss)
             if it == 0:
+                assert (m1.arena.flat - m0.arena.flat).abs().max().item() <= 2.5 * lr
                 assert st["loss"] and abs(st["loss"][0] - ref_loss) <= 2e-6 * abs(ref_loss)
         if replay:
             assert l1._graphs.replays >= 2, l1._graphs.replays
@@ -319,7 +346,7 @@ def _worker_mirrored(port, loss, q, transport, replay, world_emulated, Bl):
 
 @pytest.mark.parametrize("replay", [None, "plan"])
 @pytest.mark.parametrize("transport", ["torch", "rccl"])
-@pytest.mark.parametrize("loss,world_emulated,Bl", [("btcvae", 8, 16), ("VAE", 4, 12)])
+@pytest.mark.parametrize("loss,world_emulated,Bl", [("btcvae", 8, 16), ("VAE", 4, 12), ("factor", 4, 16)])
 def test_mirrored_world_runs_the_sharded_path_on_one_gpu(loss, world_emulated, Bl, transport, replay):
     """The data-parallel step at world_size > 1 through RCCL on the ONE GPU of the test box (see _worker_mirrored); with
     replay="plan" iterations 3 and 4 are replays of the recorded sharded launch plan, NCCL collectives included."""
