@@ -618,6 +618,19 @@ def settle_rounds(step_fn, max_rounds=12, tol=0.015, min_round_ms=40.0):
     return rounds
 
 
+def host_issue_ms(step_fn, n=30):
+    """Host time to ISSUE one iteration (the GPU idle at the start, no synchronisation inside): when this exceeds the GPU's
+    time per step the iteration is bound by the host, whatever the kernels do.  Median of n."""
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step_fn()
+        ts.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    return sorted(ts)[len(ts) // 2] * 1e3
+
+
 def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single", "torch", "rccl")):
     """BASELINE configs[3] as ONE of its eight ranks runs it, on this one GPU: 128 images per step through the SHARDED code
     path of the btcvae step (disvae_amd.parallel: packed latent all-gather, the rank's 128 rows of the 1024-column B x B
@@ -670,12 +683,14 @@ def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         final = float(loss.item())
+        host = host_issue_ms(lambda: trainer._train_iteration_async(data, storer))
         if comm is not None:
             comm.close()
         tf = flops / (ms * 1e-3) / 1e12
         return {"ms_per_step": round(ms, 4), "value": round(B / (ms * 1e-3), 1), "step_tflops": round(tf, 2),
                 "step_frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "final_loss": round(final, 4),
-                "replay": loss_f._replay_mode(True, data) or "eager", "settle_ms_per_step": [round(x, 4) for x in rounds]}
+                "replay": loss_f._replay_mode(True, data) or "eager", "host_issue_ms_per_step": round(host, 4),
+                "settle_ms_per_step": [round(x, 4) for x in rounds]}
 
     mark("configs:shard:single")
     if "single" in which:
@@ -899,6 +914,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    host_ms = host_issue_ms(lambda: trainer._train_iteration_async(data, storer), n=20) if not ddp else None
 
     def flush_c_stdio():
         # RCCL in this image prints a banner ("Hostname", "Librccl path") through C stdio, block-buffered on a pipe:
@@ -945,6 +961,7 @@ def main():
                                           "iterations" % nseg},
         "step_tflops": round(step_tf, 2),
         "step_frac_of_fp32_peak": round(step_tf / world / PEAK_FP32_MFMA_TFLOPS, 4),
+        "host_issue_ms_per_step": None if host_ms is None else round(host_ms, 4),
         "settle": {"untimed_steps_before_warmup": 20 if ddp else 5 * len(settle), "ms_per_step_rounds_of_5": [round(x, 4) for x in settle]},
     }
     if parity is not None:

@@ -397,6 +397,8 @@ int dvae_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, void* stream) {
   return launch_fc_chain_fwd(a, (hipStream_t)stream);
 }
 
+int dvae_fc_chain_rows(int n) { return fc_chain_rows(n); }
+
 int dvae_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, void* stream) {
   DVAE_CHECK_ARG(a && a->gd3 && a->w_d3 && a->w_d2 && a->w_d1 && a->w_ml && a->w_e2 && a->w_e1);
   DVAE_CHECK_ARG(a->d2 && a->d1 && a->h2 && a->h1 && a->a_flat && a->mu && a->logvar && a->scal && a->coef);
@@ -482,13 +484,21 @@ int dvae_add(const float* a, const float* b, float* out, long n, void* stream) {
   return launch_add(a, b, out, n, (hipStream_t)stream);
 }
 
+int dvae_adam_step(const dvae_adam_tensor* tensors, int nt, float step_new, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, void* stream) {
+  DVAE_CHECK_ARG(tensors && nt > 0 && step_new >= 1.f && lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1.);
+  DVAE_CHECK_ARG(eps >= 0. && weight_decay >= 0.);
+  for (int i = 0; i < nt; ++i) DVAE_CHECK_ARG(tensors[i].p && tensors[i].g && tensors[i].m && tensors[i].v && tensors[i].n >= 0);
+  return launch_adam(tensors, nt, step_new, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream);
+}
+
 int dvae_axpby(float* out, const float* a, float alpha, const float* b, float beta, long n, void* stream) {
   DVAE_CHECK_ARG(out && a && n > 0);
   return launch_axpby(out, a, alpha, b, beta, n, (hipStream_t)stream);
 }
 
 int dvae_swap_outer(const float* src, float* dst, int A, int Bn, long inner, void* stream) {
-  DVAE_CHECK_ARG(src && dst && src != dst && A > 0 && Bn > 0 && inner > 0);
+  DVAE_CHECK_ARG(src && dst && src != dst && A > 0 && Bn > 0 && inner > 0 && inner < (1L << 31) && (long)A * Bn < (1L << 31));
   return launch_swap_outer(src, dst, A, Bn, inner, (hipStream_t)stream);
 }
 

@@ -177,6 +177,7 @@ size_t latent_entropy_ws_floats(long N, int D, int S);
 int launch_latent_entropy(const float* z_ds, const float* mean, const float* logvar, long N, int D, int S, float* ws,
                           float* H, hipStream_t s);
 int launch_linear_wgrad_grouped(const dvae_linear_wgrad_desc* d, int n, hipStream_t s);
+int fc_chain_rows(int n);
 int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s);
 int launch_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, hipStream_t s);
 int reparam_kl_blocks(int B);
@@ -223,6 +224,8 @@ int launch_loss_epilogue(int kind, const float* rec_partials, const float* kl_di
                          int Bl, const float* disc_sums, int Bg, const float* coef, float* packed, float* scal,
                          hipStream_t s);
 int launch_set_coef(float* coef, const float* v, hipStream_t s);
+int launch_adam(const dvae_adam_tensor* ts, int nt, float step_new, double lr, double beta1, double beta2, double eps,
+                double weight_decay, hipStream_t s);
 int launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);
 int launch_axpby(float* out, const float* a, float alpha, const float* b, float beta, long n, hipStream_t s);
 int launch_swap_outer(const float* src, float* dst, int A, int Bn, long inner, hipStream_t s);

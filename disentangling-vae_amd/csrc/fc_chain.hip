@@ -25,7 +25,6 @@
 
 namespace dvae {
 
-#define FCC_R 8
 #define FCC_XS 516        // LDS row stride of an activation tile (floats): rows r, r+1 are 4 banks apart -> the four distinct
                           // 16-byte addresses of a broadcast ds_read_b128 never share a bank
 #define FCC_HID 256
@@ -36,18 +35,21 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
-// accumulators of one 64-column group: [row group 0-3 / 4-7][even / odd contraction step]
-struct Acc8 { f32x4 a[2][2]; };
-__device__ __forceinline__ void acc_zero(Acc8& c) {
+// accumulators of one 64-column group: [row group of 4 rows][even / odd contraction step]; RG row groups = 4 RG rows per workgroup
+template <int RG>
+struct AccR { f32x4 a[RG][2]; };
+template <int RG>
+__device__ __forceinline__ void acc_zero(AccR<RG>& c) {
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < RG; ++g)
 #pragma unroll
     for (int p = 0; p < 2; ++p) c.a[g][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
-// the lane's column, rows 0..7
-__device__ __forceinline__ void acc_rows(const Acc8& c, float (&v)[8]) {
+// the lane's column, rows 0 .. 4 RG - 1
+template <int RG>
+__device__ __forceinline__ void acc_rows(const AccR<RG>& c, float (&v)[4 * RG]) {
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < RG; ++g) {
     const f32x4 s = c.a[g][0] + c.a[g][1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[4 * g + r] = s[r];
@@ -68,26 +70,28 @@ __device__ __forceinline__ void ring_fill(Ring<DEPTH, NG>& ring, const float* __
   }
 }
 
-__device__ __forceinline__ void mac_chunk(const f32x4 a0, const f32x4 a1, const f32x4 w, Acc8& acc) {
+template <int RG>
+__device__ __forceinline__ void mac_chunk(const f32x4 (&a)[RG], const f32x4 w, AccR<RG>& acc) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    acc.a[0][j & 1] = mfma4(a0[j], w[j], acc.a[0][j & 1]);
-    acc.a[1][j & 1] = mfma4(a1[j], w[j], acc.a[1][j & 1]);
+#pragma unroll
+    for (int g = 0; g < RG; ++g) acc.a[g][j & 1] = mfma4(a[g][j], w[j], acc.a[g][j & 1]);
   }
 }
 
 // NCH chunks (4 contraction steps each) of NG column groups.  `ring` holds chunks 0..DEPTH-1 on entry; while the last DEPTH
 // chunks are consumed the first chunks of the NEXT layer's stream are requested into `nring` (NGN = 0: none), so a layer
 // boundary costs no exposed weight latency.  xr = activation tile + (lane & 3) * FCC_XS (row group 1 is 4 rows further).
-template <int DEPTH, int NCH, int NG, int NCHN, int NGN>
+template <int DEPTH, int NCH, int NG, int NCHN, int NGN, int RG>
 __device__ __forceinline__ void gemm_run(Ring<DEPTH, NG>& ring, const float* __restrict__ wp, int gstride, int cstride,
-                                         const float* xr, Acc8 (&acc)[NG], Ring<DEPTH, (NGN > 0 ? NGN : 1)>& nring,
+                                         const float* xr, AccR<RG> (&acc)[NG], Ring<DEPTH, (NGN > 0 ? NGN : 1)>& nring,
                                          const float* __restrict__ wn, int gstride_n, int cstride_n) {
   static_assert(NCH % DEPTH == 0, "chunk count must be a multiple of the ring depth");
-  // A operands one chunk ahead (register ping-pong): the LDS latency hides under the 8 MFMAs of the current chunk.  The
+  // A operands one chunk ahead (register ping-pong): the LDS latency hides under the 4 RG MFMAs of the current chunk.  The
   // read for chunk NCH lands in the tile row's padding (FCC_XS >= C + 4) and is never used.
-  f32x4 a0 = *reinterpret_cast<const f32x4*>(xr);
-  f32x4 a1 = *reinterpret_cast<const f32x4*>(xr + 4 * FCC_XS);
+  f32x4 an[RG], nn[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) an[g] = *reinterpret_cast<const f32x4*>(xr + 4 * g * FCC_XS);
   for (int c0 = 0; c0 < NCH - DEPTH; c0 += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
@@ -98,17 +102,18 @@ __device__ __forceinline__ void gemm_run(Ring<DEPTH, NG>& ring, const float* __r
         w[g] = ring.v[d][g];
         ring.v[d][g] = *reinterpret_cast<const f32x4*>(wp + g * gstride + (c + DEPTH) * cstride);
       }
-      const f32x4 n0 = *reinterpret_cast<const f32x4*>(xr + 4 * (c + 1));
-      const f32x4 n1 = *reinterpret_cast<const f32x4*>(xr + 4 * FCC_XS + 4 * (c + 1));
 #pragma unroll
-      for (int g = 0; g < NG; ++g) mac_chunk(a0, a1, w[g], acc[g]);
-      a0 = n0; a1 = n1;
+      for (int g = 0; g < RG; ++g) nn[g] = *reinterpret_cast<const f32x4*>(xr + 4 * g * FCC_XS + 4 * (c + 1));
+#pragma unroll
+      for (int g = 0; g < NG; ++g) mac_chunk<RG>(an, w[g], acc[g]);
+#pragma unroll
+      for (int g = 0; g < RG; ++g) an[g] = nn[g];
       // pin the software pipeline: the re-request of the slot just consumed stays HERE (DEPTH chunks ahead of its use) and
       // the next chunk's operand reads precede this chunk's MFMAs; left alone the scheduler gathers all DEPTH loads at the
       // end of the loop body, where their latency is fully exposed
-      __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);       // NG VMEM reads
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // 2 DS reads (next chunk)
-      __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);   // 8 MFMAs per column group (this chunk)
+      __builtin_amdgcn_sched_group_barrier(0x020, NG, 0);            // NG VMEM reads
+      __builtin_amdgcn_sched_group_barrier(0x100, RG, 0);            // RG DS reads (next chunk)
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * RG * NG, 0);   // 4 RG MFMAs per column group (this chunk)
     }
   }
 #pragma unroll
@@ -119,38 +124,42 @@ __device__ __forceinline__ void gemm_run(Ring<DEPTH, NG>& ring, const float* __r
 #pragma unroll
       for (int g = 0; g < NGN; ++g) nring.v[d][g] = *reinterpret_cast<const f32x4*>(wn + g * gstride_n + cn * cstride_n);
     }
-    const f32x4 n0 = *reinterpret_cast<const f32x4*>(xr + 4 * (c + 1));
-    const f32x4 n1 = *reinterpret_cast<const f32x4*>(xr + 4 * FCC_XS + 4 * (c + 1));
 #pragma unroll
-    for (int g = 0; g < NG; ++g) mac_chunk(a0, a1, ring.v[d][g], acc[g]);
-    a0 = n0; a1 = n1;
+    for (int g = 0; g < RG; ++g) nn[g] = *reinterpret_cast<const f32x4*>(xr + 4 * g * FCC_XS + 4 * (c + 1));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) mac_chunk<RG>(an, ring.v[d][g], acc[g]);
+#pragma unroll
+    for (int g = 0; g < RG; ++g) an[g] = nn[g];
     __builtin_amdgcn_sched_group_barrier(0x020, NGN, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NG, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, RG, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * RG * NG, 0);
   }
 }
 
 // layer with a SMALL contraction (C <= 32, run-time: the latent side): chunks 0..c4-1 of one column group, all requested at
 // once (c4 <= 8)
-__device__ __forceinline__ void gemm_small_c(const float* __restrict__ wp, int cstride, int c4, const float* xr, Acc8& acc) {
+template <int RG>
+__device__ __forceinline__ void gemm_small_c(const float* __restrict__ wp, int cstride, int c4, const float* xr, AccR<RG>& acc) {
   f32x4 w[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) w[c] = *reinterpret_cast<const f32x4*>(wp + (c < c4 ? c : 0) * cstride);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     if (c < c4) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(xr + 4 * FCC_XS + 4 * c);
-      mac_chunk(a0, a1, w[c], acc);
+      f32x4 a[RG];
+#pragma unroll
+      for (int g = 0; g < RG; ++g) a[g] = *reinterpret_cast<const f32x4*>(xr + 4 * g * FCC_XS + 4 * c);
+      mac_chunk<RG>(a, w[c], acc);
     }
   }
 }
 
-// 8 x C rows of a row-major [n][C] tensor -> LDS tile (zero rows beyond n)
-template <int C, int NT>
+// R x C rows of a row-major [n][C] tensor -> LDS tile (zero rows beyond n)
+template <int C, int NT, int R>
 __device__ __forceinline__ void load_rows(const float* __restrict__ x, int row0, int n, float* tile, int tid) {
   constexpr int Q = C / 4;                      // 16-byte chunks per row
-  constexpr int NP = FCC_R * Q / NT;
+  constexpr int NP = R * Q / NT;
+  static_assert(NP >= 1 && NP * NT == R * Q, "the tile must be a whole number of 16-byte chunks per thread");
   f32x4 v[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
@@ -207,25 +216,26 @@ struct Lane {
 // 256-wide layer, contraction of NCH chunks: complete sums in v[] of the waves with kh == 0 (one workgroup barrier inside
 // when KS == 2).  wp = this layer's image + col * 4; tile = activation tile.  The next layer's first chunks are requested
 // into nring from wn (already offset for this wave) while the last DEPTH chunks are consumed.
-template <int DEPTH, int KS, int NCH, int NCHN, int NGN>
+template <int DEPTH, int KS, int NCH, int NCHN, int NGN, int RG>
 __device__ __forceinline__ void layer256(const Lane<KS>& L, Ring<DEPTH, 1>& ring, const float* __restrict__ wp, int cstride,
                                          const float* tile, Ring<DEPTH, (NGN > 0 ? NGN : 1)>& nring,
-                                         const float* __restrict__ wn, int gstride_n, int cstride_n, float* part, float (&v)[8]) {
+                                         const float* __restrict__ wn, int gstride_n, int cstride_n, float* part,
+                                         float (&v)[4 * RG]) {
   constexpr int NW = NCH / KS;                  // chunks per wave
-  Acc8 acc[1];
+  AccR<RG> acc[1];
   acc_zero(acc[0]);
-  gemm_run<DEPTH, NW, 1, NCHN, NGN>(ring, wp + (long)L.kh * NW * cstride, 0, cstride, tile + L.xo + L.kh * NW * 4, acc, nring, wn,
-                                    gstride_n, cstride_n);
+  gemm_run<DEPTH, NW, 1, NCHN, NGN, RG>(ring, wp + (long)L.kh * NW * cstride, 0, cstride, tile + L.xo + L.kh * NW * 4, acc, nring,
+                                        wn, gstride_n, cstride_n);
   acc_rows(acc[0], v);
   if (KS == 2) {
     if (L.kh == 1) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) part[r * FCC_HID + L.col] = v[r];
+      for (int r = 0; r < 4 * RG; ++r) part[r * FCC_HID + L.col] = v[r];
     }
     __syncthreads();
     if (L.kh == 0) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] += part[r * FCC_HID + L.col];
+      for (int r = 0; r < 4 * RG; ++r) v[r] += part[r * FCC_HID + L.col];
     }
   }
 }
@@ -237,22 +247,23 @@ __device__ __forceinline__ void fill256(const Lane<KS>& L, Ring<DEPTH, 1>& ring,
 }
 
 // ---------------------------------------------------------------------------------------------- forward
-template <int DEPTH, int KS>
+template <int DEPTH, int KS, int RG>
 __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   const dvae_fc_chain_fwd_args& a = P.a;
+  constexpr int R = 4 * RG;                         // batch rows per workgroup
   constexpr int NT = 256 * KS, NWV = 4 * KS;
   constexpr int SD = 64 / NWV;                      // chunks per wave of a layer whose contraction is split over ALL waves
   constexpr int G512 = KS == 2 ? 1 : 2;             // 256-column halves of a 512-wide layer per wave
-  __shared__ __attribute__((aligned(16))) float tA[FCC_R * FCC_XS];
-  __shared__ __attribute__((aligned(16))) float tB[FCC_R * FCC_XS];
-  __shared__ float red[NWV][FCC_R][64];
-  __shared__ float mlt[FCC_R][64];
-  __shared__ float part[KS == 2 ? FCC_R * FCC_HID : 1];
+  __shared__ __attribute__((aligned(16))) float tA[R * FCC_XS];
+  __shared__ __attribute__((aligned(16))) float tB[R * FCC_XS];
+  __shared__ float red[NWV][R][64];
+  __shared__ float mlt[R][64];
+  __shared__ float part[KS == 2 ? R * FCC_HID : 1];
   __shared__ __attribute__((aligned(16))) float warm_sink[256];
   const Lane<KS> L;
   const int tid = L.tid, lane = L.lane, wv = L.wv, col = L.col, xo = L.xo;
   const bool own = L.kh == 0;                       // this wave finishes the 256-wide layers (bias, activation, stores)
-  const int row0 = blockIdx.x * FCC_R;
+  const int row0 = blockIdx.x * R;
   const int D = a.D, D2 = 2 * a.D;
   constexpr int CS = FCC_HID * 4;                   // chunk stride of a 256-wide image
 
@@ -267,16 +278,16 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
     l2_warm(a.w_d2, FCC_HID * FCC_HID, sh, nsh, wv, NWV, lane, sink);
     l2_warm(a.w_d3, FCC_HID * FCC_FLAT, sh, nsh, wv, NWV, lane, sink);
   }
-  load_rows<FCC_FLAT, NT>(a.a_flat, row0, a.n_enc, tA, tid);
+  load_rows<FCC_FLAT, NT, R>(a.a_flat, row0, a.n_enc, tA, tid);
   const float be1 = a.b_e1[col], be2 = a.b_e2[col];
   __syncthreads();
 
-  float v[8];
+  float v[R];
   // ---- encoder lin1: 512 -> 256, ReLU
-  layer256<DEPTH, KS, 128, 64 / KS, 1>(L, r1, a.w_e1 + col * 4, CS, tA, r2, a.w_e2 + col * 4 + (long)L.kh * (64 / KS) * CS, 0, CS, part, v);
+  layer256<DEPTH, KS, 128, 64 / KS, 1, RG>(L, r1, a.w_e1 + col * 4, CS, tA, r2, a.w_e2 + col * 4 + (long)L.kh * (64 / KS) * CS, 0, CS, part, v);
   if (own) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       v[r] = fmaxf(v[r] + be1, 0.f);
       tB[r * FCC_XS + col] = v[r];
       if (row0 + r < a.n_enc) a.h1[(long)(row0 + r) * FCC_HID + col] = v[r];
@@ -287,11 +298,11 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   Ring<SD, 1> rml;
   const int cml = lane < D2 ? lane : D2 - 1;
   const float* wml = a.w_ml + ((long)wv * SD * D2 + cml) * 4;
-  layer256<DEPTH, KS, 64, 0, 0>(L, r2, a.w_e2 + col * 4, CS, tB, dummy, nullptr, 0, 0, part, v);
+  layer256<DEPTH, KS, 64, 0, 0, RG>(L, r2, a.w_e2 + col * 4, CS, tB, dummy, nullptr, 0, 0, part, v);
   ring_fill<SD, 1, SD>(rml, wml, 0, D2 * 4);
   if (own) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       v[r] = fmaxf(v[r] + be2, 0.f);
       tA[r * FCC_XS + col] = v[r];
       if (row0 + r < a.n_enc) a.h2[(long)(row0 + r) * FCC_HID + col] = v[r];
@@ -300,19 +311,19 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   __syncthreads();
   // ---- mu_logvar_gen: 256 -> 2D (no activation): wave w contracts k in [4 SD w, 4 SD (w+1)), partial sums through LDS
   {
-    Acc8 acc[1];
+    AccR<RG> acc[1];
     acc_zero(acc[0]);
-    gemm_run<SD, SD, 1, 0, 0>(rml, wml, 0, D2 * 4, tA + xo + wv * SD * 4, acc, dummy_s, nullptr, 0, 0);
+    gemm_run<SD, SD, 1, 0, 0, RG>(rml, wml, 0, D2 * 4, tA + xo + wv * SD * 4, acc, dummy_s, nullptr, 0, 0);
     acc_rows(acc[0], v);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) red[wv][r][lane] = v[r];
+    for (int r = 0; r < R; ++r) red[wv][r][lane] = v[r];
   }
   // the decoder's second weight stream does not depend on anything computed here: request it now
   Ring<DEPTH, 1> rd2;
   const bool dec = row0 < a.n_dec;                  // workgroup-uniform
   if (dec) fill256<DEPTH, KS, 64>(L, rd2, a.w_d2 + col * 4, CS);
   __syncthreads();
-  for (int t = tid; t < FCC_R * D2; t += NT) {
+  for (int t = tid; t < R * D2; t += NT) {
     const int r = t / D2, j = t % D2;
     float m = red[0][r][j];
 #pragma unroll
@@ -324,9 +335,9 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   __syncthreads();
   // ---- reparameterise (vae.py:66-68) + per-dim KL terms (losses.py:470); z -> tB (zero padded to a multiple of 4 columns)
   {
-    float* klt = &red[0][0][0];                     // [8][16]
+    float* klt = &red[0][0][0];                     // [R][16]
     const int dp = (D + 3) & ~3;
-    for (int t = tid; t < FCC_R * 16; t += NT) {
+    for (int t = tid; t < R * 16; t += NT) {
       const int r = t >> 4, d = t & 15;
       float kl = 0.f;
       if (d < dp) {
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
     if (a.kl_part && tid < 16) {
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < FCC_R; ++r) s += klt[r * 16 + tid];
+      for (int r = 0; r < R; ++r) s += klt[r * 16 + tid];
       a.kl_part[(long)blockIdx.x * 16 + tid] = s;
     }
   }
@@ -357,12 +368,12 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   const float bd1 = a.b_d1[col], bd2 = a.b_d2[col];
   // ---- decoder lin1: D -> 256, ReLU
   if (own) {
-    Acc8 acc;
+    AccR<RG> acc;
     acc_zero(acc);
-    gemm_small_c(a.w_d1 + col * 4, CS, (D + 3) >> 2, tB + xo, acc);
+    gemm_small_c<RG>(a.w_d1 + col * 4, CS, (D + 3) >> 2, tB + xo, acc);
     acc_rows(acc, v);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       v[r] = fmaxf(v[r] + bd1, 0.f);
       tA[r * FCC_XS + col] = v[r];
       if (row0 + r < a.n_dec) a.d1[(long)(row0 + r) * FCC_HID + col] = v[r];
@@ -372,10 +383,10 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   // ---- decoder lin2: 256 -> 256, ReLU; its tail requests lin3's stream (512 wide: column half kh when KS == 2, both else)
   Ring<DEPTH, G512> rd3;
   const float* wd3 = a.w_d3 + (col + (KS == 2 ? L.kh * FCC_HID : 0)) * 4;
-  layer256<DEPTH, KS, 64, 64, G512>(L, rd2, a.w_d2 + col * 4, CS, tA, rd3, wd3, FCC_HID * 4, FCC_FLAT * 4, part, v);
+  layer256<DEPTH, KS, 64, 64, G512, RG>(L, rd2, a.w_d2 + col * 4, CS, tA, rd3, wd3, FCC_HID * 4, FCC_FLAT * 4, part, v);
   if (own) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       v[r] = fmaxf(v[r] + bd2, 0.f);
       tB[r * FCC_XS + col] = v[r];
       if (row0 + r < a.n_dec) a.d2[(long)(row0 + r) * FCC_HID + col] = v[r];
@@ -384,38 +395,39 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   __syncthreads();
   // ---- decoder lin3: 256 -> 512, ReLU
   {
-    Acc8 acc[G512];
+    AccR<RG> acc[G512];
 #pragma unroll
     for (int g = 0; g < G512; ++g) acc_zero(acc[g]);
-    gemm_run<DEPTH, 64, G512, 0, 0>(rd3, wd3, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
+    gemm_run<DEPTH, 64, G512, 0, 0, RG>(rd3, wd3, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
 #pragma unroll
     for (int g = 0; g < G512; ++g) {
       const int c512 = col + (KS == 2 ? L.kh : g) * FCC_HID;
       const float b = a.b_d3[c512];
       acc_rows(acc[g], v);
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
+      for (int r = 0; r < R; ++r)
         if (row0 + r < a.n_dec) a.d3[(long)(row0 + r) * FCC_FLAT + c512] = fmaxf(v[r] + b, 0.f);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-template <int DEPTH, int KS>
+template <int DEPTH, int KS, int RG>
 __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   const dvae_fc_chain_bwd_args& a = P.a;
+  constexpr int R = 4 * RG;
   constexpr int NT = 256 * KS, NWV = 4 * KS;
   constexpr int SD = 64 / NWV;
   constexpr int G512 = KS == 2 ? 1 : 2;
-  __shared__ __attribute__((aligned(16))) float tA[FCC_R * FCC_XS];
-  __shared__ __attribute__((aligned(16))) float tB[FCC_R * FCC_XS];
-  __shared__ float red[NWV][FCC_R][64];
-  __shared__ float part[KS == 2 ? FCC_R * FCC_HID : 1];
+  __shared__ __attribute__((aligned(16))) float tA[R * FCC_XS];
+  __shared__ __attribute__((aligned(16))) float tB[R * FCC_XS];
+  __shared__ float red[NWV][R][64];
+  __shared__ float part[KS == 2 ? R * FCC_HID : 1];
   __shared__ __attribute__((aligned(16))) float warm_sink[256];
   const Lane<KS> L;
   const int tid = L.tid, lane = L.lane, wv = L.wv, col = L.col, xo = L.xo;
   const bool own = L.kh == 0;
-  const int row0 = blockIdx.x * FCC_R;
+  const int row0 = blockIdx.x * R;
   const int n = a.n;
   const int D = a.D, D2 = 2 * a.D;
   constexpr int CS = FCC_HID * 4;
@@ -431,22 +443,22 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
     l2_warm(a.w_e2, FCC_HID * FCC_HID, sh, nsh, wv, NWV, lane, sink);
     l2_warm(a.w_e1, FCC_FLAT * FCC_HID, sh, nsh, wv, NWV, lane, sink);
   }
-  load_rows<FCC_FLAT, NT>(a.gd3, row0, n, tA, tid);
-  float mk[8], v[8];
+  load_rows<FCC_FLAT, NT, R>(a.gd3, row0, n, tA, tid);
+  float mk[R], v[R];
   // ReLU mask of a 256-wide layer = its saved post-activation output (zero rows beyond n: their gradients are not stored)
   auto load_mask = [&](const float* __restrict__ act) {
     if (own) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) mk[r] = row0 + r < n ? act[(long)(row0 + r) * FCC_HID + col] : 0.f;
+      for (int r = 0; r < R; ++r) mk[r] = row0 + r < n ? act[(long)(row0 + r) * FCC_HID + col] : 0.f;
     }
   };
   load_mask(a.d2);
   __syncthreads();
   // ---- decoder lin3 input gradient: 512 -> 256, mask d2
-  layer256<DEPTH, KS, 128, 64 / KS, 1>(L, r3, a.w_d3 + col * 4, CS, tA, r2, a.w_d2 + col * 4 + (long)L.kh * (64 / KS) * CS, 0, CS, part, v);
+  layer256<DEPTH, KS, 128, 64 / KS, 1, RG>(L, r3, a.w_d3 + col * 4, CS, tA, r2, a.w_d2 + col * 4 + (long)L.kh * (64 / KS) * CS, 0, CS, part, v);
   if (own) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       v[r] = mk[r] > 0.f ? v[r] : 0.f;
       tB[r * FCC_XS + col] = v[r];
       if (row0 + r < n) a.gd2[(long)(row0 + r) * FCC_HID + col] = v[r];
@@ -458,11 +470,11 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   Ring<SD, 1> r1;
   const int c1 = lane < D ? lane : D - 1;
   const float* w1 = a.w_d1 + ((long)wv * SD * D + c1) * 4;
-  layer256<DEPTH, KS, 64, 0, 0>(L, r2, a.w_d2 + col * 4, CS, tB, dummy, nullptr, 0, 0, part, v);
+  layer256<DEPTH, KS, 64, 0, 0, RG>(L, r2, a.w_d2 + col * 4, CS, tB, dummy, nullptr, 0, 0, part, v);
   ring_fill<SD, 1, SD>(r1, w1, 0, D * 4);
   if (own) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       v[r] = mk[r] > 0.f ? v[r] : 0.f;
       tA[r * FCC_XS + col] = v[r];
       if (row0 + r < n) a.gd1[(long)(row0 + r) * FCC_HID + col] = v[r];
@@ -471,12 +483,12 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   __syncthreads();
   // ---- decoder lin1 input gradient: 256 -> D (dL/dz through the decoder)
   {
-    Acc8 acc[1];
+    AccR<RG> acc[1];
     acc_zero(acc[0]);
-    gemm_run<SD, SD, 1, 0, 0>(r1, w1, 0, D * 4, tA + xo + wv * SD * 4, acc, dummy_s, nullptr, 0, 0);
+    gemm_run<SD, SD, 1, 0, 0, RG>(r1, w1, 0, D * 4, tA + xo + wv * SD * 4, acc, dummy_s, nullptr, 0, 0);
     acc_rows(acc[0], v);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) red[wv][r][lane] = v[r];
+    for (int r = 0; r < R; ++r) red[wv][r][lane] = v[r];
   }
   fill256<DEPTH, KS, 64>(L, re2, a.w_e2 + col * 4, CS);   // encoder lin2's stream: independent of the latent glue below
   load_mask(a.h2);
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   {
     const float klw = a.scal[DVAE_S_KLW] * a.coef[DVAE_C_INV_B];
     const int dp2 = (D2 + 3) & ~3;
-    for (int t = tid; t < FCC_R * 32; t += NT) {
+    for (int t = tid; t < R * 32; t += NT) {
       const int r = t >> 5, d = t & 31;
       if (d < D) {
         float dm = 0.f, dl = 0.f;
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
         tB[r * FCC_XS + 2 * d + 1] = dl;
       }
     }
-    if (tid < FCC_R * 4) {                           // padding columns D2 .. dp2-1 (at most 2: D2 is even)
+    if (tid < R * 4) {                           // padding columns D2 .. dp2-1 (at most 2: D2 is even)
       const int r = tid >> 2, c = D2 + (tid & 3);
       if (c < dp2) tB[r * FCC_XS + c] = 0.f;
     }
@@ -518,12 +530,12 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   __syncthreads();
   // ---- mu_logvar_gen input gradient: 2D -> 256, mask h2
   if (own) {
-    Acc8 acc;
+    AccR<RG> acc;
     acc_zero(acc);
-    gemm_small_c(a.w_ml + col * 4, CS, (D2 + 3) >> 2, tB + xo, acc);
+    gemm_small_c<RG>(a.w_ml + col * 4, CS, (D2 + 3) >> 2, tB + xo, acc);
     acc_rows(acc, v);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       v[r] = mk[r] > 0.f ? v[r] : 0.f;
       tA[r * FCC_XS + col] = v[r];
       if (row0 + r < n) a.gh2[(long)(row0 + r) * FCC_HID + col] = v[r];
@@ -535,69 +547,87 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   Ring<DEPTH, G512> re1;
   const int half = KS == 2 ? L.kh : 0;
   const float* we1 = a.w_e1 + (col + half * FCC_HID) * 4;
-  layer256<DEPTH, KS, 64, 64, G512>(L, re2, a.w_e2 + col * 4, CS, tA, re1, we1, FCC_HID * 4, FCC_FLAT * 4, part, v);
+  layer256<DEPTH, KS, 64, 64, G512, RG>(L, re2, a.w_e2 + col * 4, CS, tA, re1, we1, FCC_HID * 4, FCC_FLAT * 4, part, v);
   if (own) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       v[r] = mk[r] > 0.f ? v[r] : 0.f;
       tB[r * FCC_XS + col] = v[r];
       if (row0 + r < n) a.gh1[(long)(row0 + r) * FCC_HID + col] = v[r];
     }
   }
   // masks of the 512-wide output: the conv stack's flattened activation (encoders.py:80)
-  float mk2[G512][8];
+  float mk2[G512][R];
 #pragma unroll
   for (int g = 0; g < G512; ++g)
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+    for (int r = 0; r < R; ++r)
       mk2[g][r] = row0 + r < n ? a.a_flat[(long)(row0 + r) * FCC_FLAT + (KS == 2 ? half : g) * FCC_HID + col] : 0.f;
   __syncthreads();
   // ---- encoder lin1 input gradient: 256 -> 512, mask a_flat
   {
-    Acc8 acc[G512];
+    AccR<RG> acc[G512];
 #pragma unroll
     for (int g = 0; g < G512; ++g) acc_zero(acc[g]);
-    gemm_run<DEPTH, 64, G512, 0, 0>(re1, we1, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
+    gemm_run<DEPTH, 64, G512, 0, 0, RG>(re1, we1, FCC_HID * 4, FCC_FLAT * 4, tB + xo, acc, dummy, nullptr, 0, 0);
 #pragma unroll
     for (int g = 0; g < G512; ++g) {
       const int c512 = col + (KS == 2 ? half : g) * FCC_HID;
       acc_rows(acc[g], v);
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
+      for (int r = 0; r < R; ++r)
         if (row0 + r < n) a.ga_flat[(long)(row0 + r) * FCC_FLAT + c512] = mk2[g][r] > 0.f ? v[r] : 0.f;
     }
   }
 }
 
 // ring depth x contraction split of the shipped library.  Measured (profiles/r03_v2_fcc_ab.txt, B = 128 / 1024, forward |
-// backward, us): <8,1> 28.1 | 33.6 / 30.5 | 40.2; <16,1> 28.0 | 33.4 / 30.3 | 38.4; <8,2> 23.6 | 25.3 / 26.1 | 27.7; <16,2> 24.4 |
-// 26.0 / 26.8 | 28.4 -- the second wave per SIMD helps, a deeper ring does not: ~65 GB/s of weight stream per CU either way.
-// Debug builds can A/B the other instantiations with DVAE_FCC_VARIANT = 10 * DEPTH + KS
+// backward, us, 8 rows per workgroup): <8,1> 28.1 | 33.6 / 30.5 | 40.2; <16,1> 28.0 | 33.4 / 30.3 | 38.4; <8,2> 23.6 | 25.3 /
+// 26.1 | 27.7; <16,2> 24.4 | 26.0 / 26.8 | 28.4 -- the second wave per SIMD helps, a deeper ring does not: with 8 rows the
+// launch is bound by its 12.8 k MFMAs per SIMD (21.6 us).  Round 5: FOUR rows per workgroup (RG = 1: half the MFMAs per
+// workgroup, twice the workgroups; then the ring depth matters: the bound becomes the L2 -> register weight stream) up to
+// FCC_R4_MAX_ROWS batch rows, where the doubled workgroup count still fits the chip in one wave; 8 rows above.
+// Debug builds can A/B the other instantiations with DVAE_FCC_VARIANT = 100 * rows + 10 * DEPTH + KS (rows = 0: by batch)
 #ifndef FCC_DEFAULT_VARIANT
 #define FCC_DEFAULT_VARIANT 82
 #endif
+#ifndef FCC_R4_DEPTH
+#define FCC_R4_DEPTH 16
+#endif
+#define FCC_R4_MAX_ROWS 1024
 
-template <int DEPTH, int KS>
-static void launch_fwd_t(const FwdArgs& P, int nblk, hipStream_t s) {
-  hipLaunchKernelGGL((k_fc_chain_fwd<DEPTH, KS>), dim3(nblk), dim3(256 * KS), 0, s, P);
+// batch rows per workgroup of the chain kernels for a launch over n rows (= the granularity of the forward's KL partial blocks)
+int fc_chain_rows(int n) {
+  static const int variant = env_int("DVAE_FCC_VARIANT", 0);
+  if (variant >= 100) return variant / 100 == 4 ? 4 : 8;
+  return n <= FCC_R4_MAX_ROWS ? 4 : 8;
 }
-template <int DEPTH, int KS>
-static void launch_bwd_t(const BwdArgs& P, int nblk, hipStream_t s) {
-  hipLaunchKernelGGL((k_fc_chain_bwd<DEPTH, KS>), dim3(nblk), dim3(256 * KS), 0, s, P);
+
+template <int DEPTH, int KS, int RG>
+static void launch_fwd_t(const FwdArgs& P, hipStream_t s) {
+  hipLaunchKernelGGL((k_fc_chain_fwd<DEPTH, KS, RG>), dim3((P.a.n_enc + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), 0, s, P);
+}
+template <int DEPTH, int KS, int RG>
+static void launch_bwd_t(const BwdArgs& P, hipStream_t s) {
+  hipLaunchKernelGGL((k_fc_chain_bwd<DEPTH, KS, RG>), dim3((P.a.n + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), 0, s, P);
 }
 
 int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s) {
   FwdArgs P;
   P.a = *a;
-  const int nblk = (a->n_enc + FCC_R - 1) / FCC_R;
-  static const int variant = env_int("DVAE_FCC_VARIANT", FCC_DEFAULT_VARIANT);
+  static const int variant = env_int("DVAE_FCC_VARIANT", 0) % 100;
+  const bool r4 = fc_chain_rows(a->n_enc) == 4;
   switch (variant) {
 #ifdef DVAE_DEBUG_SWITCHES
-    case 81: launch_fwd_t<8, 1>(P, nblk, s); break;
-    case 161: launch_fwd_t<16, 1>(P, nblk, s); break;
-    case 162: launch_fwd_t<16, 2>(P, nblk, s); break;
+    case 81: if (r4) launch_fwd_t<8, 1, 1>(P, s); else launch_fwd_t<8, 1, 2>(P, s); break;
+    case 82: if (r4) launch_fwd_t<8, 2, 1>(P, s); else launch_fwd_t<8, 2, 2>(P, s); break;
+    case 161: if (r4) launch_fwd_t<16, 1, 1>(P, s); else launch_fwd_t<16, 1, 2>(P, s); break;
+    case 162: if (r4) launch_fwd_t<16, 2, 1>(P, s); else launch_fwd_t<16, 2, 2>(P, s); break;
 #endif
-    default: launch_fwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10>(P, nblk, s); break;
+    default:
+      if (r4) launch_fwd_t<FCC_R4_DEPTH, 2, 1>(P, s);
+      else launch_fwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10, 2>(P, s);
+      break;
   }
   DVAE_CHECK_LAUNCH();
   return 0;
@@ -606,15 +636,19 @@ int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s) {
 int launch_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, hipStream_t s) {
   BwdArgs P;
   P.a = *a;
-  const int nblk = (a->n + FCC_R - 1) / FCC_R;
-  static const int variant = env_int("DVAE_FCC_VARIANT", FCC_DEFAULT_VARIANT);
+  static const int variant = env_int("DVAE_FCC_VARIANT", 0) % 100;
+  const bool r4 = fc_chain_rows(a->n) == 4;
   switch (variant) {
 #ifdef DVAE_DEBUG_SWITCHES
-    case 81: launch_bwd_t<8, 1>(P, nblk, s); break;
-    case 161: launch_bwd_t<16, 1>(P, nblk, s); break;
-    case 162: launch_bwd_t<16, 2>(P, nblk, s); break;
+    case 81: if (r4) launch_bwd_t<8, 1, 1>(P, s); else launch_bwd_t<8, 1, 2>(P, s); break;
+    case 82: if (r4) launch_bwd_t<8, 2, 1>(P, s); else launch_bwd_t<8, 2, 2>(P, s); break;
+    case 161: if (r4) launch_bwd_t<16, 1, 1>(P, s); else launch_bwd_t<16, 1, 2>(P, s); break;
+    case 162: if (r4) launch_bwd_t<16, 2, 1>(P, s); else launch_bwd_t<16, 2, 2>(P, s); break;
 #endif
-    default: launch_bwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10>(P, nblk, s); break;
+    default:
+      if (r4) launch_bwd_t<FCC_R4_DEPTH, 2, 1>(P, s);
+      else launch_bwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10, 2>(P, s);
+      break;
   }
   DVAE_CHECK_LAUNCH();
   return 0;

@@ -567,12 +567,16 @@ __global__ void k_axpby(float* __restrict__ out, const float* __restrict__ a, fl
 
 // src[A][Bn][inner] -> dst[Bn][A][inner]: the packed exchanges of the sharded beta-TCVAE step (an all-gather delivers
 // [world][3][B*D], the estimator reads [3][world*B*D]; its column gradients [2][world][B*D] leave as [world][2][B*D])
-__global__ void k_swap_outer(const float* __restrict__ src, float* __restrict__ dst, int A, int Bn, long inner) {
-  const long n = (long)A * Bn * inner;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const long e = i % inner, ab = i / inner;
-    const int b = (int)(ab % Bn), a = (int)(ab / Bn);
-    dst[((long)b * A + a) * inner + e] = src[i];
+__global__ void k_swap_outer(const float* __restrict__ src, float* __restrict__ dst, int A, int Bn, int inner) {
+  // one workgroup per (a, b) slab: no per-element index division
+  const int a = blockIdx.x / Bn, b = blockIdx.x % Bn;
+  const float* s = src + (long)blockIdx.x * inner;
+  float* d = dst + ((long)b * A + a) * inner;
+  if ((inner & 3) == 0 && (((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+    for (int i = threadIdx.x; i < inner / 4; i += blockDim.x)
+      reinterpret_cast<f32x4*>(d)[i] = reinterpret_cast<const f32x4*>(s)[i];
+  } else {
+    for (int i = threadIdx.x; i < inner; i += blockDim.x) d[i] = s[i];
   }
 }
 
@@ -738,9 +742,7 @@ int launch_axpby(float* out, const float* a, float alpha, const float* b, float 
 }
 
 int launch_swap_outer(const float* src, float* dst, int A, int Bn, long inner, hipStream_t s) {
-  const long n = (long)A * Bn * inner;
-  long g = (n + 255) / 256; if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(k_swap_outer, dim3(g), dim3(256), 0, s, src, dst, A, Bn, inner);
+  hipLaunchKernelGGL(k_swap_outer, dim3(A * Bn), dim3(256), 0, s, src, dst, A, Bn, (int)inner);
   DVAE_CHECK_LAUNCH();
   return 0;
 }

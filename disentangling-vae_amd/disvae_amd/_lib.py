@@ -47,6 +47,7 @@ SIGNATURES = {
     "dvae_convT3_dgrad_bits": [_p, _p, _p, _p, _i, _i, _p],
     "dvae_fc_chain_fwd": [_p, _p],
     "dvae_fc_chain_bwd": [_p, _p],
+    "dvae_fc_chain_rows": [_i],
     "dvae_reparam_kl_blocks": [_i],
     "dvae_kl_finish": [_p, _i, _p, _i, _p],
     "dvae_u8_to_f32": [_p, _p, _l, _p],
@@ -88,6 +89,8 @@ SIGNATURES = {
     "dvae_comm_group_start": [],
     "dvae_comm_group_end": [],
     "dvae_add": [_p, _p, _p, _l, _p],
+    "dvae_adam_step": [_p, _i, ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                       ctypes.c_double, _p],
     "dvae_axpby": [_p, _p, ctypes.c_float, _p, ctypes.c_float, _l, _p],
     "dvae_swap_outer": [_p, _p, _i, _i, _l, _p],
     "dvae_stream_order": [_p, _p],
@@ -103,7 +106,13 @@ _RESTYPE = {"dvae_last_error": ctypes.c_char_p, "dvae_conv_wgrad_ws_floats": cty
 FCW_MAX = 8
 KL_MAX_BLOCKS = 8192                 # DVAE_KL_MAX_BLOCKS
 KL_FLOATS = 16 + KL_MAX_BLOCKS * 16   # DVAE_KL_FLOATS
-FC_CHAIN_ROWS = 8                    # batch rows per workgroup of dvae_fc_chain_*: ceil(n / 8) KL partial blocks
+FC_CHAIN_MAX_ROWS = 8 * KL_MAX_BLOCKS  # rows one dvae_fc_chain_* launch takes
+
+
+def fc_chain_rows(n):
+    """dvae_fc_chain_rows(n): batch rows per workgroup of dvae_fc_chain_* over n rows = granularity of its KL partial blocks."""
+    return int(lib().dvae_fc_chain_rows(int(n)))
+
 
 
 class ConvImageDesc(ctypes.Structure):
@@ -147,6 +156,11 @@ def struct_of(cls, **kw):
     for k, v in kw.items():
         setattr(st, k, v)
     return st, ctypes.addressof(st)
+
+
+class AdamTensor(ctypes.Structure):
+    """dvae_adam_tensor (include/dvae_hip.h)."""
+    _fields_ = [("p", _p), ("g", _p), ("m", _p), ("v", _p), ("step", _p), ("n", _l)]
 
 
 class LinearWgradDesc(ctypes.Structure):

@@ -220,6 +220,7 @@ class VAEEngine:
         self._ws = None
         self._ws_side = None
         self._side = None      # side HIP stream: the weight-gradient kernels run beside the dgrad chain
+        self._aux = None       # exchange stream of sharded steps (see buffers())
         # small batches: everything on the caller's stream.  Below ~256 images the iteration is bound by the latency of
         # dependent launches, a fork / join between hardware queues costs ~6 us each (5 forks + 1 join per iteration) and
         # the weight-gradient kernels that the side stream would overlap are a few microseconds long.  Set per step by the
@@ -267,6 +268,10 @@ class VAEEngine:
             self._ws_side = torch.empty(n, dtype=torch.float32, device=self.device)
             # (a high-priority side stream measured the same step time: profiles/r04_v45_side_priority.txt)
             self._side = torch.cuda.Stream(device=self.device)
+            # third stream (sharded batches): the exchange-bound part of a step -- latent all-gather, the estimator over the
+            # global batch, column-gradient reduce-scatter, the all-reduce of the loss sums -- must not sit in front of the
+            # weight gradients on the side stream, which is the tail of the iteration
+            self._aux = torch.cuda.Stream(device=self.device)
         return b
 
     # ---- per-step weight staging -------------------------------------------------------------------
@@ -338,6 +343,13 @@ class VAEEngine:
 
     def _side_raw(self):
         return _stream() if self.single_stream else self._side.cuda_stream
+
+    @property
+    def aux_stream(self):
+        return torch.cuda.current_stream() if self.single_stream else self._aux
+
+    def _aux_raw(self):
+        return _stream() if self.single_stream else self._aux.cuda_stream
 
     def _side_wgrad_grouped(self, problems):
         """All FC weight gradients of `problems` = [(x, dy, dw, db, M, K, N)] (tensors) in ONE launch on the side stream
@@ -439,7 +451,8 @@ class VAEEngine:
     @staticmethod
     def kl_blocks(n_enc):
         """Number of KL partial blocks fc_chain_fwd leaves at kl_dim + 16 (dvae_loss_epilogue / dvae_kl_finish argument)."""
-        return (n_enc + _lib.FC_CHAIN_ROWS - 1) // _lib.FC_CHAIN_ROWS
+        r = _lib.fc_chain_rows(n_enc)
+        return (n_enc + r - 1) // r
 
     def fc_chain_fwd(self, buf, eps, kl_dim, n_enc, n_kl=None, n_dec=None):
         """buf.a_flat -> h1, h2, ml, mu, logvar, z (rows < n_enc; KL partial blocks from rows < n_kl at kl_dim + 16) and
@@ -447,8 +460,8 @@ class VAEEngine:
         decoders.py:71-73.  eps [n_enc, D] or None (z = mu)."""
         n_kl = n_enc if n_kl is None else n_kl
         n_dec = n_enc if n_dec is None else n_dec
-        if n_enc > _lib.FC_CHAIN_ROWS * _lib.KL_MAX_BLOCKS:
-            raise _lib.DvaeHipError("fc_chain_fwd: at most %d rows per launch" % (_lib.FC_CHAIN_ROWS * _lib.KL_MAX_BLOCKS))
+        if n_enc > _lib.FC_CHAIN_MAX_ROWS:
+            raise _lib.DvaeHipError("fc_chain_fwd: at most %d rows per launch" % _lib.FC_CHAIN_MAX_ROWS)
         P, I = self.p, self._img
         addr = self._args(("fcf", id(buf), ptr(eps), ptr(kl_dim), n_enc, n_kl, n_dec, self._images.buf.data_ptr()),
                           _lib.FcChainFwdArgs, a_flat=ptr(buf.a_flat),

@@ -16,6 +16,7 @@ import abc
 import torch
 
 from .. import _lib
+from .. import optim
 from .._lib import call, ptr, record_on_stream, record_py
 from ..utils.math import log_importance_weights
 from .discriminator import Discriminator
@@ -398,7 +399,7 @@ class _SingleOptimizerLoss(BaseLoss):
             self._device_step(data, model, sc, eps, is_train)
         if is_train:
             model.assign_grads()          # optimizer.zero_grad(); loss.backward()  (training.py:156-157)
-            optimizer.step()              # training.py:158
+            optim.step(optimizer)         # optimizer.step(), training.py:158 (one launch for a stock Adam: disvae_amd/optim.py)
         if storer is not None:
             vals = sc.scal.tolist()       # ONE device->host copy for every logged scalar
             self._store(storer, vals, D)
@@ -423,7 +424,7 @@ class _SingleOptimizerLoss(BaseLoss):
         # the FC core in one launch: lin1 -> lin2 -> mu_logvar -> reparameterise (+ KL partial blocks) -> lin1 -> lin2 -> lin3
         eng.fc_chain_fwd(buf, eps, sc.kl_dim, B)
         klb = eng.kl_blocks(B)            # single process: the one-launch loss epilogue finishes the KL partials
-        lat = {"rowstats": None, "dz": None, "dmu": None, "dlv": None}
+        lat = {"rowstats": None, "dz": None, "dmu": None, "dlv": None, "xbuf": None}
         btc = self.KIND == _lib.LOSS_BTCVAE
 
         def estimator():
@@ -431,7 +432,7 @@ class _SingleOptimizerLoss(BaseLoss):
             # while the decoder forward occupies the current one
             ew, er = self._est_world()            # the estimator's view of the sharding (local mode: one shard = one batch)
             Be = B * ew
-            with torch.cuda.stream(eng.side_stream):
+            with torch.cuda.stream(eng.aux_stream if world > 1 else eng.side_stream):
                 ss = _stream()
                 zg, mug, lvg = buf.z, buf.mu, buf.logvar
                 if ew > 1:
@@ -442,12 +443,15 @@ class _SingleOptimizerLoss(BaseLoss):
                      ptr(tc_tmp), ptr(rowstats), ss)
                 if is_train:
                     dz_x = sc.latent("dz_tc", B, D)
-                    cols = sc.latent("dcols_all", 2 * Be, D)         # (dmu, dlogvar) of ALL columns: two slabs of one buffer
-                    dmu_all, dlv_all = cols[:Be], cols[Be:]
+                    # (dmu, dlogvar) of ALL columns: two slabs of one buffer, followed by the packed loss sums -- sharded, the
+                    # lot is summed over the ranks by ONE all-reduce in the step's late epilogue (Comm.all_reduce_cols_sums)
+                    xbuf = sc.latent("xbuf", 1, 2 * Be * D + _lib.NPACK).view(-1)
+                    dmu_all, dlv_all = xbuf[:Be * D].view(Be, D), xbuf[Be * D:2 * Be * D].view(Be, D)
                     call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Be, D, er * B, B,
                          int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(tc_tmp), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), ss)
                     if ew > 1:
-                        dmu_x, dlv_x = self.comm.reduce_scatter_cols(dmu_all, dlv_all)
+                        lat["xbuf"] = xbuf
+                        dmu_x, dlv_x = dmu_all[er * B:(er + 1) * B], dlv_all[er * B:(er + 1) * B]
                     else:
                         dmu_x, dlv_x = dmu_all, dlv_all
                     if world > ew:                # local estimator: its mean runs over B, the loss over B * world
@@ -456,10 +460,13 @@ class _SingleOptimizerLoss(BaseLoss):
                     lat["dz"], lat["dmu"], lat["dlv"] = dz_x, dmu_x, dlv_x
 
         fuse = (data, self._rec_code(), sc.coef, sc.partials)
-        if btc:
-            eng.fork_side()
         if btc and world == 1:
+            eng.fork_side()
             estimator()
+        elif btc:
+            # sharded: the estimator with its exchanges on a stream of its own (engine.buffers: the side stream is the tail of
+            # the iteration, nothing may queue in front of its weight gradients)
+            call("dvae_stream_order", s, eng._aux_raw())
         # decoder convT stack; its last layer also evaluates the reconstruction likelihood and dL/dlogit
         eng.decode_convs(buf, B, fuse_loss=fuse)
         if btc and world > 1:
@@ -474,7 +481,10 @@ class _SingleOptimizerLoss(BaseLoss):
         # the all-reduce of the packed loss sums sits between the two halves of the epilogue, on the side stream as well.
         late_join = (is_train and not eng.single_stream and (btc or world > 1) and knob("DVAE_LATE_JOIN", "1") != "0")
         if btc and not late_join:
-            eng._join_side()
+            if world > 1:
+                call("dvae_stream_order", eng._aux_raw(), s)
+            else:
+                eng._join_side()
         if late_join:
             def epilogue():                       # after the next fork (the backward pass's first): no fork of its own
                 ss = eng._side_raw()
@@ -482,11 +492,20 @@ class _SingleOptimizerLoss(BaseLoss):
                     call("dvae_loss_epilogue", self.KIND, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), B, None, Bg,
                          ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), ss)
                 else:
+                    # on the exchange stream, behind the estimator; ordered after this stream's fork point through the side
+                    # stream (whose only queued work at this moment is the wait for that fork): no second event on this stream
+                    ss = eng._aux_raw()
+                    call("dvae_stream_order", eng._side_raw(), ss)
+                    xbuf = lat["xbuf"]
+                    packed = sc.packed if xbuf is None else xbuf[xbuf.numel() - _lib.NPACK:]
                     call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, ss)
-                    call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), ss)
-                    with torch.cuda.stream(eng.side_stream):
-                        self.comm.all_reduce(sc.packed)
-                    call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), ss)
+                    call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(packed), ss)
+                    with torch.cuda.stream(eng.aux_stream):
+                        if xbuf is None:
+                            self.comm.all_reduce(packed)
+                        else:                     # + the estimator's column gradients: one collective
+                            self.comm.all_reduce_cols_sums(xbuf, B, D, _lib.NPACK)
+                    call("dvae_loss_finalize", self.KIND, ptr(packed), D, Bg, ptr(sc.coef), ptr(sc.scal), ss)
                 call("dvae_event_record", self._ev_slot, ss)
             eng.at_next_fork(epilogue)
         elif world > 1:
@@ -509,17 +528,22 @@ class _SingleOptimizerLoss(BaseLoss):
         # one join, at the end of the backward pass.  Single process: ONE grouped launch for all six FC weight gradients
         # (issued by encode_backward).  Sharded: the decoder's three are launched with the decoder's conv weight gradients --
         # every kernel that writes a decoder gradient goes to the side stream, so the all-reduce of the decoder span is ordered
-        # behind the SIDE stream and overlaps the encoder backward; this stream never waits for it before the end
-        eng.decode_backward(buf.z, buf, join=False, defer_fc_wgrad=world == 1, fc_chain=fc_chain)
+        # behind the SIDE stream and overlaps the encoder backward; this stream never waits for it before the end.  Small shards
+        # (the dependency-driven schedule: the step is a latency chain, and every collective costs the host and both streams
+        # more than the overlap of 1 MB buys): ONE all-reduce of the whole arena after the final join.
+        spans = world > 1 and not eng.eager_wgrad
+        eng.decode_backward(buf.z, buf, join=False, defer_fc_wgrad=not spans, fc_chain=fc_chain)
         pending = []
-        if world > 1:
+        if spans:
             with torch.cuda.stream(eng.side_stream):
                 pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
         eng.encode_backward(data, buf, fc_chain=True)
-        if world > 1:
+        if spans:
             pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))
             for h_ in pending:
                 h_.wait()
+        elif world > 1:
+            self.comm.all_reduce(model.arena.grad)
 
 
 class BetaHLoss(_SingleOptimizerLoss):
@@ -729,20 +753,26 @@ class FactorKLoss(BaseLoss):
         # stream, an event slot marks it (as in the btcvae step)
         def epilogue(on_side):
             stream = eng._side_raw() if on_side else s
+            if world > 1 and on_side:             # sharded: the exchange stream (see the btcvae step), ordered through the side stream
+                stream = eng._aux_raw()
+                call("dvae_stream_order", eng._side_raw(), stream)
             if world == 1:
                 call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), klb, D, None, 0,
                      ptr(sc.disc_sums), Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), stream)
                 return
             call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, stream)
             call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), stream)
-            with torch.cuda.stream(eng.side_stream if on_side else torch.cuda.current_stream()):
+            with torch.cuda.stream(eng.aux_stream if on_side else torch.cuda.current_stream()):
                 self.comm.all_reduce(sc.packed)
             call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), stream)
+            if on_side:
+                call("dvae_event_record", self._ev_slot, stream)
         late_epi = not eng.single_stream and knob("DVAE_LATE_JOIN", "1") != "0"
         if late_epi:                          # after the next fork (the backward pass's first): no fork of its own
             def deferred():
                 epilogue(True)
-                call("dvae_event_record", self._ev_slot, eng._side_raw())
+                if world == 1:
+                    call("dvae_event_record", self._ev_slot, eng._side_raw())
             eng.at_next_fork(deferred)
         else:
             epilogue(False)
@@ -763,15 +793,18 @@ class FactorKLoss(BaseLoss):
 
         # one join, at the end of encode_backward; sharded: the decoder span's all-reduce is ordered behind the side stream
         # (every decoder gradient is written there) and overlaps the encoder backward
-        eng.decode_backward(buf.z, buf, n=Bh, join=False, defer_fc_wgrad=world == 1, fc_chain=fc_chain)
-        if world > 1:
+        spans = world > 1 and not eng.eager_wgrad      # small shards: ONE all-reduce of the whole VAE arena (see the btcvae step)
+        eng.decode_backward(buf.z, buf, n=Bh, join=False, defer_fc_wgrad=not spans, fc_chain=fc_chain)
+        if spans:
             with torch.cuda.stream(eng.side_stream):
                 pending.append(self.comm.all_reduce_async(model.arena.span("decoder.")))
         eng.encode_backward(data, buf, n=Bh, fc_chain=True)
-        if world > 1:
+        if spans:
             pending.append(self.comm.all_reduce_async(model.arena.span("encoder.")))
-            for h_ in pending:
-                h_.wait()
+        elif world > 1:
+            self.comm.all_reduce(model.arena.grad)
+        for h_ in pending:
+            h_.wait()
 
     def call_optimize(self, data, model, optimizer, storer, noise=None):
         """noise: optional (eps1[Bh,D], eps2[Bh,D], perms int64[D,Bh]) injected for parity;
@@ -847,8 +880,8 @@ class FactorKLoss(BaseLoss):
             return sc.scal[_lib.S_LOSS]
         model.assign_grads()
         disc.assign_grads()
-        optimizer.step()              # losses.py:307
-        self.optimizer_d.step()       # losses.py:308
+        optim.step(optimizer)         # optimizer.step(), losses.py:307
+        optim.step(self.optimizer_d)  # losses.py:308
         if storer is not None:
             vals = sc.scal.tolist()
             storer['recon_loss'].append(vals[_lib.S_REC])

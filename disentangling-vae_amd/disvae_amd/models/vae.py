@@ -145,7 +145,7 @@ class VAE(nn.Module):
             self._engine = VAEEngine(self.img_size, self.latent_dim, self._arena)
         return self._engine
 
-    FLAT_CHUNK = int(knob("DVAE_FLAT_CHUNK", 8192))
+    FLAT_CHUNK = int(knob("DVAE_FLAT_CHUNK", 16384))
 
     def _arena_chunks(self, grad=False):
         buf = self._arena.grad if grad else self._arena.flat

@@ -187,6 +187,13 @@ class Comm:
         self.reduce_scatter_into(out, send)
         return out[0], out[1]
 
+    def all_reduce_cols_sums(self, xbuf, B, D, n_tail):
+        """ONE sum-all-reduce for the two exchanges that end the beta-TCVAE estimator of a sharded step: xbuf =
+        [dmu of ALL world*B columns | dlogvar of all columns | n_tail packed loss sums] -- every rank then reads its own rows
+        of the two slabs (a reduce-scatter would move 1/world of the bytes, but at 80 KB both are one latency, and this is
+        one collective and no packing pass instead of two and one)."""
+        return self.all_reduce(xbuf)
+
     def close(self):
         pass
 
@@ -328,6 +335,20 @@ class MirroredWorldComm(Comm):
         self.inner.reduce_scatter_into(out, chunks[self.rank])
         if self.world_size > 1:
             add_scaled_(out, chunks[(self.rank + 1) % self.world_size], self.world_size - 1)
+
+    def all_reduce_cols_sums(self, xbuf, B, D, n_tail):
+        # column slabs: this rank's rows = own contribution (with the row-role terms) + (world - 1) x what it sends to a
+        # peer's rows; loss sums: world x the local ones.  The other ranks' rows of the slabs are not read.
+        W, r = self.world_size, self.rank
+        self.inner.all_reduce(xbuf)
+        n = B * D
+        if W > 1:
+            o = (r + 1) % W
+            for slab in (0, 1):
+                base = slab * W * n
+                add_scaled_(xbuf[base + r * n:base + (r + 1) * n], xbuf[base + o * n:base + (o + 1) * n], W - 1)
+        scale_(xbuf[2 * W * n:2 * W * n + n_tail], W)
+        return xbuf
 
     def broadcast(self, t, src=0):
         return self.inner.broadcast(t, src=0)

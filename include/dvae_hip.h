@@ -223,7 +223,7 @@ typedef struct {
   const float *b_e1, *b_e2, *b_ml, *b_d1, *b_d2, *b_d3;     /* their biases */
   const float* eps;                                         /* [n_enc,D] N(0,1) draws; NULL: z = mu (eval mode) */
   float *h1, *h2, *ml, *mu, *logvar, *z;                    /* [n_enc,256] x2, [n_enc,2D] (interleaved), [n_enc,D] x3 */
-  float* kl_part;                                           /* [ceil(n_enc/8),16] partial blocks (= kl_dim + 16) or NULL */
+  float* kl_part;                                           /* [ceil(n_enc/dvae_fc_chain_rows(n_enc)),16] partial blocks (= kl_dim + 16) or NULL */
   float *d1, *d2, *d3;                                      /* [n_dec,256] x2, [n_dec,512] */
   int n_enc, n_kl, n_dec, D;
 } dvae_fc_chain_fwd_args;
@@ -239,6 +239,10 @@ typedef struct {
 } dvae_fc_chain_bwd_args;
 int dvae_fc_chain_fwd(const dvae_fc_chain_fwd_args* args, void* stream);
 int dvae_fc_chain_bwd(const dvae_fc_chain_bwd_args* args, void* stream);
+/* Batch rows one workgroup of the chain kernels owns in a launch over n rows (4 up to 1024 rows, 8 above: small batches get
+ * twice the workgroups, each with half the matrix-core work) = the granularity of the forward's KL partial blocks:
+ * dvae_fc_chain_fwd over n_enc rows leaves ceil(n_enc / dvae_fc_chain_rows(n_enc)) of them at kl_part.               */
+int dvae_fc_chain_rows(int n);
 
 /* ---- reparameterisation + per-dim Gaussian KL: vae.py:52-71, losses.py:452-480 -----------
  * ml[B,2D] is the interleaved output of mu_logvar_gen (encoders.py:87: mu = ml[:,0::2],
@@ -338,7 +342,7 @@ int dvae_loss_finalize(int kind, const float* packed, int D, int Bg, const float
                        void* stream);
 /* Un-sharded batches: dvae_loss_pack and dvae_loss_finalize in ONE launch (scal == NULL: pack only).
  * kl_blocks > 0: kl_dim + 16 holds that many un-finished partial blocks (dvae_reparam_kl_fwd(coef = NULL):
- * dvae_reparam_kl_blocks(B) of them; dvae_fc_chain_fwd: ceil(n_enc / 8)); they are summed (same order as
+ * dvae_reparam_kl_blocks(B) of them; dvae_fc_chain_fwd: ceil(n_enc / dvae_fc_chain_rows(n_enc))); they are summed (same order as
  * dvae_kl_finish) and scaled by coef[INV_B].  kl_blocks == 0: kl_dim[0,D) is final.                 */
 int dvae_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_blocks, int D,
                        const float* rowstats, int Bl, const float* disc_sums, int Bg,
@@ -351,6 +355,25 @@ int dvae_set_coef(float* coef, float c0, float c1, float c2, float c3, float c4,
 
 /* out[i] = a[i] + b[i] (n elements), helper for merging latent gradients (quirk Q1).       */
 int dvae_add(const float* a, const float* b, float* out, long n, void* stream);
+
+/* ---- torch.optim.Adam's update as one launch (main.py:208, losses.py:238: the optimizers; training.py:158,
+ * losses.py:307-308: their step()) ------------------------------------------------------------------------------------
+ * The optimizer object, its hyper-parameters and its state tensors stay the caller's (torch's): this runs the element-wise
+ * arithmetic of Adam.step() -- amsgrad off, maximize off, L2 weight decay added to the gradient -- over `nt` tensors:
+ *   g' = g + wd p;  m += (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g'^2;
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),   t = step_new
+ * and writes t into every tensor's `step` slot (fp32 scalar on the device, as torch's fused Adam keeps it; may be NULL).
+ * `tensors` is HOST memory (copied into the launch).  Within 1 ulp of the parameter of torch's implementations.          */
+typedef struct {
+  float* p;            /* parameter [n] */
+  const float* g;      /* gradient [n] */
+  float* m;            /* exp_avg [n] */
+  float* v;            /* exp_avg_sq [n] */
+  float* step;         /* state["step"]: one float on the device, or NULL */
+  long n;
+} dvae_adam_tensor;
+int dvae_adam_step(const dvae_adam_tensor* tensors, int nt, float step_new, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, void* stream);
 
 /* ---- glue of the data-parallel step (new: the reference is single-process; disvae_amd/parallel.py) -------------------
  * out[i] = alpha * a[i] + beta * b[i] (b may be NULL: out = alpha * a; out may alias a or b): the 1 / world factors of means

@@ -45,8 +45,9 @@ def test_plan_ops_cover_the_launching_entry_points():
     launch (no GPU needed) and runs an argument-checked call through its trampoline (the NULL-pointer error comes back)."""
     h = _lib.lib()
     not_replayable = {"dvae_version", "dvae_last_error", "dvae_conv_wgrad_ws_floats", "dvae_latent_entropy_ws_floats",
-                      "dvae_reparam_kl_blocks", "dvae_u8_fused_supported", "dvae_plan_op", "dvae_plan_run", "dvae_comm_load",
-                      "dvae_comm_unique_id", "dvae_comm_init", "dvae_comm_destroy", "dvae_comm_world", "dvae_comm_rank"}
+                      "dvae_reparam_kl_blocks", "dvae_fc_chain_rows", "dvae_u8_fused_supported", "dvae_plan_op", "dvae_plan_run", "dvae_comm_load",
+                      "dvae_comm_unique_id", "dvae_comm_init", "dvae_comm_destroy", "dvae_comm_world", "dvae_comm_rank",
+                      "dvae_adam_step"}        # (step count and learning rate change every iteration: issued directly)
     for name in _lib.SIGNATURES:
         assert (h.dvae_plan_op(name.encode()) >= 0) == (name not in not_replayable), name
     assert h.dvae_plan_op(b"no_such_entry_point") == -1
@@ -86,7 +87,8 @@ def test_argument_structs_have_the_headers_layout(tmp_path):
         pytest.skip("needs gcc")
     pairs = [("dvae_conv_image_desc", _lib.ConvImageDesc), ("dvae_fc_image_desc", _lib.FcImageDesc),
              ("dvae_thin_image_desc", _lib.ThinImageDesc), ("dvae_fc_chain_fwd_args", _lib.FcChainFwdArgs),
-             ("dvae_fc_chain_bwd_args", _lib.FcChainBwdArgs), ("dvae_plan_entry", _lib.PlanEntry)]
+             ("dvae_fc_chain_bwd_args", _lib.FcChainBwdArgs), ("dvae_plan_entry", _lib.PlanEntry),
+             ("dvae_adam_tensor", _lib.AdamTensor)]
     body = []
     for cname, cls in pairs:
         body.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

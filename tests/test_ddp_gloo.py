@@ -145,6 +145,16 @@ def _worker_mirrored(port, q):
             assert torch.equal(da, a[sl] + (W - 1) * a[nx]) and torch.equal(db, 2 * (a[sl] + (W - 1) * a[nx]))
             t = comm.all_reduce(torch.ones(6))
             assert (t == W).all()
+            # the estimator's merged exchange: [dmu of all W*B columns | dlogvar | tail of loss sums] in ONE all-reduce
+            n, tail = B * D, 4
+            x0 = torch.arange(2 * W * n + tail, dtype=torch.float32)
+            x = comm.all_reduce_cols_sums(x0.clone(), B, D, tail)
+            o = (rank + 1) % W
+            for slab in (0, 1):
+                base = slab * W * n
+                own, peer = x0[base + rank * n:base + (rank + 1) * n], x0[base + o * n:base + (o + 1) * n]
+                assert torch.equal(x[base + rank * n:base + (rank + 1) * n], own + (W - 1) * peer)
+            assert torch.equal(x[2 * W * n:], W * x0[2 * W * n:])
             u = torch.full((5,), 3.0)
             h = comm.all_reduce_async(u)
             h.wait()

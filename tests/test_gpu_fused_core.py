@@ -179,7 +179,9 @@ def test_fc_chain_forward(n_enc, n_kl, n_dec, D, noise):
     check(out["logvar"], lv, what="chain logvar", **tol)
     check(out["z"], z, what="chain z", **tol)
     klref = (0.5 * (-1 - lv + mu * mu + torch.exp(lv)))[:n_kl].sum(0)
-    nblk = (n_enc + 7) // 8
+    rows = _lib.fc_chain_rows(n_enc)                 # 4 rows per workgroup up to 1024 batch rows, 8 above (dvae_fc_chain_rows)
+    assert rows == (4 if n_enc <= 1024 else 8)
+    nblk = (n_enc + rows - 1) // rows
     parts = kl[16:16 + nblk * 16].view(nblk, 16).cpu().double()
     check(parts.sum(0)[:D], klref, rtol=1e-5, atol_rel=2e-6, what="chain KL partial blocks")
     assert torch.all(parts[:, D:] == 0)

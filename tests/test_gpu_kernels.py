@@ -469,3 +469,25 @@ def test_linear_wgrad_grouped(M):
     arr2, addr2 = _lib.wgrad_descs([probs[3], (p0[0], p0[1], ptr(dw2), ptr(db2), M, p0[5], p0[6]), probs[4]])
     call("dvae_linear_wgrad_grouped", addr2, 3, stream())
     assert torch.equal(dw2, outs[0][0]) and torch.equal(db2, outs[0][1])
+
+
+def test_data_parallel_glue_kernels():
+    """dvae_axpby (out = alpha a [+ beta b], in place allowed) and dvae_swap_outer (src [A][Bn][inner] -> dst [Bn][A][inner]):
+    the element-wise glue of the sharded step (disvae_amd/parallel.py) against torch."""
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 7, 1280, 65537):
+        a, b = torch.randn(n, generator=g), torch.randn(n, generator=g)
+        ad, bd, od = dev(a), dev(b), dev(torch.zeros(n))
+        call("dvae_axpby", ptr(od), ptr(ad), 0.125, ptr(bd), 7.0, n, stream())
+        torch.testing.assert_close(od.cpu(), 0.125 * a + 7.0 * b, rtol=2e-7, atol=1e-6)     # (the device contracts to an fma)
+        call("dvae_axpby", ptr(od), ptr(ad), 3.0, None, 0.0, n, stream())
+        assert torch.equal(od.cpu(), 3.0 * a)
+        call("dvae_axpby", ptr(ad), ptr(ad), 8.0, None, 0.0, n, stream())             # in place: the mirrored world's x world_size
+        assert torch.equal(ad.cpu(), 8.0 * a)
+        call("dvae_axpby", ptr(bd), ptr(bd), 1.0, ptr(od), 7.0, n, stream())          # out aliases a: out += beta * b
+        torch.testing.assert_close(bd.cpu(), b + 7.0 * (3.0 * a), rtol=2e-7, atol=1e-6)
+    for A, Bn, inner in ((8, 3, 1280), (2, 8, 1280), (3, 5, 7), (1, 4, 33), (4, 1, 10)):
+        src = torch.randn(A, Bn, inner, generator=g)
+        sd, dd = dev(src), dev(torch.zeros(Bn, A, inner))
+        call("dvae_swap_outer", ptr(sd), ptr(dd), A, Bn, inner, stream())
+        assert torch.equal(dd.cpu(), src.permute(1, 0, 2).contiguous()), (A, Bn, inner)
