@@ -42,6 +42,12 @@ import sys
 import time
 from collections import defaultdict
 
+# one hardware queue per stream of the step (the caller's, the weight-gradient stream, the exchange and communication streams of
+# a sharded step, RCCL's own): with HIP's default of 4, streams alias onto shared queues and serialise (measured at 128 images
+# per GPU: 0.372 -> 0.494 ms once a fifth stream exists, profiles/r05_v14_hw_queues.txt).  Must be set before HIP initialises;
+# disvae_amd/__init__.py sets the same default for library users
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "disentangling-vae_amd")):
     if p not in sys.path:
@@ -631,7 +637,7 @@ def host_issue_ms(step_fn, n=30):
     return sorted(ts)[len(ts) // 2] * 1e3
 
 
-def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single", "torch", "rccl")):
+def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single", "rccl", "torch")):
     """BASELINE configs[3] as ONE of its eight ranks runs it, on this one GPU: 128 images per step through the SHARDED code
     path of the btcvae step (disvae_amd.parallel: packed latent all-gather, the rank's 128 rows of the 1024-column B x B
     estimator, packed column-gradient reduce-scatter, loss-sum all-reduce, the gradient arena all-reduced in two spans under
@@ -705,7 +711,7 @@ def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
             parallel.init_process_group_from_env("nccl")
             own_group = True
-        out["transports"] = {t: leg(t) for t in ("torch", "rccl") if t in which}
+        out["transports"] = {t: leg(t) for t in ("rccl", "torch") if t in which}
         if len(out["transports"]) == 2:
             a, b = out["transports"]["torch"]["ms_per_step"], out["transports"]["rccl"]["ms_per_step"]
             out["transports_rel_diff"] = round(abs(a - b) / min(a, b), 4)
