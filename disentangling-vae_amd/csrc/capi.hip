@@ -92,8 +92,9 @@ int dvae_conv4s2_dgrad(const float* dy, int dy_layout, const float* w, const flo
 int dvae_conv4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_layout, float* dw, float* db, int N,
                        int Cin, int H, int W, int Cout, float* ws, void* stream) {
   DVAE_CHECK_ARG(x && dy && dw && N > 0 && (H % 2 == 0) && (W % 2 == 0));
-  return run_wgrad(x, x_layout, dy, dy_layout, dw, db, /*bias_from_big=*/0, N, Cin, Cout, H / 2, W / 2, ws,
+  const int rc = run_wgrad(x, x_layout, dy, dy_layout, dw, db, /*bias_from_big=*/0, N, Cin, Cout, H / 2, W / 2, ws,
                    (hipStream_t)stream);
+  return rc;
 }
 
 int dvae_convT4s2_fwd(const float* x, int x_layout, const float* w, const float* b, float* y, int y_layout, int N,
@@ -116,8 +117,9 @@ int dvae_convT4s2_dgrad(const float* dy, int dy_layout, const float* w, const fl
 int dvae_convT4s2_wgrad(const float* x, int x_layout, const float* dy, int dy_layout, float* dw, float* db, int N,
                         int Cin, int H, int W, int Cout, float* ws, void* stream) {
   DVAE_CHECK_ARG(x && dy && dw && N > 0);
-  return run_wgrad(dy, dy_layout, x, x_layout, dw, db, /*bias_from_big=*/1, N, Cout, Cin, H, W, ws,
+  const int rc = run_wgrad(dy, dy_layout, x, x_layout, dw, db, /*bias_from_big=*/1, N, Cout, Cin, H, W, ws,
                    (hipStream_t)stream);
+  return rc;
 }
 
 int dvae_convT4s2_sigmoid_recon_fwd(const float* x, int x_layout, const float* w, const float* b, const float* target,

@@ -99,6 +99,27 @@ __device__ __forceinline__ float recon_elem(float p, float x, int dist, float* g
   return term;
 }
 
+// sigmoid + Bernoulli likelihood term + dL/dlogit from the LOGIT v (losses.py:430: F.binary_cross_entropy(sigmoid(v), x)).
+// With e = exp(-|v|), s = 1 + e:  p = (v >= 0 ? 1 : e) / s  and  -[x log p + (1 - x) log(1 - p)] = log(s) + max(v, 0) - x v
+// (both logarithms of ATen's form share log(s)); ATen's clamp of each logarithm at -100 = v clamped to [-100, 100] in the
+// last two terms.  Three transcendentals per output (exp, rcp, log) instead of four and a third of recon_elem's vector
+// instructions: the likelihood was 28 of the 86 us of convT3's fused forward at 1024 images (profiles/r05_v17).
+// *gl = dL/dlogit as recon_elem's: (p - x), scaled down where (1 - p) p < 1e-12 (ATen's backward clamp).
+__device__ __forceinline__ float sigmoid_bce_logit(float v, float x, float* p_out, float* gl) {
+  const float e = __expf(-fabsf(v));
+  const float s = 1.f + e;
+  const float r = __builtin_amdgcn_rcpf(s);
+  const float p = v >= 0.f ? r : e * r;
+  const float vc = fminf(fmaxf(v, -100.f), 100.f);
+  // log(s), s in [1, 2]: v_log_f32 (log2, ~1 ulp) x ln 2 -- __logf() expands to a denormal-safe, extended-precision sequence of
+  // 12 instructions here
+  const float term = __builtin_amdgcn_logf(s) * 0.69314718056f + fmaxf(vc, 0.f) - x * vc;
+  const float qq = (1.f - p) * p, d = p - x;
+  *gl = qq >= 1e-12f ? d : d * 1e12f * qq;
+  *p_out = p;
+  return term;
+}
+
 // ---- launchers implemented in the individual .hip files ---------------------------------
 // "down": big[N,Cb,2Hs,2Ws] -> small[N,Cs,Hs,Ws]  (Conv2d fwd, ConvTranspose2d dgrad)
 // "up"  : small -> big                           (ConvTranspose2d fwd, Conv2d dgrad)
@@ -197,6 +218,8 @@ static __host__ __device__ __forceinline__ int thin_pair_source(int idx, int C, 
   *cb = C - 1;
   return taps[C == 3 ? idx - 32 : idx];
 }
+int launch_up_thin_mm(const float* small, const float* wimg, const float* bias, const void* target, int target_u8, float* out,
+                      float* g, int dist, const float* coef, float* partials, int N, int act, hipStream_t s);
 int launch_up_thin_staged(const float* small, const float* wrec, const float* bias, const void* target, int target_u8,
                           float* out, float* g, int dist, const float* coef, float* partials, int N, int C, int act,
                           hipStream_t s);

@@ -383,6 +383,7 @@ __global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ sm
   const int tid = threadIdx.x;
   const int m = tid >> 5, l = tid & 31;
   const float gs = FUSE ? coef[DVAE_C_INV_B] : 0.f;
+  const bool bce_logit = FUSE && dist == DVAE_REC_BERNOULLI && act == DVAE_ACT_SIGMOID;
   float lsum = 0.f;
   // Consecutive workgroups run on different XCDs (each with its own L2), and the 8 units of an image share halo rows: with the
   // plain round-robin order they were fetched from HBM by two XCDs each (counter traffic 1.32x the algorithmic bytes).  When
@@ -501,9 +502,20 @@ __global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ sm
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
           float v0 = acc[py * 2 + 0][cb] + bv, v1 = acc[py * 2 + 1][cb] + bv;
+          const long o = ((((long)n * C + cb) * 64) + 2 * sy + py) * 64 + 2 * l;
+          if (FUSE && bce_logit) {
+            // sigmoid + Bernoulli likelihood straight from the logit (common.h: sigmoid_bce_logit), workgroup-uniform branch
+            float xt0 = tg[cb][py].x, xt1 = tg[cb][py].y;
+            if constexpr (sizeof(TT) != 4) { xt0 = xt0 / 255.0f; xt1 = xt1 / 255.0f; }
+            float p0, p1, gl0, gl1;
+            lsum += sigmoid_bce_logit(v0, xt0, &p0, &gl0);
+            lsum += sigmoid_bce_logit(v1, xt1, &p1, &gl1);
+            *reinterpret_cast<float2*>(out + o) = make_float2(p0, p1);
+            *reinterpret_cast<float2*>(g + o) = make_float2(gs * gl0, gs * gl1);
+            continue;
+          }
           if (act == DVAE_ACT_SIGMOID) { v0 = sigmoid_hw(v0); v1 = sigmoid_hw(v1); }
           else if (act == DVAE_ACT_RELU) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-          const long o = ((((long)n * C + cb) * 64) + 2 * sy + py) * 64 + 2 * l;
           *reinterpret_cast<float2*>(out + o) = make_float2(v0, v1);
           if (FUSE) {
             float xt0 = tg[cb][py].x, xt1 = tg[cb][py].y;
@@ -532,6 +544,9 @@ int launch_up_thin_staged(const float* small, const float* wrec, const float* bi
                           float* out, float* g, int dist, const float* coef, float* partials, int N, int C, int act,
                           hipStream_t s) {
   if (C != 1 && C != 3) return 1;
+  // 3 channels: the matrix-core formulation (conv_up_thin_mm.hip) on the operand image behind the pair records
+  if (C == 3 && launch_up_thin_mm(small, wrec + 32 * 48, bias, target, target_u8, out, g, dist, coef, partials, N, act, s) == 0)
+    return 0;
   const int n_units = N * 8;
   const int grid = n_units < 1536 ? n_units : 1536;
 #define UP_PK(CC, FF, TT_) hipLaunchKernelGGL((k_up_thin_pk<CC, FF, TT_>), dim3(grid), dim3(128), 0, s, small, wrec, bias, out, N, act, \

@@ -72,14 +72,25 @@ __global__ __launch_bounds__(256) void k_stage_weights(StageTable t) {
     reinterpret_cast<f32x4*>(g.img)[c] = v;
   } else if (g.kind == SEG_THIN_PAIRS) {
     // per contracted channel cs a record of REC floats in the pair order of k_up_thin_pk (conv_thin.hip); g.N = C
-    const int REC = DVAE_THIN_PAIR_FLOATS(g.N);
-    if (c >= 32 * REC / 4) return;
+    // C = 3: behind the 32 records, the A-operand image of the matrix-core forward kernel (k_up_thin_mm, conv_up_thin_mm.hip):
+    // float (tap * 8 + i) * 64 + lane = W'[m = lane % 16][(a, b, cs = 8 (lane / 16) + i)], tap = 2 a + b, output row
+    // m = 4 c + 2 dy + dx (rows 12..15 zero) = w[cs][c][kh = 2 - 2a + dy][kw = 2 - 2b + dx]
+    const int REC = g.N == 3 ? 48 : 16;
+    if (c >= 32 * DVAE_THIN_PAIR_FLOATS(g.N) / 4) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int o = (int)c * 4 + r, cs = o / REC, idx = o % REC;
-      int cb;
-      const int tap = thin_pair_source(idx, g.N, &cb);
-      v[r] = g.w[(cs * g.N + cb) * 16 + tap];
+      const int o = (int)c * 4 + r;
+      if (o < 32 * REC) {
+        const int cs = o / REC, idx = o % REC;
+        int cb;
+        const int tap = thin_pair_source(idx, g.N, &cb);
+        v[r] = g.w[(cs * g.N + cb) * 16 + tap];
+      } else {
+        const int q = o - 32 * REC, mf = q >> 6, ln = q & 63;
+        const int m = ln & 15, cs = 8 * (ln >> 4) + (mf & 7), a = mf >> 4, b = (mf >> 3) & 1;
+        const int cch = m >> 2, dy = (m >> 1) & 1, dx = m & 1;
+        v[r] = m < 12 ? g.w[(cs * 3 + cch) * 16 + (2 - 2 * a + dy) * 4 + (2 - 2 * b + dx)] : 0.f;
+      }
     }
     reinterpret_cast<f32x4*>(g.img)[c] = v;
   } else {

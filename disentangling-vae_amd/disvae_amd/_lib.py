@@ -132,7 +132,7 @@ class ThinImageDesc(ctypes.Structure):
 
 def thin_pair_floats(C):
     """DVAE_THIN_PAIR_FLOATS(C)."""
-    return 48 if C == 3 else 16
+    return 112 if C == 3 else 16
 
 
 class FcChainFwdArgs(ctypes.Structure):

@@ -366,7 +366,9 @@ class VAEEngine:
 
     def _conv_wgrad(self, fn, *args, fork=True, main=False):
         """Conv / convT weight gradient `fn(*args, ws, stream)`: off the dgrad critical path, so it
-        goes to the side stream (after a fork) and co-runs with the dgrad chain (main=True: the current stream)."""
+        goes to the side stream (after a fork) and co-runs with the dgrad chain (main=True: the current stream).
+        (Capping the side stream's chip-filling launches at 96-224 workgroups so that the other stream's short kernels find
+        free CUs measured 0.3-4.7 % SLOWER at 1024 images: profiles/r05_v23_side_cap_ab.txt.)"""
         if fork and not main:
             self.fork_side()
         call(fn, *args, ptr(self._ws if main else self._ws_side), _stream() if main else self._side_raw())

@@ -95,7 +95,9 @@ size_t dvae_conv_wgrad_ws_floats(void);
  * (skipped).  `conv`, `fc`, `thin`, `coef_vals` are HOST arrays / structs read during the call.                         */
 #define DVAE_STAGE_MAX_CONV 6
 #define DVAE_STAGE_MAX_FC 8
-#define DVAE_THIN_PAIR_FLOATS(C) ((C) == 3 ? 48 : 16)   /* per contracted channel: see conv_thin.hip, k_up_thin_pk */
+#define DVAE_THIN_PAIR_FLOATS(C) ((C) == 3 ? 112 : 16)  /* per contracted channel: the pair record of k_up_thin_pk (48 / 16 floats,
+                                                          conv_thin.hip) and, C = 3, 64 floats of the matrix-core forward kernel's
+                                                          operand image (k_up_thin_mm: 2048 floats behind the 32 records) */
 typedef struct {
   const float* w;       /* Conv2d [32,32,4,4] or ConvTranspose2d [32,32,4,4] weight = w[cs][cb][kh][kw] */
   float* img_down;      /* consumed by dvae_conv32_down */
@@ -109,7 +111,7 @@ typedef struct {
 } dvae_fc_image_desc;
 typedef struct {
   const float* w;       /* the last decoder layer's ConvTranspose2d weight [32,C,4,4] (decoders.py:65), C in {1, 3} */
-  float* img_pairs;     /* 32 * DVAE_THIN_PAIR_FLOATS(C) floats: operand pairs of the packed-FMA forward kernel */
+  float* img_pairs;     /* 32 * DVAE_THIN_PAIR_FLOATS(C) floats: operand pairs of the packed-FMA forward kernel (+ the matrix-core image) */
   int C;
 } dvae_thin_image_desc;
 int dvae_stage_weights(const dvae_conv_image_desc* conv, int n_conv, const dvae_fc_image_desc* fc, int n_fc,

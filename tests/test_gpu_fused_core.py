@@ -289,11 +289,25 @@ def _thin_records(w):
                     r += [wt[cs, 0, tap], wt[cs, 1, tap]]
         r += [wt[cs, C - 1, tap] for tap in plane]
         rec.append(torch.stack(r))
-    return torch.stack(rec).reshape(-1)
+    out = torch.stack(rec).reshape(-1)
+    if C == 3:
+        # behind the records: the A-operand image of the matrix-core kernel (k_up_thin_mm, conv_up_thin_mm.hip): float
+        # (tap * 8 + i) * 64 + lane = w[cs = 8 (lane / 16) + i][c][kh = 2 - 2a + dy][kw = 2 - 2b + dx] for output row
+        # m = lane % 16 = 4 c + 2 dy + dx (rows 12..15: zero), tap = 2 a + b: the 2 x 2 input window -> 2 x 2 output block form
+        img = torch.zeros(32, 64)
+        for mf in range(32):
+            a, b, i = mf >> 4, (mf >> 3) & 1, mf & 7
+            for ln in range(64):
+                m, cs = ln & 15, 8 * (ln >> 4) + i
+                if m < 12:
+                    c, dy, dx = m >> 2, (m >> 1) & 1, m & 1
+                    img[mf, ln] = w[cs, c, 2 - 2 * a + dy, 2 - 2 * b + dx]
+        out = torch.cat((out, img.reshape(-1)))
+    return out
 
 
 @pytest.mark.parametrize("C", [1, 3])
-@pytest.mark.parametrize("N", [3, 300])
+@pytest.mark.parametrize("N", [1, 3, 86, 300])
 def test_convT3_forward_on_staged_pair_records(N, C):
     """The last decoder layer (decoders.py:82) as the packed-FMA kernel on the records of dvae_stage_weights: the records bit
     for bit; reconstruction, likelihood partial sums (losses.py:394-449) and dL/dlogit vs the raw-weight entry points
@@ -334,7 +348,24 @@ def test_convT3_forward_on_staged_pair_records(N, C):
         check(r1, r0.cpu(), what="fused recon dist %d" % dist, **tol)
         check(g1, g0.cpu(), rtol=1e-4, atol_rel=2e-6, what="fused dL/dlogit dist %d" % dist)
         check(p1.sum(), p0.sum().cpu(), rtol=1e-5, what="fused loss sum dist %d" % dist)
-        assert torch.equal(r2, r1) and torch.equal(g2, g1) and torch.equal(p2, p1), "uint8 target == ToTensor(target), dist %d" % dist
+        if C == 1:
+            assert torch.equal(r2, r1) and torch.equal(g2, g1) and torch.equal(p2, p1), "uint8 target == ToTensor(target), dist %d" % dist
+        else:       # fp32 targets: the matrix-core kernel; uint8 targets: the packed-FMA kernel (another summation order)
+            check(r2, r1.cpu(), what="uint8-target recon dist %d" % dist, **tol)
+            check(g2, g1.cpu(), rtol=1e-4, atol_rel=2e-6, what="uint8-target dL/dlogit dist %d" % dist)
+            check(p2.sum(), p1.sum().cpu(), rtol=1e-5, what="uint8-target loss sum dist %d" % dist)
+        # against fp64: likelihood sum and dL/dlogit of the fp32-target launch
+        xr64 = x.cpu().permute(0, 3, 1, 2).double()
+        logit = F.conv_transpose2d(xr64, w.double(), b.double(), stride=2, padding=1)
+        pr, t64 = torch.sigmoid(logit), tgt.double()
+        if dist == 0:
+            tot = F.binary_cross_entropy(pr, t64, reduction="sum"); gref = (pr - t64) / N
+        elif dist == 1:
+            tot = ((255 * pr - 255 * t64) ** 2).sum() / 255; gref = 2 * 255 * (pr - t64) * pr * (1 - pr) / N
+        else:
+            tot = 3 * (pr - t64).abs().sum(); gref = 3 * torch.sign(pr - t64) * pr * (1 - pr) / N
+        check(p1.sum(), tot, rtol=1e-5, what="fused loss sum vs fp64 dist %d" % dist)
+        check(g1, gref, rtol=1e-4, atol_rel=4e-6, what="fused dL/dlogit vs fp64 dist %d" % dist)
 
 
 def test_event_slots_order_a_late_consumer_after_marked_work():
