@@ -777,10 +777,13 @@ class FactorKLoss(BaseLoss):
         else:
             epilogue(False)
         # discriminator backward of d_tc_loss (weight grads + dz), losses.py:303-304
-        dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g")
+        # (its six weight gradients: on the side stream, behind one fork after the input-gradient chain)
+        side_wg = not eng.single_stream and knob("DVAE_DISC_WGRAD_SIDE", "1") != "0"
+        dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g", side=eng if side_wg else None)
         pending = []
         if world > 1:      # the 16 MB discriminator gradients are final: their all-reduce runs under the whole VAE backward
-            pending.append(self.comm.all_reduce_async(disc.arena.grad))
+            with torch.cuda.stream(eng.side_stream if side_wg else torch.cuda.current_stream()):
+                pending.append(self.comm.all_reduce_async(disc.arena.grad))
         # tc term of vae_loss through D: dgrad only, first half (its disc weight grads are zeroed at :303)
         dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2")
 
