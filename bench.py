@@ -293,7 +293,8 @@ def thin_kernel_rooflines(B, C, device):
     launches = [
         (k_fwd, "conv1 fwd (emits the bit plane)", nx + na + nb,
          lambda: call("dvae_conv1_fwd_bits", ptr(x), 0, ptr(w), ptr(b32), ptr(ga1), ptr(bits), B, C, s)),
-        ("k_up_thin_pk<%d, true, float>" % C, "convT3 fwd + sigmoid + likelihood + dL/dlogit (staged pair records)", na + 3 * nx,
+        ("k_up_thin_mm<true, 0, float>" if C == 3 else "k_up_thin_pk<1, true, float>",
+         "convT3 fwd + sigmoid + likelihood + dL/dlogit (%s)" % ("matrix cores, 2 x 2-window form" if C == 3 else "packed FMAs"), na + 3 * nx,
          lambda: call("dvae_convT3_fwd_staged", ptr(a1), ptr(pairs), ptr(bc), ptr(x), 0, ptr(rec), ptr(g), 0, ptr(coef),
                       ptr(parts), B, C, s)),
         (k_dg, "convT3 dgrad (masked by the bit plane)", nx + na + nb,

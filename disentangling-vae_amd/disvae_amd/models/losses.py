@@ -152,9 +152,16 @@ class BaseLoss(abc.ABC):
     # one HIP stream instead of two below this many input elements per step (engine.single_stream); DVAE_STREAMS=1|2 forces
     SINGLE_STREAM_ELEMS = int(knob("DVAE_SINGLE_STREAM_ELEMS", 64 * 3 * 64 * 64))   # measured: profiles/r02_run10_streams.txt
 
-    # dependency-driven weight-gradient schedule (engine.eager_wgrad) up to this many input elements per step; above, the
-    # batch-sized schedule (measured cross-over: profiles/r03_*sweep*)
-    EAGER_WGRAD_ELEMS = int(knob("DVAE_EAGER_WGRAD_ELEMS", 384 * 3 * 64 * 64))
+    # dependency-driven weight-gradient schedule (engine.eager_wgrad: a fork per layer) up to this many input elements per
+    # step; above, the batch-sized schedule (two forks per half of the backward pass).  Round 3 measured the two within noise
+    # of each other up to 384 images; with the round-5 kernels the batch-sized schedule wins at every batch measured (128
+    # images: 0.349 vs 0.359 ms, btcvae_dsprites 0.421 vs 0.433 ms: profiles/r05_v25_schedule_ab.txt) -- each fork costs the
+    # critical path an event and the small weight gradients it frees early are not what the iteration waits for
+    EAGER_WGRAD_ELEMS = int(knob("DVAE_EAGER_WGRAD_ELEMS", 0))
+    # sharded batches up to this many input elements per rank: ONE all-reduce of the whole gradient arena at the end instead of
+    # two overlapped spans (the step is a latency chain; every collective costs the host and both streams more than the
+    # overlap of 1 MB buys)
+    SMALL_SHARD_ELEMS = 384 * 3 * 64 * 64
 
     def _streams(self, model, data):
         mode = knob("DVAE_STREAMS", "auto")
@@ -529,9 +536,9 @@ class _SingleOptimizerLoss(BaseLoss):
         # (issued by encode_backward).  Sharded: the decoder's three are launched with the decoder's conv weight gradients --
         # every kernel that writes a decoder gradient goes to the side stream, so the all-reduce of the decoder span is ordered
         # behind the SIDE stream and overlaps the encoder backward; this stream never waits for it before the end.  Small shards
-        # (the dependency-driven schedule: the step is a latency chain, and every collective costs the host and both streams
-        # more than the overlap of 1 MB buys): ONE all-reduce of the whole arena after the final join.
-        spans = world > 1 and not eng.eager_wgrad
+        # (SMALL_SHARD_ELEMS: the step is a latency chain, and every collective costs the host and both streams more than the
+        # overlap of 1 MB buys): ONE all-reduce of the whole arena after the final join.
+        spans = world > 1 and data.numel() > self.SMALL_SHARD_ELEMS
         eng.decode_backward(buf.z, buf, join=False, defer_fc_wgrad=not spans, fc_chain=fc_chain)
         pending = []
         if spans:
@@ -796,7 +803,7 @@ class FactorKLoss(BaseLoss):
 
         # one join, at the end of encode_backward; sharded: the decoder span's all-reduce is ordered behind the side stream
         # (every decoder gradient is written there) and overlaps the encoder backward
-        spans = world > 1 and not eng.eager_wgrad      # small shards: ONE all-reduce of the whole VAE arena (see the btcvae step)
+        spans = world > 1 and data.numel() > self.SMALL_SHARD_ELEMS      # small shards: ONE all-reduce of the whole VAE arena (see the btcvae step)
         eng.decode_backward(buf.z, buf, n=Bh, join=False, defer_fc_wgrad=not spans, fc_chain=fc_chain)
         if spans:
             with torch.cuda.stream(eng.side_stream):

@@ -387,3 +387,29 @@ def test_kernel_addressing_emulations(script):
         planes = [int(v) for v in re.findall(r"static constexpr int PLANE = (\d+);", src)]
         zz = [int(v) for v in re.findall(r"static constexpr int ZZ = (\d+);", src)]
         assert planes == [ns["PLANE_D"], ns["PLANE_W"]] and zz == [ns["ZZ"], ns["ZZ"]], (planes, zz)
+
+
+@pytest.mark.parametrize("loss", ["VAE", "betaH", "betaB", "factor", "btcvae"])
+def test_latent_dim_above_16_is_refused_loudly_for_every_loss(loss):
+    """main.py:81 takes any --latent-dim and disvae/models/losses.py:523-544 is dimension-agnostic; the fused HIP kernels cover
+    1..16 (include/dvae_hip.h: DVAE_MAX_D).  A larger value must fail at construction with a message that names the limit --
+    for every loss plugin, since all of them train the same native model -- never run with truncated latents."""
+    from disvae_amd.models.vae import init_specific_model, VAE
+    from disvae_amd.models.losses import get_loss_f, BtcvaeLoss
+    from disvae_amd import _lib
+    assert _lib.MAX_LATENT_DIM == 16
+    for D in (17, 32, 0, -1):
+        with pytest.raises(ValueError, match="latent_dim"):
+            init_specific_model("Burgess", (1, 32, 32), D)
+        with pytest.raises(ValueError, match="latent_dim"):
+            VAE((3, 64, 64), latent_dim=D)
+    init_specific_model("Burgess", (1, 32, 32), 16)                      # the largest accepted
+    hp = dict(rec_dist="bernoulli", reg_anneal=0, betaH_B=4, betaB_initC=0, betaB_finC=25, betaB_G=1000, factor_G=6.4,
+              latent_dim=17, lr_disc=1e-4, btcvae_A=1, btcvae_B=6, btcvae_G=1, n_data=1000, device=torch.device("cpu"))
+    loss_f = get_loss_f(loss, **hp)                                      # the plugin itself holds no latent-sized state ...
+    if loss == "btcvae":                                                 # ... and the one kernel with a per-dimension register file says so
+        with pytest.raises(ValueError, match="latent_dim=17"):
+            BtcvaeLoss._check_latent_dim(17)
+        z = torch.zeros(4, 17)
+        with pytest.raises(ValueError, match="latent_dim=17"):
+            loss_f(torch.zeros(4, 1, 32, 32), torch.zeros(4, 1, 32, 32), (z, z), True, None, latent_sample=z)
