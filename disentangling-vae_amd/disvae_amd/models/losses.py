@@ -150,7 +150,9 @@ class BaseLoss(abc.ABC):
 
     AUTO_PLAN_ELEMS = 256 * 3 * 64 * 64
     # one HIP stream instead of two below this many input elements per step (engine.single_stream); DVAE_STREAMS=1|2 forces
-    SINGLE_STREAM_ELEMS = int(knob("DVAE_SINGLE_STREAM_ELEMS", 64 * 3 * 64 * 64))   # measured: profiles/r02_run10_streams.txt
+    # (round 2 measured the cross-over at 64 images, profiles/r02_run10_streams.txt; with the round-5 schedule two streams win at
+    # 32 and 64 images as well: 0.291 / 0.301 against 0.338 / 0.346 ms, profiles/r05_v26_sweep.txt)
+    SINGLE_STREAM_ELEMS = int(knob("DVAE_SINGLE_STREAM_ELEMS", 16 * 3 * 64 * 64))
 
     # dependency-driven weight-gradient schedule (engine.eager_wgrad: a fork per layer) up to this many input elements per
     # step; above, the batch-sized schedule (two forks per half of the backward pass).  Round 3 measured the two within noise
