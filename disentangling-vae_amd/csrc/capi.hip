@@ -422,6 +422,17 @@ int dvae_set_coef(float* coef, float c0, float c1, float c2, float c3, float c4,
   return launch_set_coef(coef, v, (hipStream_t)stream);
 }
 
+int dvae_stream_create(void** stream) {
+  DVAE_CHECK_ARG(stream);
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    set_error("dvae_stream_create: %s", hipGetErrorString(hipGetLastError()));
+    return -2;
+  }
+  *stream = (void*)s;
+  return 0;
+}
+
 int dvae_stream_order(void* earlier, void* later) {
   // events are re-used round-robin: 256 of them outlive any window of outstanding fork / join pairs of an iteration (~20);
   // per device (an event belongs to the device it was created on)

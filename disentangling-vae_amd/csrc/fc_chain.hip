@@ -585,15 +585,15 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
 // backward, us, 8 rows per workgroup): <8,1> 28.1 | 33.6 / 30.5 | 40.2; <16,1> 28.0 | 33.4 / 30.3 | 38.4; <8,2> 23.6 | 25.3 /
 // 26.1 | 27.7; <16,2> 24.4 | 26.0 / 26.8 | 28.4 -- the second wave per SIMD helps, a deeper ring does not: with 8 rows the
 // launch is bound by its 12.8 k MFMAs per SIMD (21.6 us).  Round 5: FOUR rows per workgroup (RG = 1: half the MFMAs per
-// workgroup, twice the workgroups; then the ring depth matters: the bound becomes the L2 -> register weight stream) up to
+// workgroup, twice the workgroups; the bound becomes the L2 -> register weight stream, ~84 GB/s per CU) up to
 // FCC_R4_MAX_ROWS batch rows, where the doubled workgroup count still fits the chip in one wave; 8 rows above.
 // Debug builds can A/B the other instantiations with DVAE_FCC_VARIANT = 100 * rows + 10 * DEPTH + KS (rows = 0: by batch)
 #ifndef FCC_DEFAULT_VARIANT
 #define FCC_DEFAULT_VARIANT 82
 #endif
 #ifndef FCC_R4_DEPTH
-#define FCC_R4_DEPTH 16
-#endif
+#define FCC_R4_DEPTH 8            // same box, alone, 128 / 256 / 1024 rows: depth 8 18.3 / 17.9 / 20.6 us forward, depth 16 26.1 / 25.3 /
+#endif                            // 26.5 (8 rows per workgroup: 26.2 / 25.3 / 26.6): profiles/r05_final1_fcc_ab.txt
 #define FCC_R4_MAX_ROWS 1024
 
 // batch rows per workgroup of the chain kernels for a launch over n rows (= the granularity of the forward's KL partial blocks)

@@ -94,6 +94,7 @@ SIGNATURES = {
     "dvae_axpby": [_p, _p, ctypes.c_float, _p, ctypes.c_float, _l, _p],
     "dvae_swap_outer": [_p, _p, _i, _i, _l, _p],
     "dvae_stream_order": [_p, _p],
+    "dvae_stream_create": [_p],
     "dvae_event_record": [_i, _p],
     "dvae_event_wait": [_i, _p],
     "dvae_plan_op": [ctypes.c_char_p],
@@ -212,6 +213,16 @@ def next_event_slot():
     s = _next_slot[0] % EVENT_SLOTS
     _next_slot[0] += 1
     return s
+
+
+def new_stream(device):
+    """A torch handle (ExternalStream) of a stream made by dvae_stream_create on `device`: see include/dvae_hip.h for why the
+    engine's streams do not come from torch's pool."""
+    import torch
+    with torch.cuda.device(device):
+        h = ctypes.c_void_p()
+        call("dvae_stream_create", ctypes.addressof(h))
+        return torch.cuda.ExternalStream(h.value, device=device)
 
 
 ALLOC_GEN = [0]   # bumped whenever the engine (re)allocates device buffers: recorded plans hold raw pointers

@@ -112,6 +112,23 @@ class ParamArena:
 _TAIL_MAIN = ("conv3", "conv_64")
 
 
+_DEVICE_STREAMS = {}
+
+
+def device_streams(device):
+    """The (side, exchange) HIP streams of `device`, ONE pair per process: every engine on the device uses the same two.  HIP
+    multiplexes streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES); a process that builds many models -- bench.py's
+    legs, a trainer next to an evaluator -- would otherwise collect streams until two streams of one iteration share a queue
+    and serialise (the twelfth engine of a bench run: 1.32 ms per 128-image iteration instead of 0.35,
+    profiles/r05_final1_bench.json).  Iterations of different engines in one process run one after the other anyway.
+    Created through the C-ABI (dvae_stream_create), not taken from torch's pool: include/dvae_hip.h says why."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _DEVICE_STREAMS.get(key)
+    if st is None:
+        st = _DEVICE_STREAMS[key] = (_lib.new_stream(device), _lib.new_stream(device))
+    return st
+
+
 def _stream():
     """hipStream_t of torch's current stream (the raw accessor is ~20x cheaper than building a
     torch.cuda.Stream object per launch)."""
@@ -267,11 +284,10 @@ class VAEEngine:
             self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
             self._ws_side = torch.empty(n, dtype=torch.float32, device=self.device)
             # (a high-priority side stream measured the same step time: profiles/r04_v45_side_priority.txt)
-            self._side = torch.cuda.Stream(device=self.device)
             # third stream (sharded batches): the exchange-bound part of a step -- latent all-gather, the estimator over the
             # global batch, column-gradient reduce-scatter, the all-reduce of the loss sums -- must not sit in front of the
             # weight gradients on the side stream, which is the tail of the iteration
-            self._aux = torch.cuda.Stream(device=self.device)
+            self._side, self._aux = device_streams(self.device)
         return b
 
     # ---- per-step weight staging -------------------------------------------------------------------

@@ -36,6 +36,18 @@ class _Done:
         return None
 
 
+_COMM_STREAMS = {}
+
+
+def _comm_stream(dev):
+    """The communication stream of a device, one per process (see engine.device_streams: streams are a scarce resource)."""
+    key = (dev.type, dev.index)
+    st = _COMM_STREAMS.get(key)
+    if st is None:
+        st = _COMM_STREAMS[key] = _lib.new_stream(dev)
+    return st
+
+
 def _raw_stream():
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
@@ -225,7 +237,7 @@ class RcclComm(Comm):
         handle = ctypes.c_void_p()
         call("dvae_comm_init", ctypes.addressof(handle), self._uid, self.world_size, self.rank)
         self._h = handle.value
-        self._side = torch.cuda.Stream(device=dev)
+        self._side = _comm_stream(dev)
         assert h.dvae_comm_world(self._h) == self.world_size
 
     @staticmethod

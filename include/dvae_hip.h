@@ -394,6 +394,13 @@ int dvae_swap_outer(const float* src, float* dst, int A, int Bn, long inner, voi
  * its fork / join primitive: an event recorded with a DEVICE-scope release (hipEventReleaseToDevice: no system-scope cache
  * flush, the two streams share the device) from a small internal pool, then hipStreamWaitEvent.  Capturable.            */
 int dvae_stream_order(void* earlier, void* later);
+/* A new non-blocking stream on the current device (never destroyed: the host side keeps ONE side stream, one exchange stream
+ * and one communication stream per device and process).  Why not the framework's stream pool: HIP multiplexes streams onto
+ * GPU_MAX_HW_QUEUES hardware queues, a new stream joining the least-loaded queue; a pool creates dozens of streams at once, so
+ * which pool entry a caller is handed decides whether its stream shares a queue with the default stream -- and two streams of
+ * one iteration on one queue serialise (0.35 -> 0.79-1.3 ms per 128-image iteration, profiles/r05_final1_bench.json,
+ * r05_v28).  A stream created here lands on a queue the default stream is not on.                                       */
+int dvae_stream_create(void** stream /* out: hipStream_t */);
 /* The same in two halves, for a consumer that is enqueued much later than the producer: dvae_event_record marks the work
  * enqueued on `stream` so far in slot `slot` (0 <= slot < DVAE_EVENT_SLOTS, per device); dvae_event_wait makes the work enqueued
  * on `stream` afterwards wait for the slot's LAST mark.  (The btcvae step: the estimator's backward kernels and the scalar

@@ -46,7 +46,7 @@ def test_plan_ops_cover_the_launching_entry_points():
     h = _lib.lib()
     not_replayable = {"dvae_version", "dvae_last_error", "dvae_conv_wgrad_ws_floats", "dvae_latent_entropy_ws_floats",
                       "dvae_reparam_kl_blocks", "dvae_fc_chain_rows", "dvae_u8_fused_supported", "dvae_plan_op", "dvae_plan_run", "dvae_comm_load",
-                      "dvae_comm_unique_id", "dvae_comm_init", "dvae_comm_destroy", "dvae_comm_world", "dvae_comm_rank",
+                      "dvae_comm_unique_id", "dvae_comm_init", "dvae_comm_destroy", "dvae_comm_world", "dvae_comm_rank", "dvae_stream_create",
                       "dvae_adam_step"}        # (step count and learning rate change every iteration: issued directly)
     for name in _lib.SIGNATURES:
         assert (h.dvae_plan_op(name.encode()) >= 0) == (name not in not_replayable), name
