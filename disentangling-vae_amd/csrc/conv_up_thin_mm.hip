@@ -44,7 +44,7 @@ __device__ __forceinline__ float sigmoid_hw_mm(float v) { return __builtin_amdgc
 // Two workgroups per CU (69 KB of LDS, <= 128 registers): one streams its tile in / its rows out while the other multiplies;
 // a first version with ONE 121 KB workgroup per CU, a double-buffered tile and the next unit prefetched into registers ran all
 // eight waves through every phase in lock step -- 57 / 83 us without / with the likelihood at 1024 images, no better than the
-// packed-FMA kernel (profiles/r05_v18_up_thin_mm.txt).
+// packed-FMA kernel (measured in round 5; that visit's raw file did not survive a replaced build container).
 template <bool FUSE, int DIST, typename TT>
 __global__ __launch_bounds__(512, 2) void k_up_thin_mm(const float* __restrict__ small, const float* __restrict__ wimg,
                                                        const float* __restrict__ bias, float* __restrict__ out, int N,
