@@ -19,7 +19,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libdvae_hip.so")
 HEADERS = [os.path.join(SRC, "common.h"), os.path.join(SRC, "conv_mfma_common.h"), os.path.join(SRC, "wgrad_reduce.h"),
            os.path.join(HERE, "..", "include", "dvae_hip.h")]
-SOURCES = ["conv_generic", "conv_mfma", "conv_down_dma", "conv_up_ws", "conv_wgrad_ws", "conv_thin", "conv_thin_ws", "conv_up_thin_mm", "linear", "linear_narrow", "gemm_dma", "linear_grouped", "fc_chain", "stage", "loss",
+SOURCES = ["conv_generic", "conv_mfma", "conv_down_dma", "conv_up_ws", "conv_wgrad_ws", "conv_thin", "conv_thin_ws", "conv_up_thin_mm", "linear", "linear_narrow", "gemm_dma", "linear_grouped", "fc_chain", "stage", "loss", "latent_wide",
            "metrics", "adam", "comm", "plan", "capi"]
 DEBUG_SOURCES = []          # experimental kernel files: only in --debug builds
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

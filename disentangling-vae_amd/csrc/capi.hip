@@ -219,20 +219,21 @@ size_t dvae_latent_entropy_ws_floats(long N, int D, int S) {
 
 int dvae_latent_entropy(const float* z_ds, const float* mean, const float* logvar, long N, int D, int S, float* ws,
                         float* H, void* stream) {
-  DVAE_CHECK_ARG(z_ds && mean && logvar && ws && H && N > 0 && D > 0 && D <= DVAE_MAX_D && S > 0);
+  DVAE_CHECK_ARG(z_ds && mean && logvar && ws && H && N > 0 && D > 0 && D <= 65535 && S > 0);
   return launch_latent_entropy(z_ds, mean, logvar, N, D, S, ws, H, (hipStream_t)stream);
 }
 
 int dvae_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                         const float* coef, int B, int D, void* stream) {
-  DVAE_CHECK_ARG(ml && mu && logvar && z && B > 0 && D > 0 && D <= DVAE_MAX_D);    // kl_dim without coef: partials only
+  DVAE_CHECK_ARG(ml && mu && logvar && z && B > 0 && D > 0);    // kl_dim without coef: partials only
+  DVAE_CHECK_ARG(D <= DVAE_MAX_D || ((!kl_dim || coef) && D <= DVAE_KL_FLOATS));   // above: final values only
   return launch_reparam_kl_fwd(ml, eps, mu, logvar, z, kl_dim, coef, B, D, (hipStream_t)stream);
 }
 
 int dvae_reparam_kl_bwd(const float* dz, const float* dz2, const float* dz3, const float* dmu_x, const float* dlv_x,
                         const float* mu, const float* logvar, const float* eps, const float* scal, const float* coef,
                         float* dml, int B, int D, void* stream) {
-  DVAE_CHECK_ARG(mu && logvar && scal && coef && dml && B > 0 && D > 0 && D <= DVAE_MAX_D);
+  DVAE_CHECK_ARG(mu && logvar && scal && coef && dml && B > 0 && D > 0);
   return launch_reparam_kl_bwd(dz, dz2, dz3, dmu_x, dlv_x, mu, logvar, eps, scal, coef, dml, B, D, (hipStream_t)stream);
 }
 
@@ -261,7 +262,7 @@ int dvae_sigmoid_bwd(const float* grad_y, const float* y, float* out, long n, vo
 
 int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg, int D, int row0, int Bl, int is_mss,
                     const float* log_w, float* tmp, float* rowstats, void* stream) {
-  DVAE_CHECK_ARG(z && mu && logvar && tmp && rowstats && Bg > 1 && D >= 1 && D <= DVAE_BTCVAE_MAX_D && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg);
+  DVAE_CHECK_ARG(z && mu && logvar && tmp && rowstats && Bg > 1 && D >= 1 && D <= 65535 && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg);
   DVAE_CHECK_ARG(!is_mss || log_w);
   return launch_btcvae_fwd(z, mu, logvar, Bg, D, row0, Bl, is_mss, log_w, tmp, rowstats, (hipStream_t)stream);
 }
@@ -269,7 +270,7 @@ int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg
 int dvae_btcvae_bwd(const float* z, const float* mu, const float* logvar, const float* rowstats, int Bg, int D,
                     int row0, int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz,
                     float* dmu_all, float* dlv_all, void* stream) {
-  DVAE_CHECK_ARG(z && mu && logvar && rowstats && coef && tmp && dz && dmu_all && dlv_all && Bg > 1 && D >= 1 && D <= DVAE_BTCVAE_MAX_D);
+  DVAE_CHECK_ARG(z && mu && logvar && rowstats && coef && tmp && dz && dmu_all && dlv_all && Bg > 1 && D >= 1 && D <= 65535);
   DVAE_CHECK_ARG(row0 >= 0 && Bl > 0 && row0 + Bl <= Bg && (!is_mss || log_w));
   return launch_btcvae_bwd(z, mu, logvar, rowstats, Bg, D, row0, Bl, is_mss, log_w, coef, tmp, dz, dmu_all, dlv_all,
                            (hipStream_t)stream);
@@ -288,15 +289,15 @@ int dvae_disc_losses(const float* dlogits, int Bh, const float* coef, float* sum
 
 int dvae_loss_pack(const float* rec_partials, const float* kl_dim, int D, const float* rowstats, int Bl,
                    const float* disc_sums, float* packed, void* stream) {
-  DVAE_CHECK_ARG(rec_partials && packed && D >= 0 && D <= 16);
+  DVAE_CHECK_ARG(rec_partials && packed && D >= 0);
   return launch_loss_pack(rec_partials, kl_dim, D, rowstats, Bl, disc_sums, packed, (hipStream_t)stream);
 }
 
 int dvae_loss_epilogue(int kind, const float* rec_partials, const float* kl_dim, int kl_blocks, int D, const float* rowstats,
                        int Bl, const float* disc_sums, int Bg, const float* coef, float* packed, float* scal,
                        void* stream) {
-  DVAE_CHECK_ARG(rec_partials && packed && coef && D >= 0 && D <= 16 && Bl >= 0 && Bg > 0);
-  DVAE_CHECK_ARG(kl_blocks >= 0 && kl_blocks <= DVAE_KL_MAX_BLOCKS);
+  DVAE_CHECK_ARG(rec_partials && packed && coef && D >= 0 && Bl >= 0 && Bg > 0);
+  DVAE_CHECK_ARG(kl_blocks >= 0 && kl_blocks <= DVAE_KL_MAX_BLOCKS && (D <= DVAE_MAX_D || kl_blocks == 0));
   DVAE_CHECK_ARG(kind >= DVAE_LOSS_BETAH && kind <= DVAE_LOSS_FACTOR);
   return launch_loss_epilogue(kind, rec_partials, kl_dim, kl_blocks, D, rowstats, Bl, disc_sums, Bg, coef, packed, scal,
                               (hipStream_t)stream);
@@ -410,7 +411,7 @@ int dvae_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, void* stream) {
 }
 
 int dvae_loss_finalize(int kind, const float* packed, int D, int Bg, const float* coef, float* scal, void* stream) {
-  DVAE_CHECK_ARG(packed && coef && scal && D >= 0 && D <= 16 && Bg > 0);
+  DVAE_CHECK_ARG(packed && coef && scal && D >= 0 && Bg > 0);
   DVAE_CHECK_ARG(kind >= DVAE_LOSS_BETAH && kind <= DVAE_LOSS_FACTOR);
   return launch_loss_finalize(kind, packed, D, Bg, coef, scal, (hipStream_t)stream);
 }
@@ -439,6 +440,8 @@ int dvae_stream_order(void* earlier, void* later) {
   constexpr int NEV = 256, NDEV = 32;
   static hipEvent_t pool[NDEV][NEV];
   static int made[NDEV] = {}, next[NDEV] = {};
+  static std::mutex mu;                       // pool creation and the round-robin cursor: callers may come from several host threads
+  std::lock_guard<std::mutex> lock(mu);
   int d = 0;
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= NDEV) { set_error("dvae_stream_order: no current device"); return -2; }
   if (!made[d]) {

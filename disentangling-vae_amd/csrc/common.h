@@ -237,6 +237,14 @@ int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, 
 int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const float* rowstats, int Bg, int D, int row0,
                       int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz, float* dmu,
                       float* dlv, hipStream_t s);
+// latent dimensions above DVAE_MAX_D (latent_wide.hip)
+int launch_reparam_kl_fwd_wide(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
+                               const float* coef, int B, int D, hipStream_t s);
+int launch_btcvae_fwd_wide(const float* z, const float* mu, const float* lv, int Bg, int D, int row0, int Bl, int is_mss,
+                           const float* log_w, float* tmp, float* rowstats, hipStream_t s);
+int launch_btcvae_bwd_wide(const float* z, const float* mu, const float* lv, const float* rowstats, int Bg, int D, int row0,
+                           int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz, float* dmu,
+                           float* dlv, hipStream_t s);
 int launch_permute_dims(const float* z, const int64_t* perm, float* out, int B, int D, hipStream_t s);
 int launch_disc_losses(const float* lg, int Bh, const float* coef, float* sums, float* g_dtc, float* g_tc,
                        hipStream_t s);

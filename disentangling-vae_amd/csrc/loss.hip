@@ -411,6 +411,10 @@ __device__ __forceinline__ void loss_pack_body(const float* __restrict__ rec_par
   __shared__ float red[5][4];
   __shared__ float klred[256];
   const int tid = threadIdx.x;
+  // latent dimensions above DVAE_MAX_D ("wide", include/dvae_hip.h): rowstats rows of DVAE_ROWSTATS_STRIDE(D) floats, kl_dim = D
+  // FINAL values (no partial blocks), copied to packed[DVAE_WIDE_KL0 + d]; the 16 narrow KL slots stay zero
+  const bool wide = D > DVAE_MAX_D;
+  const int rstride = DVAE_ROWSTATS_STRIDE(D);
   // un-finished per-workgroup KL partials (dvae_reparam_kl_fwd without coef, dvae_fc_chain_fwd): same order as k_reparam_kl_finish
   const float klsum = (kl_dim && kl_blocks > 0) ? kl_blocks_sum(kl_dim + 16, kl_blocks, klred) : 0.f;
   float r = 0.f;
@@ -418,7 +422,7 @@ __device__ __forceinline__ void loss_pack_body(const float* __restrict__ rec_par
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (rowstats) {
     for (int i = tid; i < Bl; i += 256) {
-      const float* rs = rowstats + (long)i * DVAE_ROWSTATS;
+      const float* rs = rowstats + (long)i * rstride;
       s0 += rs[0]; s1 += rs[1]; s2 += rs[2]; s3 += rs[3];
     }
   }
@@ -436,8 +440,11 @@ __device__ __forceinline__ void loss_pack_body(const float* __restrict__ rec_par
   if (tid < 16) {
     const int d = tid;
     float v = 0.f;
-    if (kl_dim && d < D) v = kl_blocks > 0 ? klsum * kl_scale : kl_dim[d];
+    if (kl_dim && d < D && !wide) v = kl_blocks > 0 ? klsum * kl_scale : kl_dim[d];
     packed[1 + d] = v;
+  }
+  if (wide) {
+    for (int d = tid; d < D; d += 256) packed[DVAE_WIDE_KL0 + d] = kl_dim ? kl_dim[d] : 0.f;
   }
   if (tid >= 64 && tid < 64 + 3) packed[21 + (tid - 64)] = disc_sums ? disc_sums[tid - 64] : 0.f;
   if (tid >= 96 && tid < 96 + 8) packed[24 + (tid - 96)] = 0.f;
@@ -454,7 +461,8 @@ __device__ __forceinline__ void loss_finalize_body(int kind, const float* packed
                                                    const float* __restrict__ coef, float* __restrict__ scal) {
   const float rec = packed[0] * coef[DVAE_C_INV_B];
   float kl = 0.f;
-  for (int d = 0; d < D; ++d) { kl += packed[1 + d]; scal[DVAE_S_KL0 + d] = packed[1 + d]; }
+  const int kp = D > DVAE_MAX_D ? DVAE_WIDE_KL0 : 1, ks = D > DVAE_MAX_D ? DVAE_WIDE_KL0 : DVAE_S_KL0;   // wide layouts: dvae_hip.h
+  for (int d = 0; d < D; ++d) { kl += packed[kp + d]; scal[ks + d] = packed[kp + d]; }
   const float anneal = coef[DVAE_C_ANNEAL];
   float loss = rec, klw = 0.f, mi = 0.f, tc = 0.f, dw = 0.f, dtc = 0.f;
   if (kind == DVAE_LOSS_BETAH) {
@@ -583,6 +591,7 @@ __global__ void k_swap_outer(const float* __restrict__ src, float* __restrict__ 
 // ---- launchers -------------------------------------------------------------------------------
 int launch_reparam_kl_fwd(const float* ml, const float* eps, float* mu, float* logvar, float* z, float* kl_dim,
                           const float* coef, int B, int D, hipStream_t s) {
+  if (D > DVAE_MAX_D) return launch_reparam_kl_fwd_wide(ml, eps, mu, logvar, z, kl_dim, coef, B, D, s);
   // kl_dim[16..16+RK_BLOCKS*16) is used as scratch for the per-workgroup partial sums
   const int blocks = reparam_kl_blocks(B);
   float* part = kl_dim ? kl_dim + 16 : nullptr;
@@ -616,12 +625,13 @@ int launch_recon_loss(const float* recon, const float* target, long n, int dist,
 
 int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, int D, int row0, int Bl, int is_mss,
                       const float* log_w, float* tmp, float* rowstats, hipStream_t s) {
-  // latent_dim 10 (every reference experiment) has fully unrolled kernels; any other D <= 12 (rowstats holds
-  // 4 + D floats per row) runs the same code with the dimension as a run-time bound
-  if (D < 1 || D > DVAE_BTCVAE_MAX_D) return 1;
+  // latent_dim 10 (every reference experiment) has fully unrolled kernels; any other D <= 16 runs the same code with the
+  // dimension as a run-time bound; above: latent_wide.hip
+  if (D < 1) return 1;
   const long n = (long)Bg * D;
   hipLaunchKernelGGL(k_btcvae_prep, dim3((n + 255) / 256), dim3(256), 0, s, mu, lv, Bg, D, tmp);
   DVAE_CHECK_LAUNCH();
+  if (D > DVAE_MAX_D) return launch_btcvae_fwd_wide(z, mu, lv, Bg, D, row0, Bl, is_mss, log_w, tmp, rowstats, s);
   if (D == 10) hipLaunchKernelGGL(k_btcvae_fwd<10>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, Bg, row0, Bl, is_mss, log_w, rowstats, D);
   else hipLaunchKernelGGL(k_btcvae_fwd<0>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, Bg, row0, Bl, is_mss, log_w, rowstats, D);
   DVAE_CHECK_LAUNCH();
@@ -631,7 +641,9 @@ int launch_btcvae_fwd(const float* z, const float* mu, const float* lv, int Bg, 
 int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const float* rowstats, int Bg, int D, int row0,
                       int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz, float* dmu,
                       float* dlv, hipStream_t s) {
-  if (D < 1 || D > DVAE_BTCVAE_MAX_D) return 1;
+  if (D < 1) return 1;
+  if (D > DVAE_MAX_D)
+    return launch_btcvae_bwd_wide(z, mu, lv, rowstats, Bg, D, row0, Bl, is_mss, log_w, coef, tmp, dz, dmu, dlv, s);
   if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
                                   is_mss, log_w, coef, dz, D);
   else hipLaunchKernelGGL(k_btcvae_bwd_rows<0>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,

@@ -18,9 +18,40 @@ S_LOSS, S_REC, S_KL, S_KL0, S_MI, S_TC, S_DWKL, S_KLW, S_DTC, NSCAL = 0, 1, 2, 3
 C_INV_B, C_ANNEAL, C_BETA, C_ALPHA, C_GAMMA, C_CAP, NCOEF = 0, 1, 2, 3, 4, 5, 8
 REC_NPART = 2048
 NPACK = 32
-MAX_LATENT_DIM = 16          # DVAE_MAX_D
-BTCVAE_MAX_LATENT_DIM = 16   # DVAE_BTCVAE_MAX_D
+MAX_LATENT_DIM = 16          # DVAE_MAX_D: the FUSED kernels (FC chain, register-resident estimator, 16-wide KL records)
 ROWSTATS = 32                # DVAE_ROWSTATS
+WIDE_KL0 = 32                # DVAE_WIDE_KL0
+
+
+# Layouts that depend on the latent dimension (include/dvae_hip.h: above DVAE_MAX_D the same entry points run the run-time-D
+# kernels of csrc/latent_wide.hip on "wide" buffers)
+def wide(D):
+    return D > MAX_LATENT_DIM
+
+
+def rowstats_stride(D):
+    """DVAE_ROWSTATS_STRIDE(D)."""
+    return ROWSTATS if D <= MAX_LATENT_DIM else (D + 4 + 3) & ~3
+
+
+def btcvae_tmp_floats(Bg, Bl, D):
+    """DVAE_BTCVAE_TMP_FLOATS(Bg, Bl, D)."""
+    return 3 * D * Bg + (0 if D <= MAX_LATENT_DIM else Bl * Bg)
+
+
+def npack(D):
+    """DVAE_NPACK_D(D)."""
+    return NPACK if D <= MAX_LATENT_DIM else NPACK + D
+
+
+def nscal(D):
+    """DVAE_NSCAL_D(D)."""
+    return NSCAL if D <= MAX_LATENT_DIM else NSCAL + D
+
+
+def kl0(D):
+    """First per-dimension KL slot of scal[] (DVAE_S_KL0, or DVAE_WIDE_KL0 above DVAE_MAX_D)."""
+    return S_KL0 if D <= MAX_LATENT_DIM else WIDE_KL0
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

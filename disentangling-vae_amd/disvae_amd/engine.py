@@ -188,6 +188,9 @@ class _Images:
             for kind in ("down", "up"):
                 sizes[(name, kind)] = off
                 off += 16384
+        # latent dimensions above _lib.MAX_LATENT_DIM: the FC layers run one launch each on the raw weights (fc_chain_fwd below),
+        # no operand streams are staged
+        self.FC = [] if _lib.wide(eng.latent_dim) else list(_Images.FC)
         for name in self.FC:
             N, K = arena.shapes[name + ".weight"]
             sizes[(name, "fwd")] = off
@@ -206,7 +209,8 @@ class _Images:
         self.conv_descs = (_lib.ConvImageDesc * len(conv))()
         for d, name in zip(self.conv_descs, conv):
             d.w, d.img_down, d.img_up = ptr(arena.view(name + ".weight")), self.ptrs[(name, "down")], self.ptrs[(name, "up")]
-        self.fc_descs = (_lib.FcImageDesc * len(self.FC))()
+        self.fc_descs = (_lib.FcImageDesc * max(len(self.FC), 1))()
+        self.n_fc = len(self.FC)
         for d, name in zip(self.fc_descs, self.FC):
             N, K = arena.shapes[name + ".weight"]
             d.w, d.img_fwd, d.img_bwd, d.N, d.K = (ptr(arena.view(name + ".weight")), self.ptrs[(name, "fwd")],
@@ -311,7 +315,7 @@ class VAEEngine:
                 im.coef_vals[i] = v
             cv = ctypes.addressof(im.coef_vals)
         call("dvae_stage_weights", ctypes.addressof(im.conv_descs), len(im.conv_descs), ctypes.addressof(im.fc_descs),
-             len(im.fc_descs), None if im.thin_desc is None else ctypes.addressof(im.thin_desc), ptr(coef), cv, _stream())
+             im.n_fc, None if im.thin_desc is None else ctypes.addressof(im.thin_desc), ptr(coef), cv, _stream())
 
     def _img(self, layer, kind):
         return self._images.ptrs[(layer, kind)]
@@ -466,18 +470,24 @@ class VAEEngine:
         call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z), ptr(kl_dim),
              ptr(coef), B, self.latent_dim, _stream())
 
-    @staticmethod
-    def kl_blocks(n_enc):
-        """Number of KL partial blocks fc_chain_fwd leaves at kl_dim + 16 (dvae_loss_epilogue / dvae_kl_finish argument)."""
+    def kl_blocks(self, n_enc):
+        """Number of KL partial blocks fc_chain_fwd leaves at kl_dim + 16 (dvae_loss_epilogue / dvae_kl_finish argument).
+        0 above _lib.MAX_LATENT_DIM: kl_dim then holds the D final values and there is nothing to finish."""
+        if _lib.wide(self.latent_dim):
+            return 0
         r = _lib.fc_chain_rows(n_enc)
         return (n_enc + r - 1) // r
 
-    def fc_chain_fwd(self, buf, eps, kl_dim, n_enc, n_kl=None, n_dec=None):
+    def fc_chain_fwd(self, buf, eps, kl_dim, n_enc, n_kl=None, n_dec=None, coef=None):
         """buf.a_flat -> h1, h2, ml, mu, logvar, z (rows < n_enc; KL partial blocks from rows < n_kl at kl_dim + 16) and
         d1, d2, d3 (rows < n_dec) in ONE launch (dvae_fc_chain_fwd): encoders.py:81-87, vae.py:52-71, losses.py:470,
-        decoders.py:71-73.  eps [n_enc, D] or None (z = mu)."""
+        decoders.py:71-73.  eps [n_enc, D] or None (z = mu).
+        Latent dimensions above _lib.MAX_LATENT_DIM: the same tensors from one launch per layer (_fc_layers_fwd); kl_dim then
+        receives the D FINAL per-dimension values, normalised by coef[INV_B] (`coef` is required with kl_dim)."""
         n_kl = n_enc if n_kl is None else n_kl
         n_dec = n_enc if n_dec is None else n_dec
+        if _lib.wide(self.latent_dim):
+            return self._fc_layers_fwd(buf, eps, kl_dim, n_enc, n_kl, n_dec, coef)
         if n_enc > _lib.FC_CHAIN_MAX_ROWS:
             raise _lib.DvaeHipError("fc_chain_fwd: at most %d rows per launch" % _lib.FC_CHAIN_MAX_ROWS)
         P, I = self.p, self._img
@@ -493,9 +503,63 @@ class VAEEngine:
                           n_enc=n_enc, n_kl=n_kl, n_dec=n_dec, D=self.latent_dim)
         call("dvae_fc_chain_fwd", addr, _stream())
 
+    def _fc_layers_fwd(self, buf, eps, kl_dim, n_enc, n_kl, n_dec, coef):
+        """fc_chain_fwd for any latent dimension: dvae_linear_fwd x 3, dvae_reparam_kl_fwd (its run-time-D form), x 3."""
+        s = _stream()
+        ws = ptr(self._ws)
+        D = self.latent_dim
+        P = self.p
+        if kl_dim is not None and n_kl > 0 and coef is None:
+            raise _lib.DvaeHipError("fc_chain_fwd: latent_dim > %d needs `coef` with kl_dim" % _lib.MAX_LATENT_DIM)
+        for x, name, y, K, N in ((buf.a_flat, "encoder.lin1", buf.h1, HID * 16, HIDDEN_DIM),
+                                 (buf.h1, "encoder.lin2", buf.h2, HIDDEN_DIM, HIDDEN_DIM),
+                                 (buf.h2, "encoder.mu_logvar_gen", buf.ml, HIDDEN_DIM, 2 * D)):
+            call("dvae_linear_fwd", ptr(x), ptr(P(name + ".weight")), ptr(P(name + ".bias")), ptr(y), n_enc, K, N,
+                 ACT_NONE if name.endswith("gen") else ACT_RELU, ws, s)
+        # KL over the rows < n_kl only (FactorVAE: the first half batch, losses.py:255-259): two row ranges
+        with_kl = kl_dim is not None and n_kl > 0
+        n0 = n_kl if with_kl else n_enc
+        call("dvae_reparam_kl_fwd", ptr(buf.ml), ptr(eps), ptr(buf.mu), ptr(buf.logvar), ptr(buf.z),
+             ptr(kl_dim) if with_kl else None, ptr(coef) if with_kl else None, n0, D, s)
+        if n0 < n_enc:
+            o = n0 * D * 4
+            call("dvae_reparam_kl_fwd", ptr(buf.ml) + 2 * o, None if eps is None else ptr(eps) + o, ptr(buf.mu) + o,
+                 ptr(buf.logvar) + o, ptr(buf.z) + o, None, None, n_enc - n0, D, s)
+        if n_dec > 0:
+            for x, name, y, K, N in ((buf.z, "decoder.lin1", buf.d1, D, HIDDEN_DIM),
+                                     (buf.d1, "decoder.lin2", buf.d2, HIDDEN_DIM, HIDDEN_DIM),
+                                     (buf.d2, "decoder.lin3", buf.d3, HIDDEN_DIM, HID * 16)):
+                call("dvae_linear_fwd", ptr(x), ptr(P(name + ".weight")), ptr(P(name + ".bias")), ptr(y), n_dec, K, N,
+                     ACT_RELU, ws, s)
+
+    def _fc_layers_bwd(self, buf, eps, dz2, dz3, dmu_x, dlv_x, scal, coef, n):
+        """fc_chain_bwd for any latent dimension: dvae_linear_dgrad x 3, dvae_reparam_kl_bwd, x 3 (the launches of the
+        autograd-compatible path: decode_backward / encode_backward without fc_chain)."""
+        s = _stream()
+        ws = ptr(self._ws)
+        D = self.latent_dim
+        P = self.p
+        call("dvae_linear_dgrad", ptr(buf.gd3), ptr(P("decoder.lin3.weight")), ptr(buf.d2), ACT_RELU, ptr(buf.gd2),
+             n, HIDDEN_DIM, HID * 16, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.gd2), ptr(P("decoder.lin2.weight")), ptr(buf.d1), ACT_RELU, ptr(buf.gd1),
+             n, HIDDEN_DIM, HIDDEN_DIM, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.gd1), ptr(P("decoder.lin1.weight")), None, ACT_NONE, ptr(buf.dz),
+             n, D, HIDDEN_DIM, ws, s)
+        call("dvae_reparam_kl_bwd", ptr(buf.dz), ptr(dz2), ptr(dz3), ptr(dmu_x), ptr(dlv_x), ptr(buf.mu), ptr(buf.logvar),
+             ptr(eps), ptr(scal), ptr(coef), ptr(buf.dml), n, D, s)
+        call("dvae_linear_dgrad", ptr(buf.dml), ptr(P("encoder.mu_logvar_gen.weight")), ptr(buf.h2), ACT_RELU, ptr(buf.gh2),
+             n, HIDDEN_DIM, 2 * D, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.gh2), ptr(P("encoder.lin2.weight")), ptr(buf.h1), ACT_RELU, ptr(buf.gh1),
+             n, HIDDEN_DIM, HIDDEN_DIM, ws, s)
+        call("dvae_linear_dgrad", ptr(buf.gh1), ptr(P("encoder.lin1.weight")), ptr(buf.a_flat), ACT_RELU, ptr(buf.ga_flat),
+             n, HID * 16, HIDDEN_DIM, ws, s)
+
     def fc_chain_bwd(self, buf, eps, dz2, dz3, dmu_x, dlv_x, scal, coef, n):
         """buf.gd3 -> gd2, gd1, dz, dml, gh2, gh1, ga_flat (rows < n) in ONE launch (dvae_fc_chain_bwd): the input gradients
-        of the six FC layers with dvae_reparam_kl_bwd's arithmetic in the middle (training.py:157)."""
+        of the six FC layers with dvae_reparam_kl_bwd's arithmetic in the middle (training.py:157).  Latent dimensions above
+        _lib.MAX_LATENT_DIM: one launch per layer (_fc_layers_bwd)."""
+        if _lib.wide(self.latent_dim):
+            return self._fc_layers_bwd(buf, eps, dz2, dz3, dmu_x, dlv_x, scal, coef, n)
         I = self._img
         addr = self._args(("fcb", id(buf), ptr(eps), ptr(dz2), ptr(dz3), ptr(dmu_x), ptr(dlv_x), ptr(scal), ptr(coef), n,
                            self._images.buf.data_ptr()),

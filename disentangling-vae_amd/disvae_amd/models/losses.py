@@ -81,6 +81,18 @@ class _Scratch:
         self.rowstats = None
         self.lat = {}
 
+    def for_latent_dim(self, D):
+        """`scal` / `packed` sized for latent dimension D (include/dvae_hip.h: above DVAE_MAX_D the per-dimension KL values follow
+        the 32 fixed slots) -- grown once; recorded launch plans are invalidated with the allocation."""
+        if self.scal.numel() < _lib.nscal(D):
+            _lib.note_alloc()
+            self.scal = torch.zeros(_lib.nscal(D), dtype=torch.float32, device=self.device)
+            self.packed = torch.zeros(_lib.npack(D), dtype=torch.float32, device=self.device)
+        if self.kl_dim.numel() < D:
+            _lib.note_alloc()
+            self.kl_dim = torch.zeros(D, dtype=torch.float32, device=self.device)
+        return self
+
     def set_coef(self, **kw):
         h = self.coef_host
         for k, v in kw.items():
@@ -228,7 +240,7 @@ class BaseLoss(abc.ABC):
     def _store_kl(storer, vals, D):
         storer['kl_loss'].append(vals[_lib.S_KL])
         for i in range(D):
-            storer['kl_loss_' + str(i)].append(vals[_lib.S_KL0 + i])
+            storer['kl_loss_' + str(i)].append(vals[_lib.kl0(D) + i])
 
 
 # ------------------------------------------------------------------------------------------
@@ -265,7 +277,7 @@ class _KLFn(torch.autograd.Function):
         ml = torch.stack((mu, logvar), dim=-1).reshape(B, 2 * D).contiguous()
         scratch.set_coef(INV_B=1.0 / B)
         tmp = torch.empty(3, B, D, dtype=torch.float32, device=mu.device)
-        kl_dim = torch.empty(16 + 64 * 16, dtype=torch.float32, device=mu.device)
+        kl_dim = torch.empty(max(16 + 64 * 16, D), dtype=torch.float32, device=mu.device)
         call("dvae_reparam_kl_fwd", ptr(ml), None, ptr(tmp[0]), ptr(tmp[1]), ptr(tmp[2]), ptr(kl_dim),
              ptr(scratch.coef), B, D, _stream())
         ctx.save_for_backward(mu, logvar)
@@ -290,15 +302,16 @@ class _BtcvaeFn(torch.autograd.Function):
         z, mu, logvar = z.contiguous(), mu.contiguous(), logvar.contiguous()
         B, D = z.shape
         scratch.set_log_w(B, n_data)
-        rowstats = torch.empty(B, _lib.ROWSTATS, dtype=torch.float32, device=z.device)
-        tmp = torch.empty(3 * D, B, dtype=torch.float32, device=z.device)
+        rowstats = torch.empty(B, _lib.rowstats_stride(D), dtype=torch.float32, device=z.device)
+        tmp = torch.empty(_lib.btcvae_tmp_floats(B, B, D), dtype=torch.float32, device=z.device)
         call("dvae_btcvae_fwd", ptr(z), ptr(mu), ptr(logvar), B, D, 0, B, int(is_mss), ptr(scratch.log_w),
              ptr(tmp), ptr(rowstats), _stream())
-        # batch means of the four log-densities -> (mi, tc, dw_kl) by the scalar epilogue kernels (losses.py:369-373)
-        packed = torch.empty(_lib.NPACK, dtype=torch.float32, device=z.device)
-        scal = torch.empty(_lib.NSCAL, dtype=torch.float32, device=z.device)
-        call("dvae_loss_pack", ptr(scratch.partials), None, 0, ptr(rowstats), B, None, ptr(packed), _stream())
-        call("dvae_loss_finalize", _lib.LOSS_BTCVAE, ptr(packed), 0, B, ptr(scratch.coef), ptr(scal), _stream())
+        # batch means of the four log-densities -> (mi, tc, dw_kl) by the scalar epilogue kernels (losses.py:369-373); no KL
+        # values are passed (kl_dim = NULL): D only tells the kernels the row stride of `rowstats`
+        packed = torch.empty(_lib.npack(D), dtype=torch.float32, device=z.device)
+        scal = torch.empty(_lib.nscal(D), dtype=torch.float32, device=z.device)
+        call("dvae_loss_pack", ptr(scratch.partials), None, D, ptr(rowstats), B, None, ptr(packed), _stream())
+        call("dvae_loss_finalize", _lib.LOSS_BTCVAE, ptr(packed), D, B, ptr(scratch.coef), ptr(scal), _stream())
         ctx.save_for_backward(z, mu, logvar, rowstats, tmp)
         ctx.is_mss, ctx.scratch = is_mss, scratch
         return scal[_lib.S_MI:_lib.S_DWKL + 1].clone()       # [mi, tc, dw_kl]
@@ -385,14 +398,13 @@ class _SingleOptimizerLoss(BaseLoss):
         storer = self._pre_call(is_train, storer)
         B, D = data.shape[0], model.latent_dim
         world, rank = self._world()
-        sc = self.scratch(data.device)
+        sc = self.scratch(data.device).for_latent_dim(D)
         # ONE launch: this step's weight images (32-channel conv layers, FC chain) + its loss coefficients
         sc.set_coef_host(INV_B=1.0 / (B * world), **self._coefs(is_train))
         model.engine.stage(sc.coef, sc.coef_host)
         data = data.contiguous()
         self._streams(model, data)
         if self.KIND == _lib.LOSS_BTCVAE:
-            self._check_latent_dim(D)
             sc.set_log_w(B * self._est_world()[0], self.n_data)
         mode = self._replay_mode(is_train, data)
         if mode:
@@ -431,8 +443,10 @@ class _SingleOptimizerLoss(BaseLoss):
             eps = None
         eng.encode_convs(data, buf)
         # the FC core in one launch: lin1 -> lin2 -> mu_logvar -> reparameterise (+ KL partial blocks) -> lin1 -> lin2 -> lin3
-        eng.fc_chain_fwd(buf, eps, sc.kl_dim, B)
+        # (latent dimensions above 16: one launch per layer, kl_dim final at once and klb = 0 -- engine.fc_chain_fwd)
+        eng.fc_chain_fwd(buf, eps, sc.kl_dim, B, coef=sc.coef)
         klb = eng.kl_blocks(B)            # single process: the one-launch loss epilogue finishes the KL partials
+        npk = _lib.npack(D)
         lat = {"rowstats": None, "dz": None, "dmu": None, "dlv": None, "xbuf": None}
         btc = self.KIND == _lib.LOSS_BTCVAE
 
@@ -446,15 +460,15 @@ class _SingleOptimizerLoss(BaseLoss):
                 zg, mug, lvg = buf.z, buf.mu, buf.logvar
                 if ew > 1:
                     zg, mug, lvg = self.comm.all_gather_latents(buf.z, buf.mu, buf.logvar)
-                rowstats = lat["rowstats"] = sc.latent("rowstats", B, _lib.ROWSTATS)
-                tc_tmp = sc.latent("tc_tmp", 3 * D, Be)
+                rowstats = lat["rowstats"] = sc.latent("rowstats", B, _lib.rowstats_stride(D))
+                tc_tmp = sc.latent("tc_tmp", 1, _lib.btcvae_tmp_floats(Be, B, D))
                 call("dvae_btcvae_fwd", ptr(zg), ptr(mug), ptr(lvg), Be, D, er * B, B, int(self.is_mss), ptr(sc.log_w),
                      ptr(tc_tmp), ptr(rowstats), ss)
                 if is_train:
                     dz_x = sc.latent("dz_tc", B, D)
                     # (dmu, dlogvar) of ALL columns: two slabs of one buffer, followed by the packed loss sums -- sharded, the
                     # lot is summed over the ranks by ONE all-reduce in the step's late epilogue (Comm.all_reduce_cols_sums)
-                    xbuf = sc.latent("xbuf", 1, 2 * Be * D + _lib.NPACK).view(-1)
+                    xbuf = sc.latent("xbuf", 1, 2 * Be * D + npk).view(-1)
                     dmu_all, dlv_all = xbuf[:Be * D].view(Be, D), xbuf[Be * D:2 * Be * D].view(Be, D)
                     call("dvae_btcvae_bwd", ptr(zg), ptr(mug), ptr(lvg), ptr(rowstats), Be, D, er * B, B,
                          int(self.is_mss), ptr(sc.log_w), ptr(sc.coef), ptr(tc_tmp), ptr(dz_x), ptr(dmu_all), ptr(dlv_all), ss)
@@ -506,19 +520,21 @@ class _SingleOptimizerLoss(BaseLoss):
                     ss = eng._aux_raw()
                     call("dvae_stream_order", eng._side_raw(), ss)
                     xbuf = lat["xbuf"]
-                    packed = sc.packed if xbuf is None else xbuf[xbuf.numel() - _lib.NPACK:]
-                    call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, ss)
+                    packed = sc.packed if xbuf is None else xbuf[xbuf.numel() - npk:]
+                    if klb:
+                        call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, ss)
                     call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(packed), ss)
                     with torch.cuda.stream(eng.aux_stream):
                         if xbuf is None:
                             self.comm.all_reduce(packed)
                         else:                     # + the estimator's column gradients: one collective
-                            self.comm.all_reduce_cols_sums(xbuf, B, D, _lib.NPACK)
+                            self.comm.all_reduce_cols_sums(xbuf, B, D, npk)
                     call("dvae_loss_finalize", self.KIND, ptr(packed), D, Bg, ptr(sc.coef), ptr(sc.scal), ss)
                 call("dvae_event_record", self._ev_slot, ss)
             eng.at_next_fork(epilogue)
         elif world > 1:
-            call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, s)
+            if klb:
+                call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, s)
             call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
             self.comm.all_reduce(sc.packed)
             call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), s)
@@ -634,12 +650,6 @@ class BtcvaeLoss(_SingleOptimizerLoss):
         anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
         return dict(ANNEAL=anneal, ALPHA=self.alpha, BETA=self.beta, GAMMA=self.gamma)
 
-    @staticmethod
-    def _check_latent_dim(D):
-        if D > _lib.BTCVAE_MAX_LATENT_DIM:
-            raise ValueError("btcvae: latent_dim={} > {}: the fused B x B estimator kernels keep their per-dimension state "
-                             "in registers".format(D, _lib.BTCVAE_MAX_LATENT_DIM))
-
     def _store(self, storer, vals, D):
         storer['recon_loss'].append(vals[_lib.S_REC])
         storer['loss'].append(vals[_lib.S_LOSS])
@@ -650,7 +660,6 @@ class BtcvaeLoss(_SingleOptimizerLoss):
 
     def __call__(self, data, recon_batch, latent_dist, is_train, storer, latent_sample=None):
         storer = self._pre_call(is_train, storer)
-        self._check_latent_dim(latent_sample.shape[1])
         sc = self.scratch(recon_batch.device)
         rec_loss = _reconstruction_loss(data, recon_batch, storer=storer, distribution=self.rec_dist, scratch=sc)
         terms = _BtcvaeFn.apply(latent_sample, latent_dist[0], latent_dist[1], self.n_data, self.is_mss, sc)
@@ -732,7 +741,7 @@ class FactorKLoss(BaseLoss):
         eng.encode_convs(data, buf, n=2 * Bh)                         # data1 and data2 in one pass
         # FC core of both halves in one launch; KL only over data1 with the half batch as denominator (losses.py:255-259),
         # decoder only for data1
-        eng.fc_chain_fwd(buf, eps12, sc.kl_dim, 2 * Bh, n_kl=Bh, n_dec=Bh)
+        eng.fc_chain_fwd(buf, eps12, sc.kl_dim, 2 * Bh, n_kl=Bh, n_dec=Bh, coef=sc.coef)
         klb = eng.kl_blocks(2 * Bh)
         eng.decode_convs(buf, Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
         off = Bh
@@ -769,7 +778,8 @@ class FactorKLoss(BaseLoss):
                 call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), klb, D, None, 0,
                      ptr(sc.disc_sums), Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), stream)
                 return
-            call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, stream)
+            if klb:
+                call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, stream)
             call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), stream)
             with torch.cuda.stream(eng.aux_stream if on_side else torch.cuda.current_stream()):
                 self.comm.all_reduce(sc.packed)
@@ -833,7 +843,7 @@ class FactorKLoss(BaseLoss):
         Bhg = Bh * world
         dev = data.device
         s = _stream()
-        sc = self.scratch(dev)
+        sc = self.scratch(dev).for_latent_dim(D)
         anneal = linear_annealing(0, 1, self.n_train_steps, self.steps_anneal) if is_train else 1
         sc.set_coef_host(INV_B=1.0 / Bhg, ANNEAL=anneal, BETA=self.gamma)
         eng.stage(sc.coef, sc.coef_host)       # ONE launch: this step's weight images + its loss coefficients
@@ -870,8 +880,9 @@ class FactorKLoss(BaseLoss):
             data = eng.input(data, buf)
             eng.encode_convs(data, buf, n=Bh)
             # z = mean; KL over data1 with the half batch as denominator (losses.py:255-259)
-            eng.fc_chain_fwd(buf, None, sc.kl_dim, Bh)
-            call("dvae_kl_finish", ptr(sc.kl_dim), eng.kl_blocks(Bh), ptr(sc.coef), D, s)
+            eng.fc_chain_fwd(buf, None, sc.kl_dim, Bh, coef=sc.coef)
+            if eng.kl_blocks(Bh):
+                call("dvae_kl_finish", ptr(sc.kl_dim), eng.kl_blocks(Bh), ptr(sc.coef), D, s)
             eng.decode_convs(buf, Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
             # evaluation: vae_loss only (losses.py:276-278); discriminator on z1
             logits = disc.forward_raw(buf.z, Bh)

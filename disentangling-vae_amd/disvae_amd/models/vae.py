@@ -63,9 +63,10 @@ class VAE(nn.Module):
         if list(img_size[1:]) not in [[32, 32], [64, 64]]:
             raise RuntimeError("{} sized images not supported. Only (None, 32, 32) and (None, 64, 64) supported. "
                                "Build your own architecture or reshape images!".format(img_size))
-        if not (isinstance(latent_dim, int) and 1 <= latent_dim <= _lib.MAX_LATENT_DIM):
-            raise ValueError("latent_dim={!r}: the fused HIP kernels cover 1 <= latent_dim <= {} (the reference uses 10 in "
-                             "every experiment of hyperparam.ini)".format(latent_dim, _lib.MAX_LATENT_DIM))
+        # any dimension, like main.py:81: the fused kernels cover 1..16 (_lib.MAX_LATENT_DIM), above that the engine runs the FC
+        # layers one launch each and the latent / loss kernels their run-time-D forms (csrc/latent_wide.hip)
+        if not (isinstance(latent_dim, int) and not isinstance(latent_dim, bool) and latent_dim >= 1):
+            raise ValueError("latent_dim={!r}: expected a positive integer".format(latent_dim))
         self.latent_dim = latent_dim
         self.img_size = tuple(img_size)
         self.num_pixels = self.img_size[1] * self.img_size[2]
@@ -241,7 +242,7 @@ def _check_input(model, x):
 
 
 def _zeros_scal(dev):
-    return torch.zeros(_lib.NSCAL, dtype=torch.float32, device=dev)
+    return torch.zeros(_lib.NSCAL, dtype=torch.float32, device=dev)    # (dvae_reparam_kl_bwd reads the fixed slots only)
 
 
 def _param_grads(model):

@@ -25,14 +25,27 @@
 extern "C" {
 #endif
 
-#define DVAE_VERSION 107
+#define DVAE_VERSION 108
 
-/* latent dimensions the fused kernels cover (the reference's --latent-dim is 10 in every experiment of
- * hyperparam.ini): reparameterisation / KL / scalar slots, the FC chain and the beta-TCVAE estimator up to 16.
- * D = 10 has fully unrolled kernels.                                                                  */
+/* Latent dimensions.  The reference's --latent-dim is any integer (main.py:81); every experiment of hyperparam.ini uses 10.
+ * The FUSED kernels (the FC chain, the register-resident beta-TCVAE estimator, the 16-wide KL / scalar records) cover
+ * 1 <= D <= DVAE_MAX_D, D = 10 fully unrolled.  Above that the same entry points take any D and run run-time-D kernels
+ * (csrc/latent_wide.hip; the FC layers go one launch each through dvae_linear_*): only dvae_fc_chain_* and the partial-block
+ * form of the KL (dvae_reparam_kl_fwd without coef, dvae_kl_finish, kl_blocks > 0) stay limited to DVAE_MAX_D.  Buffers whose
+ * size depends on D beyond that point are sized by the macros below ("wide" layouts):                              */
 #define DVAE_MAX_D 16
-#define DVAE_BTCVAE_MAX_D 16
+#define DVAE_BTCVAE_MAX_D DVAE_MAX_D   /* (kept for callers of version <= 107: the estimator's fused kernels) */
 #define DVAE_ROWSTATS 32        /* floats per row of the estimator's row statistics: 4 + D used */
+/* row stride of `rowstats` */
+#define DVAE_ROWSTATS_STRIDE(D) ((D) <= DVAE_MAX_D ? DVAE_ROWSTATS : (((D) + 4 + 3) & ~3))
+/* floats of the estimator's `tmp`: [3][D][Bg] column constants; above DVAE_MAX_D followed by the [Bl][Bg] joint log-densities */
+#define DVAE_BTCVAE_TMP_FLOATS(Bg, Bl, D) \
+  ((size_t)3 * (D) * (Bg) + ((D) <= DVAE_MAX_D ? (size_t)0 : (size_t)(Bl) * (Bg)))
+/* floats of `packed` / `scal`; above DVAE_MAX_D the per-dimension KL values follow the 32 fixed slots: packed[32 + d], scal[32 + d]
+ * (the 16 narrow KL slots stay zero) */
+#define DVAE_WIDE_KL0 32
+#define DVAE_NPACK_D(D) ((D) <= DVAE_MAX_D ? 32 : 32 + (D))
+#define DVAE_NSCAL_D(D) ((D) <= DVAE_MAX_D ? 32 : 32 + (D))
 
 enum { DVAE_NCHW = 0, DVAE_NHWC = 1 };
 enum { DVAE_ACT_NONE = 0, DVAE_ACT_RELU = 1, DVAE_ACT_LEAKY02 = 2, DVAE_ACT_SIGMOID = 3 };
@@ -41,7 +54,7 @@ enum { DVAE_LOSS_BETAH = 0, DVAE_LOSS_BETAB = 1, DVAE_LOSS_BTCVAE = 2, DVAE_LOSS
 
 /* scalar slots written by dvae_loss_finalize (float[DVAE_NSCAL]) */
 enum {
-  DVAE_S_LOSS = 0, DVAE_S_REC = 1, DVAE_S_KL = 2, DVAE_S_KL0 = 3 /* ..3+D-1, D<=16 */,
+  DVAE_S_LOSS = 0, DVAE_S_REC = 1, DVAE_S_KL = 2, DVAE_S_KL0 = 3 /* ..3+D-1 for D <= DVAE_MAX_D; above: DVAE_WIDE_KL0 + d */,
   DVAE_S_MI = 19, DVAE_S_TC = 20, DVAE_S_DWKL = 21, DVAE_S_KLW = 22, DVAE_S_DTC = 23,
   DVAE_NSCAL = 32
 };
@@ -250,7 +263,8 @@ int dvae_fc_chain_rows(int n);
  * ml[B,2D] is the interleaved output of mu_logvar_gen (encoders.py:87: mu = ml[:,0::2],
  * logvar = ml[:,1::2]).  z = mu + exp(.5 logvar) eps (eps == NULL: z = mu, eval mode).
  * kl_dim (may be NULL): float[DVAE_KL_FLOATS]; [0,D) = coef[INV_B] * sum_b 0.5(-1 - lv + mu^2 + e^lv),
- * the rest (kl_dim + 16) holds per-workgroup partial sums, blocks of 16 floats.  With kl_dim != NULL and coef == NULL
+ * the rest (kl_dim + 16) holds per-workgroup partial sums, blocks of 16 floats (D <= DVAE_MAX_D; above, kl_dim is just the
+ * D final values, kl_dim != NULL needs coef, and D must fit the buffer).  With kl_dim != NULL and coef == NULL
  * only the dvae_reparam_kl_blocks(B) partial blocks are written (no finishing launch): dvae_loss_epilogue(kl_blocks = that
  * count) or dvae_kl_finish completes them -- every consumer adds the blocks in the same fixed order.            */
 #define DVAE_KL_MAX_BLOCKS 8192
@@ -299,8 +313,8 @@ int dvae_convT4s2_sigmoid_recon_fwd(const float* x, int x_layout, const float* w
  * z,mu,logvar: [Bg,D] (the whole -- global -- batch); this call evaluates rows
  * [row0,row0+Bl).  log_w = {log(1/N), log(strat), log(1/M)} in fp32 as the reference
  * computes them (math.py:66-73), ignored when is_mss == 0.
- * rowstats[Bl,DVAE_ROWSTATS]: log_pz, log_qz, log_prod_qzi, log_q_zCx, lse_d[0..D-1]  (1 <= D <= DVAE_BTCVAE_MAX_D).
- * tmp[3*Bg*D]: scratch filled by fwd with the transposed per-column constants (mu, -0.5(log
+ * rowstats[Bl,DVAE_ROWSTATS_STRIDE(D)]: log_pz, log_qz, log_prod_qzi, log_q_zCx, lse_d[0..D-1]  (any D >= 1).
+ * tmp[DVAE_BTCVAE_TMP_FLOATS(Bg,Bl,D)]: scratch filled by fwd with the transposed per-column constants (mu, -0.5(log
  * 2pi + logvar), exp(-logvar)) and re-read by bwd: pass the same buffer to both.             */
 int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg, int D, int row0,
                     int Bl, int is_mss, const float* log_w, float* tmp, float* rowstats, void* stream);
@@ -322,7 +336,7 @@ int dvae_disc_losses(const float* dlogits, int Bh, const float* coef, float* sum
                      float* g_tc, void* stream);
 
 /* ---- entropy estimator of the MIG / AAM metrics: evaluate.py:233-297 (_estimate_latent_entropies) -------
- * H[d] = 1/S sum_s [ log N - logsumexp_n log N(z_ds[d,s]; mean[n,d], exp(logvar[n,d])) ],  d < D <= DVAE_MAX_D.
+ * H[d] = 1/S sum_s [ log N - logsumexp_n log N(z_ds[d,s]; mean[n,d], exp(logvar[n,d])) ],  d < D (any D).
  * z_ds[D,S]: the S sampled latents exactly as the reference lays them out -- the [S,D] gather of sampled rows
  * re-viewed as [D,S] (evaluate.py:262, a reshape, not a transpose); mean, logvar: [N,D] (the whole data set or a
  * conditional slice of it).  ws: dvae_latent_entropy_ws_floats(N, D, S) floats.                          */
@@ -331,11 +345,12 @@ int dvae_latent_entropy(const float* z_ds, const float* mean, const float* logva
                         float* ws, float* H, void* stream);
 
 /* ---- scalar epilogue of the loss plugins: losses.py:139-153,186-202,268-274,369-389 -------
- * dvae_loss_pack reduces this rank's partial sums into packed[DVAE_NPACK]:
+ * dvae_loss_pack reduces this rank's partial sums into packed[DVAE_NPACK_D(D)]:
  *   [0] sum of rec_partials, [1..16] kl_dim, [17..20] column sums of rowstats[:,0..3]
- *   (log_pz, log_qz, log_prod_qzi, log_q_zCx), [21..23] discriminator sums.
+ *   (log_pz, log_qz, log_prod_qzi, log_q_zCx), [21..23] discriminator sums; D > DVAE_MAX_D: kl_dim at [32..32+D), [1..16] zero,
+ *   rowstats with stride DVAE_ROWSTATS_STRIDE(D).
  * When the batch is sharded over ranks, sum-all-reduce `packed` before dvae_loss_finalize.
- * dvae_loss_finalize(kind = DVAE_LOSS_*) writes scal[DVAE_NSCAL]; Bg = global batch
+ * dvae_loss_finalize(kind = DVAE_LOSS_*) writes scal[DVAE_NSCAL_D(D)]; Bg = global batch
  * (btcvae) or global half batch (factor).                                                   */
 #define DVAE_NPACK 32
 int dvae_loss_pack(const float* rec_partials, const float* kl_dim, int D, const float* rowstats, int Bl,

@@ -26,7 +26,7 @@ def test_header_symbols_exported():
 def test_ctypes_table_matches_header():
     assert sorted(_lib.SIGNATURES) == _declared()
     h = _lib.lib()
-    assert h.dvae_version() == 107
+    assert h.dvae_version() == 108
     assert h.dvae_conv_wgrad_ws_floats() > 4_000_000
 
 
@@ -113,3 +113,30 @@ def test_argument_structs_have_the_headers_layout(tmp_path):
         decl = re.sub(r"\[[^\]]*\]", "", decl)                # array members: name[N]
         names = re.findall(r"[\*\s,]([A-Za-z_][A-Za-z_0-9]*)\s*(?=[,;])", re.sub(r"/\*.*?\*/", "", decl, flags=re.S))
         assert names == [n for n, _ in cls._fields_], (cname, names)
+
+
+def test_latent_layout_macros_match_the_python_helpers(tmp_path):
+    """The D-dependent buffer layouts of include/dvae_hip.h (DVAE_ROWSTATS_STRIDE, DVAE_BTCVAE_TMP_FLOATS, DVAE_NPACK_D,
+    DVAE_NSCAL_D, DVAE_WIDE_KL0: latent dimensions above DVAE_MAX_D use the "wide" layouts) evaluated by gcc == the helpers of
+    disvae_amd/_lib.py that size the buffers.  A mismatch would make a kernel write past a buffer the Python side allocated."""
+    import shutil
+    import subprocess
+    from disvae_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    dims = [1, 3, 10, 16, 17, 20, 28, 29, 32, 33, 64, 100, 1000]
+    body = ['printf("max %d kl0 %d\\n", DVAE_MAX_D, DVAE_WIDE_KL0);']
+    for D in dims:
+        body.append('printf("%d %%d %%zu %%d %%d\\n", DVAE_ROWSTATS_STRIDE(%d), DVAE_BTCVAE_TMP_FLOATS(1024, 128, %d), '
+                    'DVAE_NPACK_D(%d), DVAE_NSCAL_D(%d));' % (D, D, D, D, D))
+    src = tmp_path / "macros.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dvae_hip.h"\nint main(void) {\n' + "\n".join(body) + "\nreturn 0;\n}\n")
+    exe = tmp_path / "macros"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    lines = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert lines[0].split() == ["max", str(_lib.MAX_LATENT_DIM), "kl0", str(_lib.WIDE_KL0)]
+    for D, line in zip(dims, lines[1:]):
+        got = [int(x) for x in line.split()]
+        assert got == [D, _lib.rowstats_stride(D), _lib.btcvae_tmp_floats(1024, 128, D), _lib.npack(D), _lib.nscal(D)], (D, got)
+        assert _lib.rowstats_stride(D) >= 4 + D and _lib.kl0(D) + D <= _lib.nscal(D)

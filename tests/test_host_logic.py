@@ -193,20 +193,16 @@ def test_bench_algorithmic_flops_match_survey():
 
 
 def test_latent_dim_limits_are_reported_clearly():
-    """unsupported latent dimensions must fail at construction / first use with a clear message, not
-    with a generic 'bad argument' from the C-ABI at the first training step."""
+    """a latent dimension the model cannot have must fail at construction with a clear message, not with a generic
+    'bad argument' from the C-ABI at the first training step.  (Round 5: every positive integer is a valid dimension --
+    test_any_latent_dim_is_accepted_for_every_loss; what remains to refuse is what is not one.)"""
     import pytest
     from disvae_amd.models.vae import init_specific_model
-    from disvae_amd.models.losses import BtcvaeLoss
-    for D in (1, 10, 16):
+    for D in (1, 10, 16, 17, 64):
         assert init_specific_model("Burgess", (1, 32, 32), D).latent_dim == D
-    with pytest.raises(ValueError, match="latent_dim"):
-        init_specific_model("Burgess", (1, 32, 32), 17)
-    with pytest.raises(ValueError, match="latent_dim"):
-        init_specific_model("Burgess", (1, 32, 32), 0)
-    with pytest.raises(ValueError, match="btcvae: latent_dim=17"):
-        BtcvaeLoss(1000)._check_latent_dim(17)
-    BtcvaeLoss(1000)._check_latent_dim(16)
+    for D in (0, -3, 10.0):
+        with pytest.raises(ValueError, match="latent_dim"):
+            init_specific_model("Burgess", (1, 32, 32), D)
 
 
 def test_unknown_replay_mode_is_reported(monkeypatch):
@@ -390,26 +386,36 @@ def test_kernel_addressing_emulations(script):
 
 
 @pytest.mark.parametrize("loss", ["VAE", "betaH", "betaB", "factor", "btcvae"])
-def test_latent_dim_above_16_is_refused_loudly_for_every_loss(loss):
-    """main.py:81 takes any --latent-dim and disvae/models/losses.py:523-544 is dimension-agnostic; the fused HIP kernels cover
-    1..16 (include/dvae_hip.h: DVAE_MAX_D).  A larger value must fail at construction with a message that names the limit --
-    for every loss plugin, since all of them train the same native model -- never run with truncated latents."""
+def test_any_latent_dim_is_accepted_for_every_loss(loss):
+    """main.py:81 takes any --latent-dim and disvae/models/losses.py:523-544 is dimension-agnostic.  The fused HIP kernels
+    cover 1..16 (include/dvae_hip.h: DVAE_MAX_D); above that the engine switches to the run-time-D kernels (csrc/latent_wide.hip,
+    tests/test_gpu_wide_latent.py) -- nothing is refused and nothing is truncated: the model carries 2D / D-wide layers, the
+    loss plugin's buffers follow the "wide" layouts.  What IS refused: values that are not positive integers."""
     from disvae_amd.models.vae import init_specific_model, VAE
-    from disvae_amd.models.losses import get_loss_f, BtcvaeLoss
+    from disvae_amd.models.losses import get_loss_f
     from disvae_amd import _lib
     assert _lib.MAX_LATENT_DIM == 16
-    for D in (17, 32, 0, -1):
+    for D in (0, -1, 2.5, "10", True, None):
         with pytest.raises(ValueError, match="latent_dim"):
             init_specific_model("Burgess", (1, 32, 32), D)
         with pytest.raises(ValueError, match="latent_dim"):
             VAE((3, 64, 64), latent_dim=D)
-    init_specific_model("Burgess", (1, 32, 32), 16)                      # the largest accepted
+    for D in (1, 16, 17, 32, 100):
+        m = init_specific_model("Burgess", (1, 32, 32), D)
+        sd = m.state_dict()
+        assert sd["encoder.mu_logvar_gen.weight"].shape == (2 * D, 256) and sd["decoder.lin1.weight"].shape == (256, D)
+        assert (_lib.wide(D), _lib.kl0(D)) == ((False, _lib.S_KL0) if D <= 16 else (True, _lib.WIDE_KL0))
     hp = dict(rec_dist="bernoulli", reg_anneal=0, betaH_B=4, betaB_initC=0, betaB_finC=25, betaB_G=1000, factor_G=6.4,
               latent_dim=17, lr_disc=1e-4, btcvae_A=1, btcvae_B=6, btcvae_G=1, n_data=1000, device=torch.device("cpu"))
-    loss_f = get_loss_f(loss, **hp)                                      # the plugin itself holds no latent-sized state ...
-    if loss == "btcvae":                                                 # ... and the one kernel with a per-dimension register file says so
-        with pytest.raises(ValueError, match="latent_dim=17"):
-            BtcvaeLoss._check_latent_dim(17)
-        z = torch.zeros(4, 17)
-        with pytest.raises(ValueError, match="latent_dim=17"):
-            loss_f(torch.zeros(4, 1, 32, 32), torch.zeros(4, 1, 32, 32), (z, z), True, None, latent_sample=z)
+    loss_f = get_loss_f(loss, **hp)                                      # the plugin itself holds no latent-sized state
+    if loss == "factor":
+        assert loss_f.discriminator.state_dict()["lin1.weight"].shape == (1000, 17)
+    # the logged scalars of a wide step: kl_loss_i is read at scal[DVAE_WIDE_KL0 + i]
+    from collections import defaultdict
+    st = defaultdict(list)
+    vals = list(range(_lib.nscal(20)))
+    type(loss_f)._store_kl(st, vals, 20)
+    assert st["kl_loss_0"] == [32] and st["kl_loss_19"] == [51] and st["kl_loss"] == [_lib.S_KL]
+    st = defaultdict(list)
+    type(loss_f)._store_kl(st, vals, 10)
+    assert st["kl_loss_0"] == [_lib.S_KL0] and st["kl_loss_9"] == [_lib.S_KL0 + 9]
