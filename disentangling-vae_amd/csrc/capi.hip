@@ -60,7 +60,8 @@ static int run_wgrad(const float* big, int big_layout, const float* small, int s
     if ((Cb == 1 || Cb == 3) && Hs == 32 && big_layout == DVAE_NCHW)
       return launch_wgrad_thin(big, small, dw, db, bias_from_big, N, Cb, Hs, ws, s);
   }
-  return launch_wgrad_generic(big, big_layout, small, small_layout, dw, db, bias_from_big, N, Cb, Cs, Hs, Ws, s);
+  return launch_wgrad_generic(big, big_layout, small, small_layout, dw, db, bias_from_big, N, Cb, Cs, Hs, Ws, ws,
+                              dvae_conv_wgrad_ws_floats(), s);
 }
 
 }  // namespace dvae

@@ -140,8 +140,8 @@ struct ConvArgs {
 int launch_down_generic(const ConvArgs& a, hipStream_t s);
 int launch_up_generic(const ConvArgs& a, hipStream_t s);
 int launch_wgrad_generic(const float* big, int big_layout, const float* small, int small_layout,
-                         float* dw, float* db, int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws,
-                         hipStream_t s);
+                         float* dw, float* db, int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws, float* ws,
+                         size_t ws_floats, hipStream_t s);
 // MFMA paths (32 <-> 32 channels, NHWC, Hs == Ws in {4,8,16}); return 1 if not applicable
 int launch_down_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_up_mfma32(const ConvArgs& a, hipStream_t s);

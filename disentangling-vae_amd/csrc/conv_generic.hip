@@ -129,6 +129,81 @@ __global__ __launch_bounds__(256) void k_wgrad_generic(const float* __restrict__
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// The same reduction with the positions split over gridDim.y chunks (round 5): one workgroup per (cs, cb) pair leaves most of
+// the chip idle and walks 16 K positions per thread-block at the 32x32 MNIST geometry (152 us per launch at 64 images, plus
+// 56 us of k_chansum on 32 -- or ONE -- workgroups: 60 % of that configuration's iteration).  Per-chunk partial sums
+// [chunk][pair][17] (16 taps + the pair's share of the bias gradient) go to the caller's workspace; k_wgrad_generic_fin adds
+// the chunks in order.  The bias sum rides on values the workgroup loads anyway: pair (cs, 0) sums the small-side channel cs
+// (Conv2d), pair (0, cb) the big-side channel cb through the taps kh, kw in {1, 2}, which visit every big pixel exactly once
+// and never leave the image (ConvTranspose2d).
+#define WGG_SLOTS 17
+__global__ __launch_bounds__(256) void k_wgrad_generic_part(const float* __restrict__ big, Strides sb,
+                                                            const float* __restrict__ small, Strides ss,
+                                                            float* __restrict__ part, int N, int Cb, int Cs, int Hs, int Ws,
+                                                            int bias_from_big) {
+  const int cs = blockIdx.x / Cb, cb = blockIdx.x % Cb;
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  float acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+  float bsum = 0.f;
+  const long total = (long)N * Hs * Ws;
+  const long chunk = (total + gridDim.y - 1) / gridDim.y;
+  const long p0 = blockIdx.y * chunk, p1 = p0 + chunk < total ? p0 + chunk : total;
+  for (long p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    int sx = p % Ws; long r = p / Ws; int sy = r % Hs; int n = r / Hs;
+    float sv = small[n * ss.n + cs * ss.c + sy * ss.h + sx * ss.w];
+    if (!bias_from_big) bsum += sv;
+    const float* bp = big + n * sb.n + cb * sb.c;
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+      int by = 2 * sy - 1 + kh;
+      if (by < 0 || by >= Hb) continue;
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) {
+        int bx = 2 * sx - 1 + kw;
+        if (bx < 0 || bx >= Wb) continue;
+        const float bv = bp[by * sb.h + bx * sb.w];
+        acc[kh * 4 + kw] = fmaf(sv, bv, acc[kh * 4 + kw]);
+        if (bias_from_big && (kh == 1 || kh == 2) && (kw == 1 || kw == 2)) bsum += bv;
+      }
+    }
+  }
+  __shared__ float red[4][WGG_SLOTS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    float v = wave_sum(acc[t]);
+    if (lane == 0) red[wv][t] = v;
+  }
+  {
+    float v = wave_sum(bsum);
+    if (lane == 0) red[wv][16] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < WGG_SLOTS)
+    part[((long)blockIdx.y * gridDim.x + blockIdx.x) * WGG_SLOTS + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void k_wgrad_generic_fin(const float* __restrict__ part, int chunks, int npairs, int Cb, int Cs,
+                                    float* __restrict__ dw, float* __restrict__ db, int bias_from_big) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < npairs * 16) {
+    const int pair = idx >> 4, t = idx & 15;
+    float v = 0.f;
+    for (int c = 0; c < chunks; ++c) v += part[((long)c * npairs + pair) * WGG_SLOTS + t];
+    dw[idx] = v;
+  }
+  const int nb = bias_from_big ? Cb : Cs;
+  if (db && idx < nb) {
+    const int pair = bias_from_big ? idx : idx * Cb;      // (cs = 0, cb = idx)  |  (cs = idx, cb = 0)
+    float v = 0.f;
+    for (int c = 0; c < chunks; ++c) v += part[((long)c * npairs + pair) * WGG_SLOTS + 16];
+    db[idx] = v;
+  }
+}
+
 // db[c] = sum over n,h,w of t[n,c,h,w]; one block per channel
 __global__ __launch_bounds__(256) void k_chansum(const float* __restrict__ t, Strides st, float* __restrict__ db,
                                                  int N, int H, int W) {
@@ -174,9 +249,24 @@ int launch_up_generic(const ConvArgs& a, hipStream_t s) {
 }
 
 int launch_wgrad_generic(const float* big, int big_layout, const float* small, int small_layout, float* dw,
-                         float* db, int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws, hipStream_t s) {
+                         float* db, int bias_from_big, int N, int Cb, int Cs, int Hs, int Ws, float* ws, size_t ws_floats,
+                         hipStream_t s) {
   Strides sb = make_strides(big_layout, Cb, 2 * Hs, 2 * Ws);
   Strides ss = make_strides(small_layout, Cs, Hs, Ws);
+  // positions split over chunks when the caller lent a workspace: >= 4 positions per thread and chunk, at most 64 chunks
+  const long total = (long)N * Hs * Ws, npairs = (long)Cs * Cb;
+  long chunks = total / 1024;
+  if (chunks > 64) chunks = 64;
+  if (ws && chunks >= 2 && npairs <= 65535 && (size_t)(chunks * npairs * WGG_SLOTS) <= ws_floats) {
+    hipLaunchKernelGGL(k_wgrad_generic_part, dim3((unsigned)npairs, (unsigned)chunks), dim3(256), 0, s, big, sb, small, ss, ws, N,
+                       Cb, Cs, Hs, Ws, bias_from_big);
+    DVAE_CHECK_LAUNCH();
+    const long nthr = npairs * 16;
+    hipLaunchKernelGGL(k_wgrad_generic_fin, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, ws, (int)chunks, (int)npairs,
+                       Cb, Cs, dw, db, bias_from_big);
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(k_wgrad_generic, dim3(Cs * Cb), dim3(256), 0, s, big, sb, small, ss, dw, N, Cb, Cs, Hs, Ws);
   DVAE_CHECK_LAUNCH();
   if (db) {

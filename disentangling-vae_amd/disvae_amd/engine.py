@@ -257,6 +257,9 @@ class VAEEngine:
         #          early as the data allows (profiles/r03_v2_timeline_b128.md: backward pass 287 us against ~150 us of
         #          dependent work).  Set per step by the loss plugins (BaseLoss._streams).
         self.eager_wgrad = False
+        # encoder weight gradients the MAIN stream computes after conv1's, at the very end of the backward pass (the balance of
+        # the two streams' tails).  Set per step by the loss plugins (BaseLoss._streams).
+        self.tail_main = _TAIL_MAIN
         self._fork_hook = None
         # 64x64 images with 1 / 3 channels: the forward kernels of conv1 and convT2 also emit the sign bits of their outputs and
         # the input-gradient kernels of conv2 and convT3 read those instead of the 32x32x32 fp32 activations (dvae_*_bits)
@@ -803,7 +806,7 @@ class VAEEngine:
                     self._conv_wgrad(*wargs, fork=False, main=True)
                 for w_ in tail_main:
                     self._conv_wgrad(*w_, fork=False, main=True)
-            elif name in _TAIL_MAIN and self.is64 and not self.single_stream:
+            elif name in self.tail_main and self.is64 and not self.single_stream:
                 tail_main.append(wargs)
             elif big:
                 self.fork_side()

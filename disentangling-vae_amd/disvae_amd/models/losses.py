@@ -182,6 +182,9 @@ class BaseLoss(abc.ABC):
         single = mode == "1" or (mode == "auto" and data.numel() <= self.SINGLE_STREAM_ELEMS)
         model.engine.single_stream = bool(single) and self._world()[0] == 1
         model.engine.eager_wgrad = data.numel() <= int(knob("DVAE_EAGER_WGRAD_ELEMS", self.EAGER_WGRAD_ELEMS))
+        tm = knob("DVAE_TAIL_MAIN", "default")      # A/B (DVAE_DEBUG=1): which encoder weight gradients end the main stream
+        if tm != "default":
+            model.engine.tail_main = tuple(v for v in tm.split(",") if v)
         return model.engine.single_stream
 
     def _replay_mode(self, is_train, data):
@@ -198,7 +201,7 @@ class BaseLoss(abc.ABC):
         batch pointer, the stream, and the few Python-side switches passed as scalars."""
         return (id(model), data.shape, data.data_ptr(), injected, _stream(), model.arena.flat.data_ptr(),
                 model.arena.grad.data_ptr(), _lib.ALLOC_GEN[0], self.rec_dist, getattr(self, "is_mss", None),
-                model.engine.single_stream, model.engine.eager_wgrad, id(self.comm), self.estimator)
+                model.engine.single_stream, model.engine.eager_wgrad, model.engine.tail_main, id(self.comm), self.estimator)
 
     @abc.abstractmethod
     def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):

@@ -26,6 +26,7 @@ CONV_CASES = [
     (3, 32, 32, _lib.NHWC), (70, 32, 32, _lib.NHWC),       # conv2 (MFMA HS=16; 280 units > 256 workgroups)
     (5, 32, 16, _lib.NHWC), (6, 32, 8, _lib.NHWC), (9, 32, 8, _lib.NHWC),   # conv3 / conv_64 (tails)
     (2, 1, 32, _lib.NCHW),                                  # MNIST geometry -> generic kernel
+    (64, 1, 32, _lib.NCHW), (37, 3, 32, _lib.NCHW),         # ... at batches where its weight gradient splits the positions over chunks
 ]
 
 
@@ -73,6 +74,7 @@ CONVT_CASES = [
     (3, 32, 1, _lib.NCHW, _lib.ACT_SIGMOID), (5, 32, 3, _lib.NCHW, _lib.ACT_SIGMOID),
     (200, 32, 3, _lib.NCHW, _lib.ACT_SIGMOID), (193, 32, 1, _lib.NCHW, _lib.ACT_SIGMOID),   # convT3: its input gradient on conv_thin_ws.hip
     (2, 16, 1, _lib.NCHW, _lib.ACT_SIGMOID),
+    (64, 16, 1, _lib.NCHW, _lib.ACT_SIGMOID), (37, 16, 3, _lib.NCHW, _lib.ACT_SIGMOID),   # MNIST geometry: split generic weight gradient, bias from the big side
 ]
 
 
