@@ -221,6 +221,14 @@ class BaseLoss(abc.ABC):
             self._scratch = _Scratch(device)
         return self._scratch
 
+    def _pack_sums(self, sc, klb, D, rowstats, Bl, disc_sums, packed, stream):
+        """This rank's partial sums -> `packed` (sharded batches: sum-all-reduced over the ranks before dvae_loss_finalize) in
+        ONE launch: dvae_loss_epilogue without `scal` is dvae_kl_finish (the klb KL partial blocks the fused FC chain left) +
+        dvae_loss_pack, bit for bit (tests/test_gpu_kernels.py::test_loss_epilogue_equals_pack_then_finalize) -- one dependent
+        launch less on the exchange stream, which the FC chain's input gradients wait for."""
+        call("dvae_loss_epilogue", _lib.LOSS_BETAH, ptr(sc.partials), ptr(sc.kl_dim), klb, D, ptr(rowstats), Bl, ptr(disc_sums), 1,
+             ptr(sc.coef), ptr(packed), None, stream)
+
     def _rec_code(self):
         if self.rec_dist not in _lib.REC:
             assert self.rec_dist not in RECON_DIST
@@ -524,9 +532,7 @@ class _SingleOptimizerLoss(BaseLoss):
                     call("dvae_stream_order", eng._side_raw(), ss)
                     xbuf = lat["xbuf"]
                     packed = sc.packed if xbuf is None else xbuf[xbuf.numel() - npk:]
-                    if klb:
-                        call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, ss)
-                    call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(packed), ss)
+                    self._pack_sums(sc, klb, D, rowstats, B, None, packed, ss)
                     with torch.cuda.stream(eng.aux_stream):
                         if xbuf is None:
                             self.comm.all_reduce(packed)
@@ -536,9 +542,7 @@ class _SingleOptimizerLoss(BaseLoss):
                 call("dvae_event_record", self._ev_slot, ss)
             eng.at_next_fork(epilogue)
         elif world > 1:
-            if klb:
-                call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, s)
-            call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, ptr(rowstats), B, None, ptr(sc.packed), s)
+            self._pack_sums(sc, klb, D, rowstats, B, None, sc.packed, s)
             self.comm.all_reduce(sc.packed)
             call("dvae_loss_finalize", self.KIND, ptr(sc.packed), D, Bg, ptr(sc.coef), ptr(sc.scal), s)
         else:
@@ -781,9 +785,7 @@ class FactorKLoss(BaseLoss):
                 call("dvae_loss_epilogue", _lib.LOSS_FACTOR, ptr(sc.partials), ptr(sc.kl_dim), klb, D, None, 0,
                      ptr(sc.disc_sums), Bhg, ptr(sc.coef), ptr(sc.packed), ptr(sc.scal), stream)
                 return
-            if klb:
-                call("dvae_kl_finish", ptr(sc.kl_dim), klb, ptr(sc.coef), D, stream)
-            call("dvae_loss_pack", ptr(sc.partials), ptr(sc.kl_dim), D, None, 0, ptr(sc.disc_sums), ptr(sc.packed), stream)
+            self._pack_sums(sc, klb, D, None, 0, sc.disc_sums, sc.packed, stream)
             with torch.cuda.stream(eng.aux_stream if on_side else torch.cuda.current_stream()):
                 self.comm.all_reduce(sc.packed)
             call("dvae_loss_finalize", _lib.LOSS_FACTOR, ptr(sc.packed), D, Bhg, ptr(sc.coef), ptr(sc.scal), stream)
