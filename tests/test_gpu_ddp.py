@@ -129,12 +129,15 @@ def test_sharded_step_matches_global_batch(loss):
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
+@pytest.mark.parametrize("replay", [None, "plan"])
 @pytest.mark.parametrize("transport", ["torch", "rccl"])
 @pytest.mark.parametrize("loss", ["btcvae", "factor"])
-def test_sharded_step_over_rccl_on_all_visible_gpus(loss, transport):
+def test_sharded_step_over_rccl_on_all_visible_gpus(loss, transport, replay):
     """The real thing: one rank per GPU over RCCL (backend nccl), both transports (torch.distributed collectives and
-    the C-ABI's dvae_comm_*), sharded step == single-process step on the global batch.  Needs >= 2 GPUs: skipped on the
-    1-GPU test boxes, runs on the multi-GPU node of the scaling tier."""
+    the C-ABI's dvae_comm_*), sharded step == single-process step on the global batch -- issued eagerly (one iteration) and
+    from the recorded launch plan, which is what "auto" selects at these sizes (three iterations: record, record again after the
+    first iteration's allocations, replay; every one compared with the eager single-process step).  Needs >= 2 GPUs: skipped on
+    the 1-GPU test boxes, runs on the multi-GPU node of the scaling tier."""
     n = torch.cuda.device_count()
     if n < 2:
         pytest.skip("needs >= 2 visible GPUs (%d here)" % n)
@@ -142,7 +145,7 @@ def test_sharded_step_over_rccl_on_all_visible_gpus(loss, transport):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, loss, q, "nccl", transport, r)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, loss, q, "nccl", transport, r, replay)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = [q.get(timeout=280) for _ in range(world)]
