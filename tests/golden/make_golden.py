@@ -2,7 +2,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
 
-    python tests/golden/make_golden.py [--latent | --metrics | --bench-size]
+    python tests/golden/make_golden.py [--latent | --wide-latent | --metrics | --bench-size]
 
 The reference is imported unmodified with the two import shims of SURVEY.md section 8c
 (stub ``imageio``; ``numpy.product = numpy.prod``).  Noise is recorded by wrapping
@@ -224,6 +224,15 @@ def main():
                 del out[k]
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
             print(name, "loss", [out["step%d/loss" % s] for s in range(steps)], os.path.getsize(os.path.join(HERE, name + ".npz")), "bytes")
+        return
+    if "--wide-latent" in sys.argv:   # latent dimensions above 16 (the engine's run-time-D kernels): only these files are written
+        for name, loss, img, b, steps, seed, n_data, lr, zdim in [
+                ("btcvae_z32_celeba", "btcvae", (3, 64, 64), 6, 2, 4321, 202599, 5e-4, 32),
+                ("factor_z20_dsprites", "factor", (1, 64, 64), 8, 2, 4321, 737280, 1e-4, 20),
+                ("vae_z24_mnist", "VAE", (1, 32, 32), 8, 2, 4321, 60000, 5e-4, 24)]:
+            out = run_case(ref, loss, img, b, steps, seed, n_data, lr, latent_dim=zdim)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "loss", [out["step%d/loss" % s] for s in range(steps)])
         return
     if "--latent" in sys.argv:        # latent dimensions other than the default 10 (main.py -z): only these files are written
         for name, loss, img, b, steps, seed, n_data, lr, zdim in [

@@ -345,3 +345,74 @@ def test_latent_entropy_above_16_latents():
         ld = -0.5 * (math.log(2 * math.pi) + lv[:, d, None]) - 0.5 * (zv[d][None, :] - m[:, d, None]) ** 2 * torch.exp(-lv[:, d, None])
         ref[d] = (math.log(N) - torch.logsumexp(ld, 0)).mean()
     check(H, ref, rtol=1e-4, atol_rel=1e-5, what="H")
+
+
+@pytest.mark.parametrize("name,loss,img,B,steps", [("btcvae_z32_celeba", "btcvae", (3, 64, 64), 6, 2), ("vae_z24_mnist", "VAE", (1, 32, 32), 8, 2)])
+def test_trainer_vs_reference_golden_above_16_latents(name, loss, img, B, steps):
+    """The REAL reference's recorded numbers at latent dimensions 32 and 24 (tests/golden/make_golden.py --wide-latent ran
+    disvae's own Trainer._train_iteration): same seed -> same initial weights; same data and injected eps -> its losses, storer
+    scalars (kl_loss_0 .. kl_loss_{D-1}), gradient and parameter digests -- the bounds of test_trainer_vs_reference_golden."""
+    from golden_util import load, tensor_digest, assert_digest_close
+    g = load(name)
+    D = int(g["latent_dim"])
+    model, opt, loss_f, _ = _model(loss, img, D, int(g["seed"]), int(g["n_data"]), float(g["lr"]))
+    for k, v in model.state_dict().items():   # same seed -> identical weights (sums: thread-count dependent order)
+        d = tensor_digest(v)
+        np.testing.assert_array_equal(d[2:], g["init_digest/" + k][2:], err_msg=k)
+        np.testing.assert_allclose(d[:2], g["init_digest/" + k][:2], rtol=1e-12, err_msg=k)
+    gen = torch.Generator().manual_seed(int(g["seed"]) + 1)
+    for s in range(steps):
+        data = torch.rand((B,) + tuple(img), generator=gen)
+        storer = defaultdict(list)
+        out = loss_f.fused_step(dev(data), model, opt, storer, eps=dev(torch.from_numpy(g["step%d/randn0" % s])))
+        np.testing.assert_allclose(out.item(), g["step%d/loss" % s], rtol=2e-5 if s == 0 else 1e-3)
+        for k, v in storer.items():
+            np.testing.assert_allclose(v[0], g["step%d/storer/%s" % (s, k)], rtol=5e-5, atol=1e-6, err_msg=k)
+        assert len(storer) == len([k for k in g if k.startswith("step%d/storer/" % s)])
+        if s == 0:
+            assert "kl_loss_%d" % (D - 1) in storer
+        gr, ga = (2e-3, 2e-3) if s == 0 else (3e-2, 3e-2)
+        for k, p in model.named_parameters():
+            assert_digest_close(tensor_digest(p.grad), g["step%d/grad_digest/%s" % (s, k)], rtol=gr, atol_scale=ga,
+                                what="%s step%d grad %s" % (name, s, k))
+            assert_digest_close(tensor_digest(p), g["step%d/param_digest/%s" % (s, k)], rtol=1e-2, atol_scale=2e-2,
+                                what="%s step%d param %s" % (name, s, k))
+    model.eval()
+    with torch.no_grad():
+        recon, (mu, logvar), z = model(dev(data))
+    np.testing.assert_allclose(mu.cpu().numpy(), g["eval/mu"], rtol=2e-3, atol=2e-4)
+    assert torch.equal(z, mu)
+
+
+def test_factor_vs_reference_golden_at_20_latents():
+    """FactorVAE with latent_dim 20 against the real reference's recorded iteration (both optimizers, quirks Q1 / Q4): loss,
+    storer scalars, VAE and discriminator gradient / parameter digests -- the bounds of test_factor_vs_reference_golden."""
+    from golden_util import load, tensor_digest, assert_digest_close
+    name, img = "factor_z20_dsprites", (1, 64, 64)
+    g = load(name)
+    D = int(g["latent_dim"])
+    model, opt, loss_f, _ = _model("factor", img, D, int(g["seed"]), int(g["n_data"]), float(g["lr"]))
+    for k, v in loss_f.discriminator.state_dict().items():
+        d = tensor_digest(v)
+        np.testing.assert_array_equal(d[2:], g["dinit_digest/" + k][2:], err_msg=k)
+        np.testing.assert_allclose(d[:2], g["dinit_digest/" + k][:2], rtol=1e-12, err_msg=k)
+    gen = torch.Generator().manual_seed(int(g["seed"]) + 1)
+    for s in range(2):
+        data = torch.rand((8,) + tuple(img), generator=gen)
+        noise = (dev(torch.from_numpy(g["step%d/randn1" % s])), dev(torch.from_numpy(g["step%d/randn2" % s])),
+                 torch.from_numpy(g["step%d/perms" % s]))
+        assert noise[0].shape == (4, D) and noise[2].shape == (D, 4)
+        storer = defaultdict(list)
+        out = loss_f.call_optimize(dev(data), model, opt, storer, noise=noise)
+        np.testing.assert_allclose(out.item(), g["step%d/loss" % s], rtol=2e-5 if s == 0 else 1e-3)
+        for k, v in storer.items():
+            np.testing.assert_allclose(v[0], g["step%d/storer/%s" % (s, k)], rtol=5e-5, atol=1e-6, err_msg=k)
+        gr, ga = (2e-3, 2e-3) if s == 0 else (3e-2, 3e-2)
+        for k, p in model.named_parameters():
+            assert_digest_close(tensor_digest(p.grad), g["step%d/grad_digest/%s" % (s, k)], rtol=gr, atol_scale=ga,
+                                what="%s step%d grad %s" % (name, s, k))
+        for k, p in loss_f.discriminator.named_parameters():
+            assert_digest_close(tensor_digest(p.grad), g["step%d/dgrad_digest/%s" % (s, k)], rtol=gr, atol_scale=ga,
+                                what="%s step%d dgrad %s" % (name, s, k))
+            assert_digest_close(tensor_digest(p), g["step%d/dparam_digest/%s" % (s, k)], rtol=1e-2, atol_scale=2e-2,
+                                what="%s step%d dparam %s" % (name, s, k))

@@ -100,10 +100,13 @@ def test_single_optimizer_cases(name, loss, img, batch, steps):
     ("btcvae_z16_dsprites", "btcvae", (1, 64, 64), 8, 2, 16),
     ("btcvae_z3_mnist", "btcvae", (1, 32, 32), 6, 2, 3),
     ("betaB_z16_celeba", "betaB", (3, 64, 64), 4, 2, 16),
+    ("btcvae_z32_celeba", "btcvae", (3, 64, 64), 6, 2, 32),       # above 16: `make_golden.py --wide-latent`
+    ("vae_z24_mnist", "VAE", (1, 32, 32), 8, 2, 24),
 ])
 def test_other_latent_dimensions(name, loss, img, batch, steps, zdim):
-    """main.py -z: latent dimensions other than 10 (the largest the native engine takes, and a small one), recorded from the
-    real reference with `make_golden.py --latent`: initial weights bit for bit, losses, storer scalars, gradients, parameters"""
+    """main.py -z: latent dimensions other than 10 (the largest the FUSED kernels of the native engine take, a small one, and
+    two above 16 for its run-time-D kernels), recorded from the real reference with `make_golden.py --latent` /
+    `--wide-latent`: initial weights bit for bit, losses, storer scalars, gradients, parameters"""
     g = load(name)
     assert int(g["latent_dim"]) == zdim
     seed = int(g["seed"])
@@ -132,29 +135,31 @@ def test_other_latent_dimensions(name, loss, img, batch, steps, zdim):
                                 what="%s step%d param %s" % (name, s, k))
 
 
-@pytest.mark.parametrize("name,img", [("factor_dsprites", (1, 64, 64)), ("factor_celeba", (3, 64, 64))])
+@pytest.mark.parametrize("name,img", [("factor_dsprites", (1, 64, 64)), ("factor_celeba", (3, 64, 64)),
+                                      ("factor_z20_dsprites", (1, 64, 64))])
 def test_factor_cases(name, img):
     g = load(name)
     seed = int(g["seed"])
+    Z = int(g["latent_dim"]) if "latent_dim" in g else 10      # 10, or 20 (`make_golden.py --wide-latent`)
     torch.manual_seed(seed)
-    params = O.init_vae_params(img, 10)
-    dparams = O.init_disc_params(10)
+    params = O.init_vae_params(img, Z)
+    dparams = O.init_disc_params(Z)
     for k, v in params.items():
         np.testing.assert_array_equal(tensor_digest(v), g["init_digest/" + k], err_msg=k)
     for k, v in dparams.items():
         np.testing.assert_array_equal(tensor_digest(v), g["dinit_digest/" + k], err_msg=k)
-    hp = dict(HP, n_data=int(g["n_data"]))
-    tr = O.OracleTrainer("factor", hp, img, 10, lr=float(g["lr"]), lr_disc=HP["lr_disc"],
+    hp = dict(HP, n_data=int(g["n_data"]), latent_dim=Z)
+    tr = O.OracleTrainer("factor", hp, img, Z, lr=float(g["lr"]), lr_disc=HP["lr_disc"],
                          steps_anneal=HP["reg_anneal"], params=params, dparams=dparams)
     gen = torch.Generator().manual_seed(seed + 1)
     B = 8
     for s in range(2):
         data = torch.rand((B,) + tuple(img), generator=gen)
-        assert g["step%d/randn0" % s].shape == (B, 10)        # wasted full-batch draw (Q4)
+        assert g["step%d/randn0" % s].shape == (B, Z)         # wasted full-batch draw (Q4)
         eps1 = torch.from_numpy(g["step%d/randn1" % s])
         eps2 = torch.from_numpy(g["step%d/randn2" % s])
         perms = [torch.from_numpy(p) for p in g["step%d/perms" % s]]
-        assert len(perms) == 10 and perms[0].numel() == B // 2
+        assert len(perms) == Z and perms[0].numel() == B // 2
         loss_val, logs = tr.train_iteration(data, eps=eps1, eps2=eps2, perms=perms)
         np.testing.assert_allclose(loss_val, g["step%d/loss" % s], rtol=2e-6)
         if s == 0:
