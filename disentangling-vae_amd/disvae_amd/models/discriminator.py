@@ -100,8 +100,9 @@ class Discriminator(nn.Module):
         return b
 
     def _ws(self, side=False):
-        """Split-K workspace of the GEMM launches (one per stream: launches of the two streams run concurrently)."""
-        name = "_wsbuf_side" if side else "_wsbuf"
+        """Split-K workspace of the GEMM launches (one per stream: launches of different streams run concurrently).
+        side: False = the caller's stream, True = the engine's side stream, "aux" = its third stream."""
+        name = "_wsbuf_aux" if side == "aux" else ("_wsbuf_side" if side else "_wsbuf")
         if getattr(self, name, None) is None or getattr(self, name).device != self._arena.flat.device:
             _lib.note_alloc()
             setattr(self, name, torch.empty(_lib.lib().dvae_conv_wgrad_ws_floats(), dtype=torch.float32,
@@ -130,18 +131,21 @@ class Discriminator(nn.Module):
             x = b["h"][i]
         return x
 
-    def backward_raw(self, z, g_logits, M, rows=None, wgrad=True, chain="g", acts=None, side=None):
+    def backward_raw(self, z, g_logits, M, rows=None, wgrad=True, chain="g", acts=None, side=None, stream=None, ws=False):
         """Back-propagate g_logits[rows,2] through the MLP evaluated by forward_raw(z, M).
         rows < M restricts to the first `rows` samples (dgrad-only chain of quirk Q1).
         Returns the gradient w.r.t. z ([rows, latent]).
+        stream / ws: raw HIP stream to enqueue on instead of the current one, with the split-K workspace that belongs to it
+        (_ws's argument) -- FactorKLoss runs its second, input-gradient-only chain beside the first one.
         side: a VAEEngine -- the six weight gradients are then launched on ITS side stream, after ONE fork behind the chain of
         input gradients (every operand -- the saved activations, this chain's gradients -- is final by then): the weight
         gradients are only due at the end of the iteration, the chain's result is the next thing the critical path needs
         (163 us of weight gradients per step at 2048 rows: profiles/r04_final2_factor_celeba_timeline.md)."""
-        s = _stream()
+        s = _stream() if stream is None else stream
         b = self._act_buffers(M) if acts is None else acts
         R = M if rows is None else rows
         on_side = wgrad and side is not None and not side.single_stream
+        wsp = ptr(self._ws(ws))
         dy = g_logits
         dys = []
         for i in range(5, -1, -1):
@@ -149,11 +153,11 @@ class Discriminator(nn.Module):
             x_in = z if i == 0 else b["h"][i - 1]
             if wgrad and not on_side:
                 call("dvae_linear_wgrad", ptr(x_in), ptr(dy), ptr(self._arena.view(n + ".weight", grad=True)),
-                     ptr(self._arena.view(n + ".bias", grad=True)), R, self.dims[i], self.dims[i + 1], ptr(self._ws()), s)
+                     ptr(self._arena.view(n + ".bias", grad=True)), R, self.dims[i], self.dims[i + 1], wsp, s)
             dys.append((i, x_in, dy))
             gx = b[chain][i]
             call("dvae_linear_dgrad", ptr(dy), ptr(self._arena.view(n + ".weight")), None if i == 0 else ptr(x_in),
-                 ACT_LEAKY02 if i > 0 else ACT_NONE, ptr(gx), R, self.dims[i], self.dims[i + 1], ptr(self._ws()), s)
+                 ACT_LEAKY02 if i > 0 else ACT_NONE, ptr(gx), R, self.dims[i], self.dims[i + 1], wsp, s)
             dy = gx
         if on_side:
             side.fork_side()

@@ -803,16 +803,29 @@ class FactorKLoss(BaseLoss):
         # discriminator backward of d_tc_loss (weight grads + dz), losses.py:303-304
         # (its six weight gradients: on the side stream, behind one fork after the input-gradient chain)
         side_wg = not eng.single_stream and knob("DVAE_DISC_WGRAD_SIDE", "1") != "0"
+        # the second chain of input gradients (the tc term of vae_loss through D: first half, no weight gradients) depends on
+        # nothing the first one computes and could run beside it on the engine's third stream.  Measured, NOT shipped (A/B under
+        # DVAE_DEBUG=1, same box: factor_dsprites 0.583 vs 0.579-0.585 ms, factor_celeba 1.905 vs 1.885-1.892, tensor 512
+        # 0.831 vs 0.788-0.819: profiles/r05_v35_disc_chain2_ab.txt): the fork and the join cost the critical path what the
+        # overlap of two launch-bound chains buys, and at 2048 rows both chains fill the chip anyway.
+        par2 = (not eng.single_stream and world == 1 and knob("DVAE_DISC_CHAIN2_AUX", "0") == "1")
+        dz_b = None
+        if par2:
+            call("dvae_stream_order", s, eng._aux_raw())
+            dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2", stream=eng._aux_raw(), ws="aux")
         dz_a = disc.backward_raw(zin, g_dtc, 2 * Bh, wgrad=True, chain="g", side=eng if side_wg else None)
         pending = []
         if world > 1:      # the 16 MB discriminator gradients are final: their all-reduce runs under the whole VAE backward
             with torch.cuda.stream(eng.side_stream if side_wg else torch.cuda.current_stream()):
                 pending.append(self.comm.all_reduce_async(disc.arena.grad))
         # tc term of vae_loss through D: dgrad only, first half (its disc weight grads are zeroed at :303)
-        dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2")
+        if dz_b is None:
+            dz_b = disc.backward_raw(zin, g_tc, 2 * Bh, rows=Bh, wgrad=False, chain="g2")
 
         def fc_chain():
             # dz_a: quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1); dz_b: the tc term through D
+            if par2:
+                call("dvae_stream_order", eng._aux_raw(), s)
             if late_epi:
                 eng.flush_fork_hook()
                 call("dvae_event_wait", self._ev_slot, s)
