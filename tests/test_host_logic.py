@@ -368,6 +368,18 @@ def test_bench_cpu_baseline_leg_runs_the_port_and_calibrates_threads_once(monkey
     assert len(seen) - n_probe == 1, "the second leg re-uses the calibrated thread count"
 
 
+def test_wide_latent_kernel_math_emulation():
+    """tools/emu/latent_wide_math.py: the arithmetic and buffer layouts of csrc/latent_wide.hip (latent dimensions above 16)
+    restated kernel by kernel in fp64 and held to the oracle -- whole batch, row shards, the wide packed / scalar layouts."""
+    import runpy
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ns = runpy.run_path(os.path.join(root, "tools", "emu", "latent_wide_math.py"), run_name="__main__")
+    assert ns["N_CASES"] == 3
+    # the kernels read the layouts the emulation uses (include/dvae_hip.h macros, evaluated in tests/test_cabi_symbols.py)
+    src = open(os.path.join(root, "disentangling-vae_amd", "csrc", "latent_wide.hip")).read()
+    assert "DVAE_ROWSTATS_STRIDE(D)" in src and "tmp + (size_t)3 * D * Bg" in src
+
+
 @pytest.mark.parametrize("script", ["thin_ws_index_math.py", "gemm_dma_index_math.py"])
 def test_kernel_addressing_emulations(script):
     """tools/emu/*: lane-level numpy emulations of the LDS-DMA kernels' addressing (workgroup -> tile maps, per-lane transfer
