@@ -26,13 +26,13 @@ def _free_port():
     return p
 
 
-def _make(loss, lr):
+def _make(loss, lr, D=10):
     from disvae_amd.models.vae import init_specific_model
     from disvae_amd.models.losses import get_loss_f
     torch.manual_seed(1234)
-    model = init_specific_model("Burgess", IMG, 10)
+    model = init_specific_model("Burgess", IMG, D)
     opt = torch.optim.Adam(model.parameters(), lr=lr)
-    loss_f = get_loss_f(loss, n_data=202599, device=torch.device("cuda"), **HP)
+    loss_f = get_loss_f(loss, n_data=202599, device=torch.device("cuda"), **dict(HP, latent_dim=D))
     model.to("cuda").train()
     return model, opt, loss_f
 
@@ -264,7 +264,7 @@ def test_local_estimator_is_rank_average(loss):
         assert msg == "ok", "rank %d: %s" % (rank, msg)
 
 
-def _worker_mirrored(port, loss, q, transport, replay, world_emulated, Bl):
+def _worker_mirrored(port, loss, q, transport, replay, world_emulated, Bl, D=10):
     """ONE rank (RCCL, backend nccl) standing in for rank 0 of `world_emulated` ranks with identical shards
     (parallel.MirroredWorldComm): the whole sharded code path at world > 1 -- packed gather / scatter, loss-sum all-reduce, the
     gradient spans all-reduced asynchronously under the backward pass, through the product transports -- must equal the
@@ -280,13 +280,13 @@ def _worker_mirrored(port, loss, q, transport, replay, world_emulated, Bl):
         from disvae_amd import parallel
         torch.cuda.set_device(0)
         parallel.init_process_group_from_env("nccl")
-        W, D, lr = world_emulated, 10, 5e-4
+        W, lr = world_emulated, 5e-4
         gen = torch.Generator().manual_seed(11)
         shard = torch.rand((Bl,) + IMG, generator=gen)
         eps = torch.randn(Bl, D, generator=gen)
-        m0, o0, l0 = _make(loss, lr)             # single process, eager, on the tiled global batch
+        m0, o0, l0 = _make(loss, lr, D)          # single process, eager, on the tiled global batch
         l0.replay = None
-        m1, o1, l1 = _make(loss, lr)             # the mirrored shard
+        m1, o1, l1 = _make(loss, lr, D)          # the mirrored shard
         l1.replay = replay
         if loss == "btcvae":
             l0.is_mss = l1.is_mss = False
@@ -299,9 +299,9 @@ def _worker_mirrored(port, loss, q, transport, replay, world_emulated, Bl):
             # FactorVAE's global permutation is not symmetric in the ranks: no tiled single-process twin.  The sharded
             # two-optimizer step (z2 all-gather, discriminator arena all-reduced under the VAE backward, late epilogue) must
             # run, replay and stay finite and deterministic: two mirrored models fed the same noise agree bit for bit
-            m2, o2, l2 = _make(loss, 1e-4)
+            m2, o2, l2 = _make(loss, 1e-4, D)
             l2.replay = None
-            m1, o1, l1 = _make(loss, 1e-4)
+            m1, o1, l1 = _make(loss, 1e-4, D)
             l1.replay = replay
             comm2 = parallel.data_parallel(m2, l2, comm=parallel.MirroredWorldComm(inner, W, 0))
             comm = parallel.data_parallel(m1, l1, comm=parallel.MirroredWorldComm(inner, W, 0))
@@ -356,6 +356,20 @@ def test_mirrored_world_runs_the_sharded_path_on_one_gpu(loss, world_emulated, B
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p_ = ctx.Process(target=_worker_mirrored, args=(_free_port(), loss, q, transport, replay, world_emulated, Bl))
+    p_.start()
+    rank, msg = q.get(timeout=280)
+    p_.join(timeout=60)
+    assert msg == "ok", msg
+
+
+@pytest.mark.parametrize("loss,world_emulated,Bl", [("btcvae", 4, 12), ("factor", 2, 8)])
+def test_mirrored_world_above_16_latents(loss, world_emulated, Bl):
+    """The sharded step with latent_dim 20 (run-time-D estimator over the global batch, wide packed sums -- 32 + D floats -- behind
+    the column gradients in the ONE all-reduce, FC layers one launch each): C-ABI RCCL transport, replayed from the recorded plan,
+    against the single-process step on the tiled batch (btcvae) / a second mirrored model bit for bit (factor)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p_ = ctx.Process(target=_worker_mirrored, args=(_free_port(), loss, q, "rccl", "plan", world_emulated, Bl, 20))
     p_.start()
     rank, msg = q.get(timeout=280)
     p_.join(timeout=60)
