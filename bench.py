@@ -1,7 +1,8 @@
 """Benchmark of the hot path: Trainer._train_iteration-equivalent steps (forward + loss +
 backward + Adam [+ RCCL collectives]) of the native HIP engine on synthetic batches resident in HBM.
 
-    python bench.py [--config NAME] --gpus N --steps K --warmup W           (N = 1)
+    python bench.py [--config NAME] --gpus N --steps K --warmup W           (N > 1 without a launcher: the script starts
+                                                                             its N ranks itself, self_launch below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workloads = BASELINE.json configs[1..4] (hyper-parameters: /root/reference/hyperparam.ini:6,76-81,123-137,
@@ -97,22 +98,44 @@ def pmc_file_order(f):
     return [int(m.group(1)), 1 if m.group(2) == "final" else 0, int(m.group(3) or 0)]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the kernel row `kernel` (the exact template variant, e.g. "k_up32ws<16, 2, false>") at B = 1024
-    (64x64x3) from the newest committed rocprofv3 PMC summary under profiles/ that has that row (tools/pmc_collect.sh ->
+def pmc_images_per_launch(path, text=None):
+    """Images per launch of the run a PMC summary was collected on: its "images_per_launch: N" header line (written by
+    tools/pmc_summary.py since round 6).  Older files carry none: they were collected on the default workload (1024 images
+    per launch) -- except the FactorVAE passes ("factor" in the name), whose per-kernel means mix 1024- and 2048-image
+    launches and are therefore not used for traffic (None)."""
+    text = open(path).read() if text is None else text
+    m = re.search(r"images_per_launch:\s*(\d+)", text)
+    if m:
+        return int(m.group(1))
+    return None if "factor" in os.path.basename(path) else 1024
+
+
+def pmc_traffic(kernel, images):
+    """HBM bytes per launch of the kernel row `kernel` (the exact template variant, e.g. "k_up32ws<16, 2, false>") at `images`
+    images per launch, from the committed rocprofv3 PMC summaries under profiles/ (tools/pmc_collect.sh ->
     tools/pmc_summary.py: separate --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled as MI355X_MICROARCH.md
-    section HBM prescribes for 16-byte coalesced streaming reads on gfx950).  Read from a file committed by an earlier GPU
-    visit, not measured in this run.  Returns (bytes, file) or (None, None)."""
+    section HBM prescribes for 16-byte coalesced streaming reads on gfx950): the newest summary collected AT that size if
+    one lists the row, else the newest one that lists it, scaled by images / its images-per-launch (every kernel here is
+    a persistent loop over per-image units).  Read from a file committed by an earlier GPU visit, not measured in this run.
+    Returns (bytes, file, images per launch of the file) or (None, None, None)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.md")), key=pmc_file_order)
+    best = None
     for f in reversed(files):
-        for l in open(f).read().splitlines():
+        text = open(f).read()
+        ipl = pmc_images_per_launch(f, text)
+        if ipl is None:
+            continue
+        for l in text.splitlines():
             cells = [c.strip() for c in l.strip("|").split("|")]
             if l.startswith("|") and cells and cells[0] == kernel:
                 try:
-                    return (float(cells[-3]) + float(cells[-2])) * 1e6, os.path.relpath(f, ROOT)
+                    hit = ((float(cells[-3]) + float(cells[-2])) * 1e6 * images / ipl, os.path.relpath(f, ROOT), ipl)
                 except ValueError:
-                    pass
-    return None, None
+                    continue
+                if ipl == images:
+                    return hit
+                best = best or hit
+    return best or (None, None, None)
 
 
 def _time_launch(fn, n=20, warm=3):
@@ -174,9 +197,10 @@ def kernel_rooflines(B, device):
     for name, launches in fams.items():
         rows = []
         for what, krow, bpi, fn in launches:
-            traffic, src = pmc_traffic(krow)
+            traffic, src, ipl = pmc_traffic(krow, B)
             rows.append({"launch": what, "kernel": krow, "us": round(_time_launch(fn) * 1e3, 2), "algorithmic_bytes": bpi * B,
-                         "traffic": round(traffic * B / 1024) if traffic is not None else None, "traffic_source": src})
+                         "traffic": round(traffic) if traffic is not None else None, "traffic_source": src,
+                         "traffic_measured_at_images": ipl})
         tot = sum(r["us"] for r in rows) * 1e-3
         achieved = flops * len(rows) / (tot * 1e-3) / 1e12
         tr = [r["traffic"] for r in rows]
@@ -308,12 +332,12 @@ def thin_kernel_rooflines(B, C, device):
     for kern, what, nbytes, fn in launches:
         ms = _time_launch(fn)
         gbs = nbytes / (ms * 1e-3) / 1e9
-        traffic, src = pmc_traffic(kern)
+        traffic, src, ipl = pmc_traffic(kern, B)
         out.append({"bound": "hbm", "kernel": kern, "launch": what, "us_per_launch": round(ms * 1e3, 2),
                     "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                     "images_per_launch": B, "algorithmic_bytes": nbytes,
-                    "traffic": round(traffic * B / 1024) if traffic is not None and C == 3 else None,
-                    "traffic_source": src if C == 3 else None})
+                    "traffic": round(traffic) if traffic is not None else None, "traffic_source": src,
+                    "traffic_measured_at_images": ipl})
     return out
 
 
@@ -638,37 +662,47 @@ def host_issue_ms(step_fn, n=30):
     return sorted(ts)[len(ts) // 2] * 1e3
 
 
-def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single", "rccl", "torch")):
-    """BASELINE configs[3] as ONE of its eight ranks runs it, on this one GPU: 128 images per step through the SHARDED code
-    path of the btcvae step (disvae_amd.parallel: packed latent all-gather, the rank's 128 rows of the 1024-column B x B
-    estimator, packed column-gradient reduce-scatter, loss-sum all-reduce, the gradient arena all-reduced in two spans under
-    the backward pass).  The seven absent peers are stood in for by parallel.MirroredWorldComm (identical shards: every
-    collective goes through a real one-rank RCCL communicator -- torch.distributed's, then the C-ABI's dvae_comm_* -- and is
-    completed by replication / scaling), so the leg times the rank's own kernels, launches and RCCL call sites; what it
-    cannot contain is the xGMI transfer time of the 2 MB + 120 KB + 80 KB a real step exchanges.  Beside them: the same
-    128 images as a single-process step (no communicator)."""
+def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single", "rccl", "torch"), name="btcvae_celeba"):
+    """BASELINE configs[3] (name = "btcvae_celeba") or configs[4] ("factor_celeba") as ONE of its eight ranks runs it, on this
+    one GPU, through the SHARDED code path of the step (disvae_amd.parallel):
+      btcvae: 128 images -- packed latent all-gather, the rank's 128 rows of the 1024-column B x B estimator, column gradients
+              + loss sums in one all-reduce, the gradient arena all-reduced under the backward pass;
+      factor: tensor 256 = 128 + 128 -- all-gather of the second half's latents (permute_dims over the GLOBAL 1024-row half
+              batch, shared-seed permutations), the 16 MB discriminator gradient arena all-reduced on the communication stream
+              under the whole VAE backward pass, the 2 MB VAE arena behind it, two optimizers (losses.py:281-308).
+    The seven absent peers are stood in for by parallel.MirroredWorldComm (identical shards: every collective goes through a
+    real one-rank RCCL communicator -- torch.distributed's, then the C-ABI's dvae_comm_* -- and is completed by replication /
+    scaling), so the leg times the rank's own kernels, launches and RCCL call sites; what it cannot contain is the xGMI
+    transfer time of the bytes a real step exchanges (btcvae 2 MB + 120 KB + 80 KB; factor 16 MB + 2 MB + 40 KB).  Beside
+    them: the same tensor as a single-process step (no communicator)."""
     import logging
     import torch.distributed as dist
     from disvae_amd.models.vae import init_specific_model
     from disvae_amd.models.losses import get_loss_f
     from disvae_amd.training import Trainer
     from disvae_amd import parallel
-    cfg = dict(CONFIGS["btcvae_celeba"])
+    cfg = dict(CONFIGS[name])
+    loss_name = cfg["loss"]
     Bg = cfg["batch"]
     B = Bg // SHARD_WORLD
     C = cfg["img"][0]
-    flops = flops_per_image_train(C) * B
-    out = {"name": "btcvae_celeba_shard", "baseline_config": 3, "loss": "btcvae", "img": list(cfg["img"]), "global_batch": Bg,
-           "batch_per_gpu": B, "world_emulated": SHARD_WORLD, "steps": steps, "warmup": warmup, "unit": "images/s",
-           "what": "one rank of eight: the sharded btcvae step at 128 images per GPU (global 1024-column estimator, packed "
-                   "collectives through a one-rank RCCL communicator completed by MirroredWorldComm); value = images/s of "
-                   "THIS rank, xGMI transfer time not included"}
+    flops = (flops_per_image_factor(C) if loss_name == "factor" else flops_per_image_train(C)) * B
+    out = {"name": name + "_shard", "baseline_config": cfg["baseline_config"], "loss": loss_name, "img": list(cfg["img"]),
+           "global_batch": Bg, "batch_per_gpu": B, "world_emulated": SHARD_WORLD, "steps": steps, "warmup": warmup,
+           "unit": "images/s",
+           "what": ("one rank of eight: the sharded btcvae step at 128 images per GPU (global 1024-column estimator, packed "
+                    "collectives through a one-rank RCCL communicator completed by MirroredWorldComm); value = images/s of "
+                    "THIS rank, xGMI transfer time not included") if loss_name != "factor" else
+                   ("one rank of eight: the sharded FactorVAE step at tensor 256 = 128 + 128 per GPU (permute_dims over the "
+                    "global half batch, the 16 MB discriminator gradient all-reduce in flight under the VAE backward pass, two "
+                    "optimizers; collectives through a one-rank RCCL communicator completed by MirroredWorldComm); value = "
+                    "images/s of THIS rank, xGMI transfer time not included")}
 
     def leg(transport):
         torch.manual_seed(1234)
         model = init_specific_model("Burgess", cfg["img"], 10).to(device)
         opt = make_optimizer(model, cfg["lr"])
-        loss_f = get_loss_f("btcvae", n_data=cfg["n_data"], device=device, lr_disc=cfg["lr_disc"], **HP)
+        loss_f = get_loss_f(loss_name, n_data=cfg["n_data"], device=device, lr_disc=cfg["lr_disc"], **HP)
         trainer = Trainer(model, opt, loss_f, device=device, logger=logging.getLogger("bench"), save_dir="/tmp/dvae_bench_shard",
                           is_progress_bar=False)
         model.train()
@@ -699,10 +733,10 @@ def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single
                 "replay": loss_f._replay_mode(True, data) or "eager", "host_issue_ms_per_step": round(host, 4),
                 "settle_ms_per_step": [round(x, 4) for x in rounds]}
 
-    mark("configs:shard:single")
+    mark("configs:%s_shard:single" % name)
     if "single" in which:
         out["single_process"] = leg(None)
-    mark("configs:shard:ddp")
+    mark("configs:%s_shard:ddp" % name)
     own_group = False
     try:
         if not dist.is_initialized():
@@ -729,19 +763,55 @@ def shard_legs(device, steps, warmup, with_parity, with_roofline, which=("single
                 dist.destroy_process_group()
             except Exception:
                 pass
-    mark("configs:shard:parity")
+    mark("configs:%s_shard:parity" % name)
     if with_parity:
         # the kernels of the shard's size (batch-sized variants: the thin convolutions, the FC chain, replayed launch plan)
-        # against the oracle: the first iteration of a single-process 128-image step
+        # against the oracle: the first iteration of a single-process step on the shard's tensor
         pc = parity_check(dict(cfg, batch=B), B, device)
         out["parity_check"] = {k: pc[k] for k in ("ok", "loss_rel_err", "worst_grad_err_over_max_abs_grad_vs_gate_matched_fp64",
                                                   "units_gated_differently_than_fp64", "batch", "seconds")}
         out["parity_check"]["sharded_path"] = ("tests/test_gpu_ddp.py: sharded == global-batch step (2 ranks), mirrored world == "
                                                "tiled single-process step at these sizes")
-    mark("configs:shard:rooflines")
+    mark("configs:%s_shard:rooflines" % name)
     if with_roofline:
-        out["roofline_kernels"] = kernel_rooflines(B, device) + thin_kernel_rooflines(B, C, device)
+        nimg = B // 2 if loss_name == "factor" else B        # FactorVAE: the decoder and the backward pass see the first half
+        out["roofline_kernels"] = kernel_rooflines(nimg, device) + thin_kernel_rooflines(nimg, C, device)
+        if loss_name == "factor":
+            out["roofline_kernels"] += disc_kernel_rooflines(B, device)
     return out
+
+
+# ---------------------------------------------------------------------------------- N ranks from one command
+def self_launch_cmd(argv, n, port):
+    """`python bench.py --gpus N ...` typed without a launcher: the command that runs the same arguments as N ranks of
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, n):
+    """Re-execute under torch.distributed.run and pass the job's output through: rank 0's JSON line stays the LAST line
+    of stdout (the launcher's own chatter goes to stderr).  Returns the job's exit code."""
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("--gpus %d but this node shows %d GPU(s)" % (n, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = self_launch_cmd(argv, n, _free_port())
+    print("[bench] --gpus %d without a launcher: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    last = None
+    for line in proc.stdout:
+        if last is not None:
+            sys.stdout.write(last)
+        last = line
+    rc = proc.wait()
+    if last is not None:
+        sys.stdout.write(last)
+    sys.stdout.flush()
+    return rc
 
 
 # ---------------------------------------------------------------------------------- main
@@ -790,8 +860,8 @@ def main():
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop-in leg (Adam(model.parameters()) + a host "
                     "sync per iteration)")
     ap.add_argument("--shard-which", default="single,torch,rccl", help="subset of the shard legs (profiling)")
-    ap.add_argument("--shard-legs", action="store_true", help="only the btcvae_celeba_shard legs (one rank of eight at 128 "
-                    "images per GPU: single process, torch transport, rccl transport), print them, exit")
+    ap.add_argument("--shard-legs", action="store_true", help="only the shard legs of --config (btcvae_celeba, default, or "
+                    "factor_celeba: one rank of eight -- single process, torch transport, rccl transport), print them, exit")
     ap.add_argument("--cpu-reference", action="store_true", help="no GPU needed: time the unmodified reference Trainer "
                     "(where /root/reference exists) and the oracle's port of it on this host, print both, exit")
     args = ap.parse_args()
@@ -812,8 +882,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))       # `python bench.py --gpus N`: start the N ranks ourselves
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus > 1" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=1" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -821,7 +893,8 @@ def main():
 
     if args.shard_legs:
         res = shard_legs(device, steps=args.steps, warmup=args.warmup, with_parity=not args.no_parity_check,
-                         with_roofline=not args.no_roofline, which=tuple(args.shard_which.split(",")))
+                         with_roofline=not args.no_roofline, which=tuple(args.shard_which.split(",")),
+                         name=args.config or "btcvae_celeba")
         try:                                     # RCCL's banner goes through C stdio: out before the result line
             ctypes.CDLL(None).fflush(None)
         except Exception:
@@ -1014,8 +1087,10 @@ def main():
         out["configs"] = [extra_config(n, device, steps=min(args.steps, 30), warmup=min(args.warmup, 10),
                                        with_cpu=not args.no_cpu_baseline, with_parity=not args.no_parity_check)
                           for n in ("vae_mnist", "btcvae_dsprites", "factor_dsprites", "factor_celeba")]
-        out["configs"].append(shard_legs(device, steps=max(min(args.steps, 100), 30), warmup=min(args.warmup, 10),
-                                         with_parity=not args.no_parity_check, with_roofline=not args.no_roofline))
+        for shard_of in ("btcvae_celeba", "factor_celeba"):
+            out["configs"].append(shard_legs(device, steps=max(min(args.steps, 100), 30), warmup=min(args.warmup, 10),
+                                             with_parity=not args.no_parity_check, with_roofline=not args.no_roofline,
+                                             name=shard_of))
     mark("end")
     out["timing_s"] = {a[0]: round(b[1] - a[1], 1) for a, b in zip(_MARKS[:-1], _MARKS[1:])}
     out["bench_wall_s"] = round(time.time() - t_main, 1)     # this process, main() entry to the line below (imports excluded)

@@ -16,7 +16,8 @@
 
 namespace dvae {
 
-#define ADAM_MAX_T 80             // tensors per launch (kernel-argument block: 80 x 48 B + prefix table < 4 KB)
+#define ADAM_MAX_T 64             // tensors per launch: the by-value table is 64 x 48 B + 65 x 4 B + 4 B = 3336 B (+ 32 B of scalars),
+                                  // inside the classic 4 KB kernel-argument block (asserted below)
 #define ADAM_CHUNK 4096           // elements per workgroup
 
 struct AdamTable {
@@ -25,9 +26,11 @@ struct AdamTable {
   int nt;
 };
 
+static_assert(sizeof(AdamTable) + 64 <= 4096, "k_adam's by-value table must fit a 4 KB kernel-argument block");
+
 __global__ __launch_bounds__(256) void k_adam(const AdamTable T, float step_new, float lr_over_bc1, float rsqrt_bc2_inv,
                                               float b1c, float b2, float b2c, float eps, float wd) {
-  // which tensor: wave-uniform search over <= 80 entries
+  // which tensor: wave-uniform search over <= ADAM_MAX_T entries
   int ti = 0;
   const int b = blockIdx.x;
   while (ti + 1 < T.nt && T.blk0[ti + 1] <= b) ++ti;

@@ -263,7 +263,8 @@ int dvae_sigmoid_bwd(const float* grad_y, const float* y, float* out, long n, vo
 
 int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg, int D, int row0, int Bl, int is_mss,
                     const float* log_w, float* tmp, float* rowstats, void* stream) {
-  DVAE_CHECK_ARG(z && mu && logvar && tmp && rowstats && Bg > 1 && D >= 1 && D <= 65535 && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg);
+  DVAE_CHECK_ARG(z && mu && logvar && tmp && rowstats && Bg > 1 && D >= 1 && row0 >= 0 && Bl > 0 && row0 + Bl <= Bg);
+  DVAE_CHECK_ARG(D <= DVAE_WIDE_MAX_D /* one row of D log-sum-exps in LDS (latent_wide.hip: k_tcw_rowstats) */);
   DVAE_CHECK_ARG(!is_mss || log_w);
   return launch_btcvae_fwd(z, mu, logvar, Bg, D, row0, Bl, is_mss, log_w, tmp, rowstats, (hipStream_t)stream);
 }
@@ -271,7 +272,8 @@ int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg
 int dvae_btcvae_bwd(const float* z, const float* mu, const float* logvar, const float* rowstats, int Bg, int D,
                     int row0, int Bl, int is_mss, const float* log_w, const float* coef, const float* tmp, float* dz,
                     float* dmu_all, float* dlv_all, void* stream) {
-  DVAE_CHECK_ARG(z && mu && logvar && rowstats && coef && tmp && dz && dmu_all && dlv_all && Bg > 1 && D >= 1 && D <= 65535);
+  DVAE_CHECK_ARG(z && mu && logvar && rowstats && coef && tmp && dz && dmu_all && dlv_all && Bg > 1 && D >= 1);
+  DVAE_CHECK_ARG(D <= DVAE_WIDE_MAX_D /* one row of D log-sum-exps in LDS (latent_wide.hip) */);
   DVAE_CHECK_ARG(row0 >= 0 && Bl > 0 && row0 + Bl <= Bg && (!is_mss || log_w));
   return launch_btcvae_bwd(z, mu, logvar, rowstats, Bg, D, row0, Bl, is_mss, log_w, coef, tmp, dz, dmu_all, dlv_all,
                            (hipStream_t)stream);

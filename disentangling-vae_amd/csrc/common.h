@@ -99,25 +99,53 @@ __device__ __forceinline__ float recon_elem(float p, float x, int dist, float* g
   return term;
 }
 
-// sigmoid + Bernoulli likelihood term + dL/dlogit from the LOGIT v (losses.py:430: F.binary_cross_entropy(sigmoid(v), x)).
-// With e = exp(-|v|), s = 1 + e:  p = (v >= 0 ? 1 : e) / s  and  -[x log p + (1 - x) log(1 - p)] = log(s) + max(v, 0) - x v
-// (both logarithms of ATen's form share log(s)); ATen's clamp of each logarithm at -100 = v clamped to [-100, 100] in the
-// last two terms.  Three transcendentals per output (exp, rcp, log) instead of four and a third of recon_elem's vector
-// instructions: the likelihood was 28 of the 86 us of convT3's fused forward at 1024 images (profiles/r05_v17).
-// *gl = dL/dlogit as recon_elem's: (p - x), scaled down where (1 - p) p < 1e-12 (ATen's backward clamp).
+// torch.sigmoid as ATen's fp32 kernel computes it (1 / (1 + exp(-v)): IEEE add, IEEE division) on the hardware
+// transcendentals.  With e = exp(-|v|), s = fl(1 + e), r = v_rcp_f32(s) (1 ulp):
+//   v >= 0:  1 / s = 1 - q / s with q = s - 1 (exact: the ROUNDED e, which is all ATen's sum keeps of it); one FMA rounds
+//            1 - q r onto p's grid (spacing 2^-24 below 1): the correctly rounded quotient except for near-ties.  That is the
+//            point: F.binary_cross_entropy takes log(1 - p) of THIS p, so from v ~ 8 upwards the reference's likelihood term
+//            is -log(k 2^-24) for an integer k, and p == 1 (term clamped to 100) from v ~ 16.64 -- losses.py:430;
+//   v <  0:  e / s (no cancellation on that side);
+//   v < DVAE_SIGMOID_ZERO_BELOW:  ATen's exp(-v) overflows fp32, so its p is exactly 0.
+#define DVAE_SIGMOID_ZERO_BELOW (-88.72283935546875f)
+__device__ __forceinline__ float sigmoid_aten(float v) {
+  const float e = __expf(-fabsf(v));
+  const float s = 1.f + e;
+  const float r = __builtin_amdgcn_rcpf(s);
+  float p = v >= 0.f ? fmaf(1.f - s, r, 1.f) : e * r;
+  if (v < -87.f)   // v_exp_f32 flushes results below 2^-126: ATen's p is a denormal down to its overflow point, then 0
+    p = v < DVAE_SIGMOID_ZERO_BELOW ? 0.f : ldexpf(__expf(v + 17.328679513998633f), -25);
+  return p;
+}
+
+// sigmoid + Bernoulli likelihood term + dL/dlogit from the LOGIT v, equal to what the reference computes in fp32
+// (losses.py:430: F.binary_cross_entropy(sigmoid(v), x) = (x - 1) max(log(1 - p), -100) - x max(log p, -100) on the fp32 p).
+// With e, s, r, p as in sigmoid_aten and ls = log(1 + e) (= log(s) + (e - q) / s, accurate also where s rounds to 1):
+//   v >= 0:  -log(1 - p) is taken from ATen's p itself (1 - p is exact; 0 -> +inf -> the clamp's 100) -- NOT v + ls, which
+//            is what it would be in exact arithmetic and differs from the reference by up to 4 % per element from v ~ 8 on
+//            and by (100 - v) (1 - x) once p rounds to 1 (round 5's form);  -log p = ls;
+//   v <  0:  -log(1 - p) = ls, -log p = ls - v (no cancellation in the reference either), 100 where ATen's p is 0.
+// Four transcendentals per output (exp, rcp, 2 x log).  *gl = dL/dlogit: (p - x), scaled down where (1 - p) p < 1e-12
+// (ATen's backward clamp, as recon_elem's).
 __device__ __forceinline__ float sigmoid_bce_logit(float v, float x, float* p_out, float* gl) {
   const float e = __expf(-fabsf(v));
   const float s = 1.f + e;
   const float r = __builtin_amdgcn_rcpf(s);
-  const float p = v >= 0.f ? r : e * r;
-  const float vc = fminf(fmaxf(v, -100.f), 100.f);
-  // log(s), s in [1, 2]: v_log_f32 (log2, ~1 ulp) x ln 2 -- __logf() expands to a denormal-safe, extended-precision sequence of
-  // 12 instructions here
-  const float term = __builtin_amdgcn_logf(s) * 0.69314718056f + fmaxf(vc, 0.f) - x * vc;
-  const float qq = (1.f - p) * p, d = p - x;
+  const float q = s - 1.f;
+  const bool pos = v >= 0.f, zero = v < DVAE_SIGMOID_ZERO_BELOW;
+  float p = pos ? fmaf(-q, r, 1.f) : e * r;
+  if (__builtin_expect(v < -87.f, 0))                      // as sigmoid_aten: a denormal down to ATen's overflow point, then 0
+    p = zero ? 0.f : ldexpf(__expf(v + 17.328679513998633f), -25);
+  // v_log_f32 (log2, ~1 ulp) x ln 2 -- __logf() expands to a denormal-safe, extended-precision sequence of 12 instructions
+  const float ls = fmaf(__builtin_amdgcn_logf(s), 0.69314718056f, (e - q) * r);
+  const float om = 1.f - p;
+  const float l1 = fminf(__builtin_amdgcn_logf(om) * -0.69314718056f, 100.f);
+  const float t0 = pos ? l1 : ls;                          // the term at x = 0
+  const float dx = pos ? ls - l1 : (zero ? 100.f : -v);    // + x times this
+  const float qq = om * p, d = p - x;
   *gl = qq >= 1e-12f ? d : d * 1e12f * qq;
   *p_out = p;
-  return term;
+  return fmaf(x, dx, t0);
 }
 
 // ---- launchers implemented in the individual .hip files ---------------------------------

@@ -9,7 +9,7 @@ namespace dvae {
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == DVAE_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == DVAE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  if (act == DVAE_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
   if (act == DVAE_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
   return v;
 }

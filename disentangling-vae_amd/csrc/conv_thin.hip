@@ -365,9 +365,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // loads off the critical path a wave is paced by its scalar weight loads alone (8.2 us per unit for ONE resident workgroup
 // per CU with tile loads, LDS reads, sigmoid and stores all removed), and twice as many barrier-delimited phases per unit
 // leave the three waves of a SIMD fewer chances to cover each other's stalls.
-// torch.sigmoid on the hardware transcendentals: v_exp_f32 (x log2 e) and v_rcp_f32, <= 2-3 ulp from the correctly rounded
-// 1 / (1 + exp(-v)) (the IEEE division and range-reduced expf of the synchronous kernel cost 15 us of 93 at B = 1024)
-__device__ __forceinline__ float sigmoid_hw(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+// torch.sigmoid on the hardware transcendentals: common.h's sigmoid_aten (v_exp_f32, v_rcp_f32 + one FMA that lands on ATen's
+// rounding of p where the Bernoulli term depends on it; the IEEE division and range-reduced expf of the synchronous kernel
+// cost 15 us of 93 at B = 1024)
+__device__ __forceinline__ float sigmoid_hw(float v) { return sigmoid_aten(v); }
 
 template <int C, bool FUSE, typename TT = float>
 __global__ __launch_bounds__(128) void k_up_thin_pk(const float* __restrict__ small, const float* __restrict__ wrec,

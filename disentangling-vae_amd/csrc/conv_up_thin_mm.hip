@@ -36,7 +36,7 @@ namespace dvae {
 #define UTM_OR 22                   // output rows per unit (before clipping to the image)
 #define UTM_STAGE (3 * UTM_OR * 64)
 
-__device__ __forceinline__ float sigmoid_hw_mm(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float sigmoid_hw_mm(float v) { return sigmoid_aten(v); }
 
 // DIST: the reconstruction distribution (FUSE) as a compile-time constant -- with a run-time code the compiler evaluates all
 // three likelihoods per output and selects (measured: 1360 vector instructions per unit and wave instead of ~500).

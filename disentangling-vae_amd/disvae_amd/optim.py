@@ -90,15 +90,16 @@ class _NativeAdam:
         """Cheap per-step check that the tables still describe the optimizer: same parameters, gradients and state tensors
         (load_state_dict, add_param_group, zero_grad(set_to_none=True), a moved model all change one of these)."""
         sig = []
+        state = opt.state
         for g in opt.param_groups:
-            ps = g["params"]
-            first, last = ps[0], ps[-1]
-            for p in (first, last):
-                st = opt.state.get(p)
-                if p.grad is None or not st:
+            for p in g["params"]:           # EVERY parameter: a middle one whose .grad was dropped or replaced, or whose state entry
+                st = state.get(p)           # was swapped, would otherwise leave a stale device pointer in the table (28 tensors)
+                gr = p.grad
+                if gr is None or not st:
                     return None
-                sig.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["step"].data_ptr()))
-            sig.append(len(ps))
+                sig.append((p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                            st["step"].data_ptr()))
+            sig.append(len(g["params"]))
         return tuple(sig)
 
     def _build(self, opt):
@@ -146,8 +147,8 @@ class _NativeAdam:
             self._sig = self._signature(opt)
         stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
         for ent, g in zip(self.groups, opt.param_groups):
-            ent[3] += 1
             b1, b2 = g["betas"]
-            call("dvae_adam_step", ent[1], ent[2], float(ent[3]), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+            call("dvae_adam_step", ent[1], ent[2], float(ent[3] + 1), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
                  float(g["weight_decay"]), stream)
+            ent[3] += 1            # only once the launch is enqueued: a refused call leaves host and device counts equal
         return True

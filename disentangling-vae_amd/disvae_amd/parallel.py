@@ -214,20 +214,29 @@ class RcclComm(Comm):
     """Same interface, data path through the C-ABI (``dvae_comm_*`` of libdvae_hip.so): RCCL collectives enqueued on the
     current HIP stream.  The torch.distributed group is used once, to broadcast rank 0's RCCL unique id."""
 
-    def __init__(self, group=None):
-        super().__init__(group)
-        h = _lib.lib()
+    @staticmethod
+    def prepare(rank):
+        """The part of the set-up that involves NO other rank: load RCCL into libdvae_hip.so and, on rank 0, draw the unique
+        id.  Everything that can fail for local reasons (a missing library, a missing symbol) fails here, BEFORE the first
+        collective a peer could be left waiting in (_auto_comm agrees on the outcome across ranks in between)."""
+        _lib.lib()
         path = os.environ.get("DVAE_RCCL_LIB")
         if path is None:                      # prefer the RCCL torch itself is linked with (one RCCL per process)
             cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
             path = cand if os.path.exists(cand) else None
         call("dvae_comm_load", path.encode() if path else None)
-        dev = torch.device("cuda", torch.cuda.current_device())
         uid = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
+        if rank == 0:
             buf = (ctypes.c_char * 128)()
             call("dvae_comm_unique_id", ctypes.addressof(buf))
             uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        return uid
+
+    def __init__(self, group=None, prepared=None):
+        super().__init__(group)
+        h = _lib.lib()
+        uid = prepared if prepared is not None else self.prepare(self.rank)
+        dev = torch.device("cuda", torch.cuda.current_device())
         if self.world_size > 1:
             backend = dist.get_backend(group)
             t = uid.to(dev) if backend == "nccl" else uid
@@ -390,15 +399,30 @@ def _auto_comm(group):
     """RcclComm where it demonstrably works on every rank, else Comm (see data_parallel)."""
     if not torch.cuda.is_available() or dist.get_backend(group) != "nccl":
         return Comm(group)
-    comm, err = None, None
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def all_ranks_ok(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) == 1
+
+    comm, err, uid = None, None, None
+    # stage 1, local: RCCL loaded into the C-ABI (+ rank 0's unique id).  The ranks agree on it BEFORE the unique-id broadcast:
+    # a rank that failed here never enters that broadcast, and its peers must not be left blocked in it
     try:
-        comm = RcclComm(group)
-        comm.self_test()
-    except Exception as e:       # noqa: a missing librccl symbol, a failed ncclCommInitRank, a wrong sum
+        uid = RcclComm.prepare(dist.get_rank(group))
+    except Exception as e:       # noqa: a missing librccl, a missing symbol
         err = e
-    flag = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 1:
+    ok = all_ranks_ok(err is None)
+    if ok:
+        # stage 2, collective on every rank: unique-id broadcast, ncclCommInitRank, one all-reduce round trip
+        try:
+            comm = RcclComm(group, prepared=uid)
+            comm.self_test()
+        except Exception as e:   # noqa: a failed ncclCommInitRank, a wrong sum
+            err = e
+        ok = all_ranks_ok(err is None)
+    if ok:
         return comm
     import warnings
     warnings.warn("disvae_amd.parallel: the C-ABI RCCL transport failed its round trip on at least one rank (%s): every rank "

@@ -29,11 +29,14 @@ extern "C" {
 
 /* Latent dimensions.  The reference's --latent-dim is any integer (main.py:81); every experiment of hyperparam.ini uses 10.
  * The FUSED kernels (the FC chain, the register-resident beta-TCVAE estimator, the 16-wide KL / scalar records) cover
- * 1 <= D <= DVAE_MAX_D, D = 10 fully unrolled.  Above that the same entry points take any D and run run-time-D kernels
+ * 1 <= D <= DVAE_MAX_D, D = 10 fully unrolled.  Above that the same entry points take any D (the estimator: up to
+ * DVAE_WIDE_MAX_D) and run run-time-D kernels
  * (csrc/latent_wide.hip; the FC layers go one launch each through dvae_linear_*): only dvae_fc_chain_* and the partial-block
  * form of the KL (dvae_reparam_kl_fwd without coef, dvae_kl_finish, kl_blocks > 0) stay limited to DVAE_MAX_D.  Buffers whose
  * size depends on D beyond that point are sized by the macros below ("wide" layouts):                              */
 #define DVAE_MAX_D 16
+#define DVAE_WIDE_MAX_D 12288   /* the run-time-D estimator keeps one row of D log-sum-exps in LDS: 48 KB of the 64 KB a launch
+                                 * gets without an opt-in; dvae_btcvae_fwd / _bwd refuse more with a message */
 #define DVAE_BTCVAE_MAX_D DVAE_MAX_D   /* (kept for callers of version <= 107: the estimator's fused kernels) */
 #define DVAE_ROWSTATS 32        /* floats per row of the estimator's row statistics: 4 + D used */
 /* row stride of `rowstats` */
@@ -313,7 +316,7 @@ int dvae_convT4s2_sigmoid_recon_fwd(const float* x, int x_layout, const float* w
  * z,mu,logvar: [Bg,D] (the whole -- global -- batch); this call evaluates rows
  * [row0,row0+Bl).  log_w = {log(1/N), log(strat), log(1/M)} in fp32 as the reference
  * computes them (math.py:66-73), ignored when is_mss == 0.
- * rowstats[Bl,DVAE_ROWSTATS_STRIDE(D)]: log_pz, log_qz, log_prod_qzi, log_q_zCx, lse_d[0..D-1]  (any D >= 1).
+ * rowstats[Bl,DVAE_ROWSTATS_STRIDE(D)]: log_pz, log_qz, log_prod_qzi, log_q_zCx, lse_d[0..D-1]  (1 <= D <= DVAE_WIDE_MAX_D).
  * tmp[DVAE_BTCVAE_TMP_FLOATS(Bg,Bl,D)]: scratch filled by fwd with the transposed per-column constants (mu, -0.5(log
  * 2pi + logvar), exp(-logvar)) and re-read by bwd: pass the same buffer to both.             */
 int dvae_btcvae_fwd(const float* z, const float* mu, const float* logvar, int Bg, int D, int row0,

@@ -86,6 +86,19 @@ def kats(losses, dmath):
     r = torch.sigmoid(torch.sin(torch.arange(32).float())).view(2, 1, 4, 4)
     for d in ["bernoulli", "gaussian", "laplace"]:
         out["kat_rec_" + d] = losses._reconstruction_loss(x, r, distribution=d).numpy()
+    # saturated Bernoulli likelihood (losses.py:430): logits whose fp32 sigmoid rounds to 1 (v >= ~16.64) or is 0 (exp(-v)
+    # overflows, v < -88.72) -- F.binary_cross_entropy's -100 clamp decides those terms; three logits = one per channel of a
+    # [2, 3, 64, 64] reconstruction, targets (i % 5) / 4 (fp32) and 255-level uint8 pixels (i % 3) -> {0, 128, 255}
+    sat = torch.tensor([[16.6, 17., 20.], [-16.6, -17., -20.], [40., 88., 90.], [-40., -88., -90.], [104., -104., 0.5],
+                        [8.5, -12., 3.]])
+    ar = torch.arange(2 * 3 * 64 * 64)
+    xs = ((ar % 5).float() / 4).view(2, 3, 64, 64)
+    x8 = (torch.tensor([0, 128, 255], dtype=torch.uint8)[ar % 3]).view(2, 3, 64, 64)
+    out["kat_rec_sat_logits"] = sat.numpy()
+    for nm, tgt in (("", xs), ("_u8", x8.float() / 255.0)):
+        out["kat_rec_sat_loss" + nm] = np.stack([
+            losses._reconstruction_loss(tgt, torch.sigmoid(v.view(1, 3, 1, 1).expand(2, 3, 64, 64).contiguous()),
+                                        distribution="bernoulli").numpy() for v in sat])
     lf = losses.BtcvaeLoss(100, alpha=1, beta=6.4, gamma=1, steps_anneal=10000)
     st = defaultdict(list)
     loss = lf(x, r, (mu[:2], logvar[:2]), True, st, latent_sample=z[:2])
@@ -214,6 +227,11 @@ def main():
         return
     ref = import_reference()
     _, losses, vae, discriminator, dmath, training = ref
+    if "--kats" in sys.argv:             # only the RNG-free known-answer vectors
+        out = kats(losses, dmath)
+        np.savez_compressed(os.path.join(HERE, "kats.npz"), **out)
+        print("kats:", {k: np.asarray(v).tolist() for k, v in out.items() if k.startswith("kat_rec")})
+        return
     if "--bench-size" in sys.argv:    # step 0 of the two dsprites BASELINE workloads at their own batch (digests + noise only)
         for name, loss, img, b, steps, seed, n_data, lr in [
                 ("btcvae_dsprites_b256", "btcvae", (1, 64, 64), 256, 1, 1234, 737280, 5e-4),

@@ -7,6 +7,7 @@
     tensor's scale) and vs the per-layer entry points it replaces in the training step.
 Reference lines: encoders.py:73-87, vae.py:52-71, losses.py:452-480, decoders.py:71-80."""
 import ctypes
+import os
 import math
 
 import pytest
@@ -366,6 +367,148 @@ def test_convT3_forward_on_staged_pair_records(N, C):
             tot = 3 * (pr - t64).abs().sum(); gref = 3 * torch.sign(pr - t64) * pr * (1 - pr) / N
         check(p1.sum(), tot, rtol=1e-5, what="fused loss sum vs fp64 dist %d" % dist)
         check(g1, gref, rtol=1e-4, atol_rel=4e-6, what="fused dL/dlogit vs fp64 dist %d" % dist)
+
+
+# logits at and beyond the points where torch.sigmoid's fp32 result rounds to 1 (v >= ~16.64) or is exactly 0 (exp(-v)
+# overflows: v < -88.72), plus the stretch below where 1 - p keeps only a few bits
+_SAT = [16.6, 17.0, 20.0, 40.0, 88.0, 90.0, 104.0]
+_SAT_TRIPLES = ([(v, -v, v2) for v, v2 in zip(_SAT, _SAT[1:] + _SAT[:1])] + [(-v, v, -v2) for v, v2 in zip(_SAT, _SAT[2:] + _SAT[:2])]
+                + [(8.5, -12.0, 3.0), (15.9, 16.2, 16.5), (-87.0, -88.5, -89.0), (0.0, 12.7, -0.5)])
+
+
+def _sat_targets(N, C, kind):
+    """(fp32 target, uint8 target or None): exact 0 / 0.5 / 1 planes, a random plane, or uint8 pixels with 0 and 255 forced in."""
+    gen = torch.Generator().manual_seed(11)
+    if kind == "u8":
+        t8 = torch.randint(0, 256, (N, C, 64, 64), dtype=torch.uint8, generator=gen)
+        t8[:, :, ::3, ::2] = 0
+        t8[:, :, 1::3, 1::2] = 255
+        return t8.float() / 255.0, t8
+    t = torch.rand(N, C, 64, 64, generator=gen)
+    t[:, :, 0::4, :] = 0.0
+    t[:, :, 1::4, :] = 1.0
+    t[:, :, 2::4, 0::2] = 0.5
+    return t, None
+
+
+@pytest.mark.parametrize("kind", ["f32", "u8"])
+@pytest.mark.parametrize("C", [1, 3])
+@pytest.mark.parametrize("N", [2, 70])
+def test_convT3_bernoulli_likelihood_on_saturated_logits(N, C, kind):
+    """losses.py:430 through the fused last decoder layer (k_up_thin_mm for 3 channels, k_up_thin_pk for 1; fp32 and uint8
+    targets) and through the raw-weight entry point, at logits where the reference's fp32 arithmetic decides the value:
+    F.binary_cross_entropy clamps log(1 - p) at -100 once sigmoid(v) rounds to 1 (term 100 (1 - x), not v (1 - x)), log p once
+    exp(-v) overflows (term 100 x), and below that 1 - p has only a few bits.  Zero weights, bias = the logit, so every path
+    sees exactly the logit the fp32 oracle (torch CPU: the reference's own arithmetic) sees.  Per element: reconstruction
+    rtol 2e-7 (1-2 ulp) for p >= 0.5, 1e-5 below, + 1e-37; dL/dlogit rtol 2e-5 + 1e-7 of the scale + 1e-20; likelihood sum
+    rtol 2e-6."""
+    wd = dev(torch.zeros(32, C, 4, 4))
+    pairs = torch.empty(32 * _lib.thin_pair_floats(C), device=DEV)
+    _stage(thin=(wd, pairs, C))
+    x = nhwc(torch.relu(_rand(N, 32, 32, 32, seed=1)))
+    tgt, tgt8 = _sat_targets(N, C, kind)
+    td = tgt8.to(DEV) if tgt8 is not None else dev(tgt)
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / N
+    coefd = dev(coef)
+    for trip in _SAT_TRIPLES:
+        for rot in range(3 if C == 1 else 1):
+            b = torch.tensor(trip[rot:rot + 1] if C == 1 else trip, dtype=torch.float32)
+            bd = dev(b)
+            v = b.view(1, C, 1, 1).expand(N, C, 64, 64).contiguous().requires_grad_(True)
+            pref = torch.sigmoid(v)
+            tot = F.binary_cross_entropy(pref, tgt, reduction="sum")             # fp32: what the reference computes
+            (tot / N).backward()
+            elem = F.binary_cross_entropy(pref.detach(), tgt, reduction="none").double().sum()
+            launches = [("staged", lambda r, g, p: call("dvae_convT3_fwd_staged", ptr(x), ptr(pairs), ptr(bd), ptr(td), int(tgt8 is not None),
+                                                        ptr(r), ptr(g), 0, ptr(coefd), ptr(p), N, C, stream()))]
+            if tgt8 is None:
+                launches.append(("raw", lambda r, g, p: call("dvae_convT4s2_sigmoid_recon_fwd", ptr(x), _lib.NHWC, ptr(wd), ptr(bd), ptr(td),
+                                                             ptr(r), ptr(g), 0, ptr(coefd), ptr(p), N, 32, 32, 32, C, stream())))
+            for name, go in launches:
+                r, g = torch.empty(N, C, 64, 64, device=DEV), torch.empty(N, C, 64, 64, device=DEV)
+                p = torch.full((_lib.REC_NPART,), 7.0, device=DEV)
+                go(r, g, p)
+                what = "%s C=%d %s logits %s: " % (name, C, kind, tuple(b.tolist()))
+                got = p.double().sum().item()
+                assert abs(got - elem.item()) <= 2e-6 * abs(elem.item()) + 1e-30, what + "likelihood sum %r vs fp32 reference %r (ATen: %r)" % (got, elem.item(), tot.item())
+                rc, rr = r.cpu().double(), pref.detach().double()
+                # p >= 0.5: ATen's rounding of p is what the likelihood sees (1-2 ulp allowed for near-ties); below, v_exp_f32's
+                # argument v log2(e) carries |v| 6e-8 of relative error into p (5e-6 at v = -88)
+                rtol_p = torch.where(rr >= 0.5, 2e-7, 1e-5)
+                assert ((rc - rr).abs() <= rtol_p * rr + 1e-37).all(), what + "reconstruction: %r" % ((rc - rr).abs().max().item(),)
+                gerr, gref = (g.cpu().double() - v.grad.double()).abs(), v.grad.double().abs()
+                # (+ 1e-20: at v = -88 ATen's p is a denormal 6e-39 and its clamped backward leaves 1e12 p x ~ 3e-27; the
+                # hardware exponential flushes that p to 0)
+                assert (gerr <= 2e-5 * gref + 1e-7 * gref.max() + 1e-20).all(), what + "dL/dlogit: %r of %r" % (gerr.max().item(), gref.max().item())
+
+
+def test_convT3_bernoulli_reference_recorded_saturated_values():
+    """The same through the values recorded from the REAL reference (tests/golden/kats.npz: losses._reconstruction_loss on
+    sigmoid(+-16.6 ... +-104), make_golden.py --kats), fp32 and uint8 targets, both likelihood kernels."""
+    import numpy as np
+    kat = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kats.npz"))
+    N = 2
+    ar = torch.arange(N * 3 * 64 * 64)
+    xs = ((ar % 5).float() / 4).view(N, 3, 64, 64)
+    x8 = (torch.tensor([0, 128, 255], dtype=torch.uint8)[ar % 3]).view(N, 3, 64, 64)
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / N
+    coefd = dev(coef)
+    x = nhwc(torch.relu(_rand(N, 32, 32, 32, seed=1)))
+    for C in (3, 1):
+        wd = dev(torch.zeros(32, C, 4, 4))
+        pairs = torch.empty(32 * _lib.thin_pair_floats(C), device=DEV)
+        _stage(thin=(wd, pairs, C))
+        for i, trip in enumerate(kat["kat_rec_sat_logits"]):
+            for key, td, u8 in (("kat_rec_sat_loss", dev(xs), 0), ("kat_rec_sat_loss_u8", keep(x8.to(DEV)), 1)):
+                want = float(kat[key][i])
+                if C == 3:
+                    bd = dev(torch.from_numpy(trip))
+                    r, g = torch.empty(N, 3, 64, 64, device=DEV), torch.empty(N, 3, 64, 64, device=DEV)
+                    p = torch.empty(_lib.REC_NPART, device=DEV)
+                    call("dvae_convT3_fwd_staged", ptr(x), ptr(pairs), ptr(bd), ptr(td), u8, ptr(r), ptr(g), 0, ptr(coefd), ptr(p), N, 3, stream())
+                    got = p.double().sum().item() / N
+                else:       # one channel at a time through the 1-channel kernel
+                    got = 0.0
+                    tc = (x8 if u8 else xs)
+                    for c in range(3):
+                        bd = dev(torch.from_numpy(trip[c:c + 1].copy()))
+                        tcd = keep(tc[:, c:c + 1].contiguous().to(DEV))
+                        r, g = torch.empty(N, 1, 64, 64, device=DEV), torch.empty(N, 1, 64, 64, device=DEV)
+                        p = torch.empty(_lib.REC_NPART, device=DEV)
+                        call("dvae_convT3_fwd_staged", ptr(x), ptr(pairs), ptr(bd), ptr(tcd), u8, ptr(r), ptr(g), 0, ptr(coefd), ptr(p), N, 1, stream())
+                        got += p.double().sum().item() / N
+                assert abs(got - want) <= 2e-6 * abs(want), "C=%d %s logits %s: %r vs the reference's %r" % (C, key, trip.tolist(), got, want)
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_convT3_bernoulli_likelihood_is_atens_formula_on_the_emitted_reconstruction(C):
+    """Random weights at a scale that spreads the logits over +-100: whatever fp32 reconstruction p the fused kernel emits, its
+    likelihood sum is F.binary_cross_entropy of THAT p (fp32 torch CPU), clamps included -- rtol 1e-5; p itself vs fp64."""
+    N = 40
+    w = _rand(32, C, 4, 4, seed=2, scale=8.0)
+    b = _rand(C, seed=3, scale=2.0)
+    wd, bd = dev(w), dev(b)
+    pairs = torch.empty(32 * _lib.thin_pair_floats(C), device=DEV)
+    _stage(thin=(wd, pairs, C))
+    x = nhwc(torch.relu(_rand(N, 32, 32, 32, seed=1)))
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / N
+    coefd = dev(coef)
+    logit = F.conv_transpose2d(x.cpu().permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=2, padding=1)
+    assert (logit > 17).float().mean() > 0.05 and (logit < -17).float().mean() > 0.05 and logit.min() < -100.0
+    for kind in ("f32", "u8"):
+        tgt, tgt8 = _sat_targets(N, C, kind)
+        td = tgt8.to(DEV) if tgt8 is not None else dev(tgt)
+        r, g = torch.empty(N, C, 64, 64, device=DEV), torch.empty(N, C, 64, 64, device=DEV)
+        p = torch.empty(_lib.REC_NPART, device=DEV)
+        call("dvae_convT3_fwd_staged", ptr(x), ptr(pairs), ptr(bd), ptr(td), int(tgt8 is not None), ptr(r), ptr(g), 0, ptr(coefd), ptr(p), N, C, stream())
+        rc = r.cpu()
+        want = F.binary_cross_entropy(rc, tgt, reduction="none").double().sum().item()
+        got = p.double().sum().item()
+        assert abs(got - want) <= 1e-5 * want, "C=%d %s: likelihood sum %r vs ATen's formula on the emitted reconstruction %r" % (C, kind, got, want)
+        check(r, torch.sigmoid(logit), rtol=1e-5, atol_rel=2e-6, what="reconstruction vs fp64 at saturating scale")
+        vg = rc.clone().requires_grad_(True)
+        (F.binary_cross_entropy(vg, tgt, reduction="sum") / N).backward()
+        check(g, vg.grad * rc * (1 - rc), rtol=1e-5, atol_rel=2e-6, what="dL/dlogit = ATen's clamped backward x sigmoid'")
 
 
 def test_event_slots_order_a_late_consumer_after_marked_work():

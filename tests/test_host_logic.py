@@ -231,25 +231,38 @@ def test_bench_reads_hbm_traffic_from_the_newest_pmc_summary(tmp_path, monkeypat
                                                           "| k_up32ws<16, false> | 1 | 50.0 | 130.0 | 0.6 |\n")
     (prof / "r01_run31_pmc_summary.md").write_text(head + "| k_up32ws<16, true> | 1 | 1.0 | 1.0 | 0.5 |\n")
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    bytes_, src = bench.pmc_traffic("k_up32ws<16, true>")
-    assert src == os.path.join("profiles", "r02_final_pmc_summary.md")
+    bytes_, src, ipl = bench.pmc_traffic("k_up32ws<16, true>", 1024)
+    assert src == os.path.join("profiles", "r02_final_pmc_summary.md") and ipl == 1024
     assert abs(bytes_ - 310.0e6) < 1.0
-    assert abs(bench.pmc_traffic("k_up32ws<16, false>")[0] - 180.0e6) < 1.0
+    assert abs(bench.pmc_traffic("k_up32ws<16, false>", 1024)[0] - 180.0e6) < 1.0
     (prof / "r03_run1_pmc_summary.md").write_text(head + "| k_up32ws<16, true> | 1 | 170.0 | 130.0 | 0.5 |\n")
-    assert bench.pmc_traffic("k_up32ws<16, true>")[1] == os.path.join("profiles", "r03_run1_pmc_summary.md")
+    assert bench.pmc_traffic("k_up32ws<16, true>", 1024)[1] == os.path.join("profiles", "r03_run1_pmc_summary.md")
     # a variant the newest summary does not list falls back to the newest one that does
-    assert bench.pmc_traffic("k_up32ws<16, false>")[1] == os.path.join("profiles", "r02_final_pmc_summary.md")
-    assert bench.pmc_traffic("k_up32ws<16") == (None, None)           # a prefix is not a row
-    assert bench.pmc_traffic("k_no_such_kernel") == (None, None)
+    assert bench.pmc_traffic("k_up32ws<16, false>", 1024)[1] == os.path.join("profiles", "r02_final_pmc_summary.md")
+    assert bench.pmc_traffic("k_up32ws<16", 1024) == (None, None, None)           # a prefix is not a row
+    assert bench.pmc_traffic("k_no_such_kernel", 1024) == (None, None, None)
     # a numbered final visit beats every vNN / runNN visit of its round whatever the numbers (round 4: r04_v35 was picked
     # over r04_final3), a later numbered final beats an earlier one, the next round's first visit beats them all
     (prof / "r04_v35_pmc_summary.md").write_text(head + "| k_up_thin_pk<3, true, float> | 1 | 240.0 | 104.3 | 0.0 |\n")
     (prof / "r04_final3_pmc_summary.md").write_text(head + "| k_up_thin_pk<3, true, float> | 1 | 186.3 | 100.7 | 0.0 |\n")
     (prof / "r04_final2_pmc_summary.md").write_text(head + "| k_up_thin_pk<3, true, float> | 1 | 200.0 | 100.0 | 0.0 |\n")
-    bytes_, src = bench.pmc_traffic("k_up_thin_pk<3, true, float>")
+    bytes_, src, _ = bench.pmc_traffic("k_up_thin_pk<3, true, float>", 1024)
     assert src == os.path.join("profiles", "r04_final3_pmc_summary.md") and abs(bytes_ - 287.0e6) < 1.0
     (prof / "r05_v2_pmc_summary.md").write_text(head + "| k_up_thin_pk<3, true, float> | 1 | 190.0 | 100.0 | 0.0 |\n")
-    assert bench.pmc_traffic("k_up_thin_pk<3, true, float>")[1] == os.path.join("profiles", "r05_v2_pmc_summary.md")
+    assert bench.pmc_traffic("k_up_thin_pk<3, true, float>", 1024)[1] == os.path.join("profiles", "r05_v2_pmc_summary.md")
+    # images per launch: a summary collected AT the asked size wins over a newer one collected elsewhere; otherwise the newest
+    # is scaled by images / its own size; FactorVAE summaries without a header (means over mixed launch sizes) are never used
+    (prof / "r06_v1_b128_pmc_summary.md").write_text("images_per_launch: 128  (x)\n\n" + head + "| k_down_thin<3, 3, float> | 1 | 6.0 | 17.6 | 0.0 |\n")
+    (prof / "r06_v2_pmc_summary.md").write_text("images_per_launch: 1024\n\n" + head + "| k_down_thin<3, 3, float> | 1 | 50.0 | 140.0 | 0.0 |\n")
+    (prof / "r06_v3_factor_pmc_summary.md").write_text(head + "| k_down_thin<3, 3, float> | 1 | 99.0 | 300.0 | 0.0 |\n"
+                                                              "| k_only_in_factor | 1 | 1.0 | 1.0 | 0.0 |\n")
+    bytes_, src, ipl = bench.pmc_traffic("k_down_thin<3, 3, float>", 128)
+    assert src == os.path.join("profiles", "r06_v1_b128_pmc_summary.md") and ipl == 128 and abs(bytes_ - 23.6e6) < 1.0
+    bytes_, src, ipl = bench.pmc_traffic("k_down_thin<3, 3, float>", 256)
+    assert src == os.path.join("profiles", "r06_v2_pmc_summary.md") and ipl == 1024 and abs(bytes_ - 190.0e6 / 4) < 1.0
+    assert bench.pmc_traffic("k_only_in_factor", 1024) == (None, None, None)
+    assert bench.pmc_images_per_launch(str(prof / "r05_v2_pmc_summary.md")) == 1024
+    assert bench.pmc_images_per_launch(str(prof / "r06_v3_factor_pmc_summary.md")) is None
     names = ["r02_run6_x.md", "r02_final_x.md", "r03_run1_x.md", "r04_v35_x.md", "r04_final_x.md", "r04_final2_x.md", "r05_v1_x.md"]
     assert sorted(reversed(names), key=bench.pmc_file_order) == names
 
@@ -341,11 +354,49 @@ def test_bench_pmc_traffic_parser(tmp_path, monkeypatch):
     (prof / "r03_final_pmc_summary.md").write_text(hdr + "| k_down32dma<16, false> | 1 | 160.0 | 33.6 | 0.6 |\n"
                                                    "| k_down32dma<16, true> | 1 | 193.6 | 33.6 | 0.5 |\n")
     monkeypatch.setattr(b, "ROOT", str(tmp_path))
-    val, src = b.pmc_traffic("k_down32dma<16, false>")
-    assert src.endswith("r03_final_pmc_summary.md")
+    val, src, ipl = b.pmc_traffic("k_down32dma<16, false>", 1024)
+    assert src.endswith("r03_final_pmc_summary.md") and ipl == 1024
     assert abs(val - (160.0 + 33.6) * 1e6) < 1.0
-    assert abs(b.pmc_traffic("k_down32dma<16, true>")[0] - (193.6 + 33.6) * 1e6) < 1.0
-    assert b.pmc_traffic("k_nonexistent") == (None, None)
+    assert abs(b.pmc_traffic("k_down32dma<16, true>", 512)[0] - (193.6 + 33.6) * 1e6 / 2) < 1.0
+    assert b.pmc_traffic("k_nonexistent", 1024) == (None, None, None)
+
+
+def test_bench_starts_its_own_ranks_for_gpus_above_one(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (VERDICT r5 missing #2): the
+    command line, and that the JSON line of rank 0 stays the last line of stdout."""
+    import io
+    import subprocess
+    b = _bench_module()
+    cmd = b.self_launch_cmd(["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, 29417)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[3:10] == ["--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29417"]
+    assert os.path.basename(cmd[10]) == "bench.py" and os.path.isabs(cmd[10])
+    assert cmd[11:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    # fewer GPUs than ranks: refused before anything is started
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    with pytest.raises(SystemExit, match="shows 0 GPU"):
+        b.self_launch(["--gpus", "2"], 2)
+    # the job's stdout is passed through line by line, exit code returned
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    seen = {}
+
+    class FakeProc:
+        stdout = io.StringIO("banner\n{\"value\": 1}\n")
+
+        def wait(self):
+            return 0
+
+    def popen(cmd_, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd_, env
+        return FakeProc()
+    monkeypatch.setattr(subprocess, "Popen", popen)
+    out = io.StringIO()
+    monkeypatch.setattr(sys, "stdout", out)
+    assert b.self_launch(["--gpus", "2"], 2) == 0
+    monkeypatch.undo()
+    assert out.getvalue().splitlines()[-1] == '{"value": 1}'
+    assert seen["cmd"][5] == "2" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_bench_cpu_baseline_leg_runs_the_port_and_calibrates_threads_once(monkeypatch):

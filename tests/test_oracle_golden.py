@@ -46,6 +46,14 @@ def test_kats():
         got = O.reconstruction_loss(x, rr, d).item()
         np.testing.assert_allclose(got, g["kat_rec_" + d], rtol=1e-6)
         np.testing.assert_allclose(got, want, rtol=1e-6)
+    # saturated sigmoids: ATen's -100 clamp on the fp32 p (recorded from the real reference's _reconstruction_loss)
+    ar = torch.arange(2 * 3 * 64 * 64)
+    xs = ((ar % 5).float() / 4).view(2, 3, 64, 64)
+    x8 = (torch.tensor([0, 128, 255], dtype=torch.uint8)[ar % 3]).view(2, 3, 64, 64)
+    for i, v in enumerate(torch.from_numpy(g["kat_rec_sat_logits"])):
+        p = torch.sigmoid(v.view(1, 3, 1, 1).expand(2, 3, 64, 64).contiguous())
+        assert O.reconstruction_loss(xs, p, "bernoulli").item() == g["kat_rec_sat_loss"][i]
+        assert O.reconstruction_loss(x8.float() / 255.0, p, "bernoulli").item() == g["kat_rec_sat_loss_u8"][i]
     st = O.LossState(rec_dist="bernoulli", steps_anneal=10000)
     hp = dict(n_data=100, btcvae_A=1, btcvae_B=6.4, btcvae_G=1)
     loss, logs, keep = O.single_optimizer_loss("btcvae", hp, st, x, rr, mu[:2], logvar[:2], z[:2], True)

@@ -6,7 +6,8 @@ export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT="$REPO/gpurun_out/pmc"
 rm -rf "$OUT"; mkdir -p "$OUT"
-# PMC_BENCH_ARGS: extra bench.py arguments (e.g. "--config factor_celeba"); PMC_OUT: name of the summary (default pmc_summary.md)
+# PMC_BENCH_ARGS: extra bench.py arguments (e.g. "--batch 128"); PMC_OUT: name of the summary (default pmc_summary.md);
+# PMC_IMAGES: images per conv launch of that run (default 1024 = the default workload), written into the summary's header
 CMD="python $REPO/bench.py ${PMC_BENCH_ARGS:-} --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity-check --no-extra-configs --no-drop-in"
 pass() {  # name counters...
   local name=$1; shift
@@ -17,4 +18,4 @@ pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS
 pass sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
-python "$REPO/tools/pmc_summary.py" "$OUT" | tee "$REPO/gpurun_out/${PMC_OUT:-pmc_summary.md}"
+python "$REPO/tools/pmc_summary.py" "$OUT" "${PMC_IMAGES:-1024}" | tee "$REPO/gpurun_out/${PMC_OUT:-pmc_summary.md}"

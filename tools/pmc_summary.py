@@ -24,7 +24,9 @@ def load(d):
     return out
 
 
-def main(root):
+def main(root, images=None):
+    if images:      # bench.py scales traffic by (its images per launch) / this
+        print("images_per_launch: %d  (every conv / thin kernel row below is one launch over that many images)\n" % int(images))
     data = defaultdict(dict)
     for p in sorted(os.listdir(root)):
         d = os.path.join(root, p)
@@ -51,4 +53,4 @@ def main(root):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else os.environ.get("PMC_IMAGES"))
