@@ -6,14 +6,35 @@
 // is a ds_read_b32 with a swizzled, non-affine address: 192 LDS reads and ~790 VALU instructions next to the 64 MFMAs of a
 // unit and wave, 240 VGPRs (nothing else fits on the CU), matrix cores 0.58 busy.  Here
 //   * the LOADER waves (4-7) write both tiles into LDS TRANSPOSED -- channel-major: sT[cs][pixel], bT[cb][row][column
-//     parity][column/2] -- with row strides that are odd multiples of 16 bytes (conflict-free 16-byte reads);
+//     parity][column pair];
 //   * a COMPUTE wave (0-3, one per SIMD) owns the four taps of one kernel row kh: for 8 consecutive small pixels of a row it
 //     reads ONE 16-byte A operand (its channel, 4 pixels per lane half) and FOUR aligned 16-byte quads of the big tile
-//     (two per column parity); the kw = 0, 1 taps use a quad as it is, the kw = 2, 3 taps use the same data shifted by one
-//     column -- a choice of registers, not a load.  5 LDS reads per 16 MFMAs, all addresses lane-base + immediates;
+//     (two per column parity); every tap's operand is a choice of registers among them, not a load.  5 LDS reads per 16
+//     MFMAs, all addresses lane-base + immediates;
 //   * tiles are double-buffered in LDS, one workgroup barrier per unit, the next-but-one tile is in flight in registers.
 // Accumulators persist over the workgroup's units (4 taps x 16 registers per compute wave); the per-workgroup partial
 // sums go to the workspace in k_wgrad32's format and k_wgrad32_reduce (conv_mfma.hip) finishes them in a fixed order.
+//
+// Round 6, the loaders.  A wave beside an MFMA-streaming wave on its SIMD gets one instruction per 40-60 cycles whatever it
+// is (profiles/r02_run19_mfma_mix.txt), i.e. 130-170 per 8192-cycle unit; the loaders transposed with scalar stores -- 13
+// 16-byte loads and 52 ds_write_b32 per thread and unit plus a predicate per load (4-way bank conflicts on top: 53 % of the
+// kernel's LDS-active cycles, profiles/r05_final1_pmc_summary.md) -- and the memory side cost 15 % of the launch.  Now a
+// thread owns "quads": ONE channel chunk (4 channels) of FOUR column pairs of a row and parity (pixels two columns apart).
+// Its four 16-byte loads are a 4 x 4 block [pixel][channel] that leaves transposed as eight ds_write2_b32 (two neighbouring
+// column pairs of ONE channel each, from two arbitrary registers): 12 loads + 24 stores per thread and unit, nothing
+// predicated per lane.  What makes that possible:
+//   * row layout [20 | 12 floats]: parity 0 = a zero quad, then column pairs 1 .. HS (big columns 1, 3, ..); parity 1 = column
+//     pairs 0 .. HS - 1 (big columns 0, 2, ..), then a zero quad: every stored quad lies inside the image's columns, the two
+//     pad columns (-1 and 2 HS) are the zero quads, written once at kernel start.  The taps: kw = 0 takes pair sx = the
+//     element BEFORE the kw = 2 element (pair sx + 1), kw = 1 / kw = 3 likewise in the other parity;
+//   * rows outside the image: HS = 8 -- a unit is a whole image, its rows 0 and 17 are zeroed once and never stored;
+//     HS = 16 -- slots are ordered row-major and a row is exactly one wave's worth (64 slots), so "row -1 of the image's first
+//     unit" / "row 2 HS of its last" are wave-uniform conditions: a scalar branch puts zeros into that wave's registers;
+//   * channel c of a tile starts at float c * CH + 4 (c >> 2) (CH = 400 / 432 big, 80 small): the 16 lanes of a ds_read_b128
+//     group hit 16 distinct 16-byte bank slots (the stores stay 4-way conflicted -- all addresses of an instruction are
+//     congruent mod 4 dwords -- which costs LDS-array cycles nobody waits for; what the loaders are short of is issue slots) --
+//     tools/emu/wgrad_ws_lds.py checks the reads and every operand value against the direct definition.
+// The MFMA stream (operands, order) is unchanged: results are bit-identical to rounds 2-5.
 #include "common.h"
 #include "conv_mfma_common.h"
 #include "wgrad_reduce.h"
@@ -26,15 +47,16 @@ namespace dvae {
 template <int HS>
 struct WGeo {
   using G = Geo<HS>;
-  static constexpr int CWP = (G::CW + 3) / 4 * 4;                       // column pairs per parity, padded to a quad: 20 / 12
-  static constexpr int BSTR_RAW = G::BROWS * 2 * CWP;                   // floats per channel of the big tile
-  static constexpr int BSTR = (BSTR_RAW / 4) % 2 ? BSTR_RAW : BSTR_RAW + 4;   // odd multiple of 4 floats: 404 / 436
-  static constexpr int SSTR = 64 + 4;                                   // 64 pixels per channel of the small tile, padded
-  static constexpr int BT_FLOATS = 32 * BSTR;
-  static constexpr int ST_FLOATS = 32 * SSTR;
-  static constexpr int BIG_SLOTS = G::BROWS * G::BPC * 8;               // 16-byte chunks of the big tile (with halo)
-  static constexpr int BIG_NPF = (BIG_SLOTS + 255) / 256;
+  static constexpr int NQ = HS / 4;                                      // stored quads per row and parity
+  static constexpr int CWP = HS + 4;                                     // floats per row and parity: 20 / 12
+  static constexpr int BCH = G::BROWS * 2 * CWP;                         // floats per channel of the big tile: 400 / 432
+  static constexpr int SCH = 64 + 16;                                    // floats per channel of the small tile
+  static constexpr int BT_FLOATS = 31 * BCH + 28 + BCH;                  // channel c at c * CH + 4 (c >> 2)
+  static constexpr int ST_FLOATS = 31 * SCH + 28 + 64;
+  static constexpr int STORED_ROWS = HS == 16 ? G::BROWS : G::BROWS - 2; // HS = 8: rows 0 and 17 are never inside the image
+  static constexpr int NBIG = STORED_ROWS * 2 * NQ * 8;                  // quads of the big tile: 640 / 512
   static constexpr int BUF_FLOATS = BT_FLOATS + ST_FLOATS;
+  static_assert(BT_FLOATS % 4 == 0 && ST_FLOATS % 4 == 0 && NBIG % 128 == 0 && NBIG + 128 <= 768, "slot plan");
 };
 
 template <int HS>
@@ -59,6 +81,10 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
   const int stride = gridDim.x;
   const int unit0 = blockIdx.x;
 
+  // zero quads / rows outside the image: written here, never again
+  for (int e = tid; e < 2 * W::BUF_FLOATS / 4; e += 512) reinterpret_cast<f32x4*>(smem)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
   if (is_compute) {
     // ------------------------------------------------------------------ compute wave: kernel row kh, taps kw = 0..3
     const int kh = wv;
@@ -69,8 +95,8 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     float sumS = 0.f, sumK1 = 0.f, sumK2 = 0.f;
-    const int abase = i * W::SSTR + 4 * h;                            // + sy * HS + 8 gx
-    const int bbase = i * W::BSTR + kh * 2 * W::CWP + 4 * h;          // + (2 sy * 2 + par) * CWP + 8 gx  (+ 4 for the second quad)
+    const int abase = i * W::SCH + 4 * (i >> 2) + 4 * h;                              // + sy * HS + 8 gx
+    const int bbase = i * W::BCH + 4 * (i >> 2) + kh * 2 * W::CWP + 4 * h;            // + (2 sy * 2 + par) * CWP + 8 gx  (+ 4: second quad)
     __builtin_amdgcn_s_setprio(1);
     __syncthreads();                                                  // tile of the first unit is in buffer 0
     int buf = 0;
@@ -88,10 +114,10 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
         if (abl & 16) return;
         const int sy = g / GPR, gx = g % GPR;
         A[slot] = *reinterpret_cast<const f32x4*>(st + abase + sy * HS + 8 * gx);
-        const float* bp = bt + bbase + (4 * sy) * W::CWP + 8 * gx;    // row 2 sy + kh, parity 0
+        const float* bp = bt + bbase + (4 * sy) * W::CWP + 8 * gx;    // row 2 sy + kh, parity 0: [zero | pairs 1..4 | ..]
         P0a[slot] = *reinterpret_cast<const f32x4*>(bp);
         P0b[slot] = *reinterpret_cast<const f32x4*>(bp + 4);
-        P1a[slot] = *reinterpret_cast<const f32x4*>(bp + W::CWP);
+        P1a[slot] = *reinterpret_cast<const f32x4*>(bp + W::CWP);     // parity 1: [pairs 0..3 | .. | zero]
         P1b[slot] = *reinterpret_cast<const f32x4*>(bp + W::CWP + 4);
       };
       rd(0, 0);
@@ -103,11 +129,12 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
         if (g + 1 < NG) rd(g + 1, c ^ 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          // small pixel sx = 8 gx + 4 h + j; big column pair cw = sx + (kw >> 1), parity kw & 1
+          // small pixel sx = 8 gx + 4 h + j; big column pair cw = sx + (kw >> 1), parity kw & 1; parity 0 is stored from pair
+          // 1 on behind a zero quad: pair cw sits at float cw + 3 of its row
           const float a = A[c][j];
-          const float b0 = P0a[c][j];                                  // kw = 0
+          const float b0 = j > 0 ? P0b[c][j - 1] : P0a[c][3];          // kw = 0: pair sx
           const float b1 = P1a[c][j];                                  // kw = 1
-          const float b2 = j < 3 ? P0a[c][j + 1] : P0b[c][0];          // kw = 2: parity 0, one column pair to the right
+          const float b2 = P0b[c][j];                                  // kw = 2: pair sx + 1
           const float b3 = j < 3 ? P1a[c][j + 1] : P1b[c][0];          // kw = 3
           acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
@@ -146,77 +173,106 @@ __global__ __launch_bounds__(512) void k_wgrad32ws(const float* __restrict__ big
   } else {
     // ------------------------------------------------------------------ loader waves
     const int lt = tid - 256;
-    // big tile: slot s = (row r, padded column pc, 16-byte chunk) -> 4 channel-major LDS floats
-    int b_lds[W::BIG_NPF], b_gofs[W::BIG_NPF], b_row[W::BIG_NPF];
+    const int lw = wv - 4;
+    // quad slot s = lt + 256 k, k = 0..2: s < NBIG: big tile, s = ((row, parity, quad), chunk) row-major -- a row of the
+    // HS = 16 tile is one wave's worth; NBIG <= s < NBIG + 128: small tile (pixel quad, chunk).  k = 0, 1 are big quads for every
+    // thread; k = 2: HS = 16 -- loader waves 0, 1 big (rows 8, 9), waves 2, 3 small; HS = 8 -- waves 0, 1 small, 2, 3 nothing
+    const bool k2_big = HS == 16 && lw < 2, k2_small = HS == 16 ? lw >= 2 : lw < 2;
+    // float offsets: source relative to the unit's base pointer (the big base is row -1 of the unit's rows, so every offset is
+    // non-negative: scalar base + 32-bit lane offset addressing); destination of (buffer, channel u) inside the LDS allocation
+    unsigned g_of[3];
+    int l_of[2][3][4];
 #pragma unroll
-    for (int k = 0; k < W::BIG_NPF; ++k) {
-      const int s = lt + k * 256;
-      b_lds[k] = -1; b_gofs[k] = 0; b_row[k] = 0;
-      if (s < W::BIG_SLOTS) {
-        const int chunk = s & 7;
-        int q = s >> 3;
-        const int pc = q % G::BPC; const int r = q / G::BPC;
-        const int par = pc & 1, cw = pc >> 1, bx = pc - 1;
-        b_lds[k] = (4 * chunk) * W::BSTR + (r * 2 + par) * W::CWP + cw;
-        b_gofs[k] = ((r - 1) * HB + bx) * 32 + chunk * 4;
-        b_row[k] = r | ((bx >= 0 && bx < HB) ? (1 << 16) : 0);
+    for (int k = 0; k < 3; ++k) {
+      const int s = lt + 256 * k;
+      int l0 = 0, ch = 0;
+      g_of[k] = 0;
+      if (s < W::NBIG) {
+        const int chunk = s & 7, q = s >> 3;
+        const int q4 = q % W::NQ, par = (q / W::NQ) & 1, r = q / (2 * W::NQ) + (HS == 16 ? 0 : 1);
+        g_of[k] = (unsigned)((r * HB + 8 * q4 + (1 - par)) * 32 + 4 * chunk);       // + 64 t: big columns 8 q4 + 2 t + (1 - par)
+        l0 = chunk * (4 * W::BCH + 4) + (r * 2 + par) * W::CWP + (par == 0 ? 4 : 0) + 4 * q4;
+        ch = W::BCH;
+      } else {                                         // (HS = 8: s >= NBIG + 128 -- loaded like the small quad 128 slots back, never stored)
+        const int sp = (s - W::NBIG) & 127, chunk = sp & 7, pq = sp >> 3;
+        g_of[k] = (unsigned)(pq * 128 + 4 * chunk);                                 // + 32 t: pixels 4 pq + t
+        l0 = W::BT_FLOATS + chunk * (4 * W::SCH + 4) + 4 * pq;
+        ch = W::SCH;
       }
+#pragma unroll
+      for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) l_of[b_][k][u] = b_ * W::BUF_FLOATS + l0 + u * ch;
     }
-    // small tile: 64 pixels x 8 chunks = 512 slots, two per loader thread
     // two register sets: tiles k+2 and k+3 are in flight from HBM while tile k+1 sits in LDS (the whole chip issues its tile
-    // loads in the same few hundred cycles after a barrier: one unit time of look-ahead does not cover the queueing delay)
-    f32x4 pbA[W::BIG_NPF], psA[2], pbB[W::BIG_NPF], psB[2];
-    auto load_unit = [&](int u, f32x4 (&pb)[W::BIG_NPF], f32x4 (&ps)[2]) {
+    // loads in the same few hundred cycles after a barrier: one unit time of look-ahead does not cover the queueing delay).
+    // Every load_unit issues the SAME 12 loads whatever the unit (a unit index past the end is clamped, a wave whose row lies
+    // outside the image loads the neighbouring row and stores zeros instead): with loads behind branches the compiler cannot
+    // count what is in flight and makes each store wait for ALL of them (s_waitcnt vmcnt(0) in rounds 2-5), the newest set
+    // included -- which is the look-ahead gone.
+    f32x4 pA[3][4], pB[3][4];
+    constexpr unsigned UPI = HS * HS / G::U;                           // units per image: 4 / 1
+    const unsigned last_unit = (unsigned)(n_units - 1);
+    auto load_unit = [&](int u_, f32x4 (&p)[3][4]) {
       if (abl & 2) return;
-      const long P0 = (long)u * G::U;
-      const int n0 = (int)(P0 / (HS * HS));
-      const int sy0 = (int)(P0 % (HS * HS)) / HS;
-      const float* bbase_g = big + ((long)n0 * HB + 2 * sy0) * HB * 32;
+      const unsigned u = (unsigned)u_ < last_unit ? (unsigned)u_ : last_unit;
+      const unsigned n0 = u / UPI, sy0 = (u % UPI) * G::R;
+      const bool top = HS == 16 && sy0 == 0, bot = HS == 16 && sy0 + G::R == HS;   // (scalar: the unit's first / last rows)
+      // base = row 2 sy0 - 1 of the image; the wave that holds row -1 (2 HS) reads row 0 (2 HS - 1) instead
+      const float* bg = big + ((size_t)n0 * HB + 2 * sy0) * (HB * 32) - HB * 32;
+      const float* s0 = bg + ((top && lw == 0) ? HB * 32 : 0) + g_of[0];
+      const float* s1 = bg + g_of[1];
+      const float* s2 = (k2_big ? bg - ((bot && lw == 1) ? HB * 32 : 0) : small + (size_t)u * (G::U * 32)) + g_of[2];
 #pragma unroll
-      for (int k = 0; k < W::BIG_NPF; ++k) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int r = b_row[k] & 0xff;
-        const int by = 2 * sy0 - 1 + r;
-        if ((b_row[k] >> 16) && by >= 0 && by < HB) v = *reinterpret_cast<const f32x4*>(bbase_g + b_gofs[k]);
-        pb[k] = v;
+      for (int t = 0; t < 4; ++t) p[0][t] = *reinterpret_cast<const f32x4*>(s0 + 64 * t);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) p[1][t] = *reinterpret_cast<const f32x4*>(s1 + 64 * t);
+      if (k2_big) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) p[2][t] = *reinterpret_cast<const f32x4*>(s2 + 64 * t);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) p[2][t] = *reinterpret_cast<const f32x4*>(s2 + 32 * t);
       }
-      const float* sbase_g = small + P0 * 32;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) ps[k] = *reinterpret_cast<const f32x4*>(sbase_g + (lt + k * 256) * 4);
     };
-    auto store_unit = [&](int b, const f32x4 (&pb)[W::BIG_NPF], const f32x4 (&ps)[2]) {
+    auto store_unit = [&](int b, int u_, const f32x4 (&p)[3][4]) {
       if (abl & 1) return;
-      float* bt = smem + b * W::BUF_FLOATS;
-      float* st = bt + W::BT_FLOATS;
+      const unsigned sy0 = ((unsigned)u_ % UPI) * G::R;
+      const bool top = HS == 16 && sy0 == 0, bot = HS == 16 && sy0 + G::R == HS;
 #pragma unroll
-      for (int k = 0; k < W::BIG_NPF; ++k) {
-        if (b_lds[k] >= 0) {
+      for (int k = 0; k < 3; ++k) {
+        if (k == 2 && !k2_big && !k2_small) continue;
+        // the 4 x 4 block [pixel t][channel u] leaves transposed: ds_write2_b32 takes its two dwords from two ARBITRARY
+        // registers, so two neighbouring pixels of one channel go out in one instruction with no register shuffling (a
+        // ds_write_b128 per channel would need its four dwords in consecutive registers: 16 v_mov per quad)
+        const bool outside = (k == 0 && lw == 0 && top) || (k == 2 && k2_big && lw == 1 && bot);   // scalar
+        if (outside) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) bt[b_lds[k] + u * W::BSTR] = pb[k][u];
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) smem[l_of[b][k][u] + t] = 0.f;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) smem[l_of[b][k][u] + t] = p[k][t][u];
         }
       }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int s = lt + k * 256;
-        const int chunk = s & 7, p = s >> 3;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) st[(4 * chunk + u) * W::SSTR + p] = ps[k][u];
-      }
     };
-    if (unit0 < n_units) { load_unit(unit0, pbA, psA); store_unit(0, pbA, psA); }
-    if (unit0 + stride < n_units) load_unit(unit0 + stride, pbA, psA);
-    if (unit0 + 2 * stride < n_units) load_unit(unit0 + 2 * stride, pbB, psB);
+    if (unit0 < n_units) { load_unit(unit0, pA); store_unit(0, unit0, pA); }
+    load_unit(unit0 + stride, pA);
+    load_unit(unit0 + 2 * stride, pB);
     __syncthreads();
     // set A holds tiles k+1 (k even), set B tiles k+1 (k odd); the loop is unrolled by two so that the sets stay static
     int unit = unit0;
     while (unit < n_units) {
-      if (unit + stride < n_units) store_unit(1, pbA, psA);
-      if (unit + 3 * stride < n_units) load_unit(unit + 3 * stride, pbA, psA);
+      if (unit + stride < n_units) store_unit(1, unit + stride, pA);
+      load_unit(unit + 3 * stride, pA);
       if (!(abl & 32)) __syncthreads();
       unit += stride;
       if (unit >= n_units) break;
-      if (unit + stride < n_units) store_unit(0, pbB, psB);
-      if (unit + 3 * stride < n_units) load_unit(unit + 3 * stride, pbB, psB);
+      if (unit + stride < n_units) store_unit(0, unit + stride, pB);
+      load_unit(unit + 3 * stride, pB);
       if (!(abl & 32)) __syncthreads();
       unit += stride;
     }
