@@ -138,16 +138,30 @@ def pmc_traffic(kernel, images):
     return best or (None, None, None)
 
 
-def _time_launch(fn, n=20, warm=3):
+def _time_launch(fn, n=50, warm=3, settle_ms=30.0, max_rounds=8):
+    """ms per launch of `fn` alone, back-to-back, HIP events on torch's current stream (= the stream the launches go to).
+    Untimed first: `warm` launches, then rounds of >= `settle_ms` of launches until two consecutive rounds agree within 2 %
+    (a roofline leg follows seconds of host work: twenty launches from an idle-clocked GPU under-read a 80 us kernel by
+    8-12 %, profiles/r06_v7_ab2.txt vs the r05 bench lines).  Then `n` timed launches."""
+    def run(k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+    last = run(5)
+    for _ in range(max_rounds):
+        cur = run(max(5, min(400, int(settle_ms / max(last, 1e-3)))))
+        done = abs(cur - last) <= 0.02 * cur
+        last = cur
+        if done:
+            break
+    return run(n)
 
 
 def kernel_rooflines(B, device):

@@ -46,7 +46,7 @@ __device__ __forceinline__ float sigmoid_hw_mm(float v) { return sigmoid_aten(v)
 // eight waves through every phase in lock step -- 57 / 83 us without / with the likelihood at 1024 images, no better than the
 // packed-FMA kernel (measured in round 5; that visit's raw file did not survive a replaced build container).
 template <bool FUSE, int DIST, typename TT>
-__global__ __launch_bounds__(512, 2) void k_up_thin_mm(const float* __restrict__ small, const float* __restrict__ wimg,
+__global__ __launch_bounds__(512, 4) void k_up_thin_mm(const float* __restrict__ small, const float* __restrict__ wimg,
                                                        const float* __restrict__ bias, float* __restrict__ out, int N,
                                                        int n_units, const TT* __restrict__ target, float* __restrict__ g,
                                                        const float* __restrict__ coef, float* __restrict__ partials) {
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512, 2) void k_up_thin_mm(const float* __restrict__
   float* tin = smem;                             // [UTM_TILE]
   float* stage = smem + UTM_TILE;                // [3][22][64]
   float* redl = stage + UTM_STAGE;               // [8]
+  float* wl = redl + 8;                          // [32][64]: the A-operand image (register q of lane l at q * 64 + l)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kg = lane >> 4;
@@ -63,10 +64,11 @@ __global__ __launch_bounds__(512, 2) void k_up_thin_mm(const float* __restrict__
   // zero columns of the tile (never written again) -- and everything else once, so that no read ever sees garbage
   for (int e = tid; e < UTM_TILE / 4; e += 512) reinterpret_cast<f32x4*>(tin)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // A operand: W'[(c, dy, dx)][(tap, 8 kg + i)] for MFMA (tap, i), this lane's row m = lane % 16 and k-slot kg
-  float wr[32];
-#pragma unroll
-  for (int q = 0; q < 32; ++q) wr[q] = wimg[q * 64 + lane];
+  // A operand: W'[(c, dy, dx)][(tap, 8 kg + i)] for MFMA (tap, i), this lane's row m = lane % 16 and k-slot kg.  Round 6: the
+  // image lives in LDS (8 KB) and a wave reads a tap's 8 registers per unit (8 conflict-free ds_read_b32 per 24 MFMAs)
+  // instead of holding all 32 for the whole kernel: those registers now carry the NEXT unit's input tile through the second
+  // phase (below)
+  for (int e = tid; e < 32 * 64 / 4; e += 512) reinterpret_cast<f32x4*>(wl)[e] = reinterpret_cast<const f32x4*>(wimg)[e];
   const float bv = (kg < 3 && bias) ? bias[kg] : 0.f;
 
   // ---- everything that does not depend on the unit, once -----------------------------------------------------------------
@@ -105,24 +107,47 @@ __global__ __launch_bounds__(512, 2) void k_up_thin_mm(const float* __restrict__
   }
   __syncthreads();                                        // the zero fill is complete
 
+  // Round 6: the NEXT unit's input tile is requested while this unit's second phase runs (registers pf: the 24 the weights
+  // used to occupy).  Alone the kernel is no faster for it (75.2 us at 1024 images against 72.5-73.2 with the weights in
+  // registers and the tile requested where it is stored; requesting the targets early as well: 96 us, the registers spill) --
+  // but the STEP is: 1.066 against 1.072-1.078 ms on the same box, three alternations (profiles/r06_v8_ab3.txt,
+  // r06_v9_ab4.txt): beside the estimator's backward kernels on the other stream, what counts is that the launch does not
+  // stand still on a round trip.
+  f32x4 pf[6];
+  auto load_tile = [&](int unit) {
+    const int n = unit / 3, u3 = unit - 3 * n;
+    const int sy0 = UTM_BR * u3 - 1;
+    const float* base = small + ((long)n * 32 + sy0) * 1024 + pgo;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int sy = sy0 + 2 * k + rhalf;
+      pf[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (sy >= 0 && sy < 32) pf[k] = *reinterpret_cast<const f32x4*>(base + 2048 * k);
+    }
+  };
+  if ((int)blockIdx.x < n_units) load_tile(blockIdx.x);
   for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     const int n = unit / 3, u3 = unit - 3 * n;
     const int Y0 = UTM_OR * u3 - 1;                       // image row of stage row 0
     const long img0 = ((long)n * 3 * 64 + Y0) * 64;       // (element offset of stage row 0 of channel 0; may be negative)
-    // ---- tile in: HBM / L2 -> registers -> swizzled LDS (rows outside the image: zeros)
-    {
-      const int sy0 = UTM_BR * u3 - 1;
-      const float* base = small + ((long)n * 32 + sy0) * 1024 + pgo;
-      f32x4 pf[6];
+    // ---- targets of the second phase: requested now
+    f32x4 tg[3];
+    uchar4 tg8[3];
+    auto load_targets = [&]() {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int sy = sy0 + 2 * k + rhalf;
-        pf[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (sy >= 0 && sy < 32) pf[k] = *reinterpret_cast<const f32x4*>(base + 2048 * k);
+      for (int k = 0; k < 3; ++k) {
+        const int Y = Y0 + brow[k];
+        tg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tg8[k] = make_uchar4(0, 0, 0, 0);
+        if (Y >= 0 && Y < 64) {
+          if constexpr (sizeof(TT) == 4) tg[k] = *reinterpret_cast<const f32x4*>(target + img0 + bgo[k]);
+          else tg8[k] = *reinterpret_cast<const uchar4*>(target + img0 + bgo[k]);
+        }
       }
+    };
+    // ---- tile in: registers -> swizzled LDS (rows outside the image: zeros)
 #pragma unroll
-      for (int k = 0; k < 6; ++k) *reinterpret_cast<f32x4*>(tin + plo + 2 * UTM_COLS * 32 * k) = pf[k];
-    }
+    for (int k = 0; k < 6; ++k) *reinterpret_cast<f32x4*>(tin + plo + 2 * UTM_COLS * 32 * k) = pf[k];
     __syncthreads();                                      // the tile is complete; the stage is free (second phase of the last unit)
     // ---- matrix phase
     f32x4 acc[3];
@@ -132,6 +157,9 @@ __global__ __launch_bounds__(512, 2) void k_up_thin_mm(const float* __restrict__
     for (int tap = 0; tap < 4; ++tap) {
       const int a = tap >> 1, b = tap & 1;
       f32x4 x[3][2];
+      float wr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wr[i] = wl[(tap * 8 + i) * 64 + lane];
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         if (s == 2 && !tile3) continue;
@@ -145,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void k_up_thin_mm(const float* __restrict__
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           if (s == 2 && !tile3) continue;
-          acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[tap * 8 + i], x[s][i >> 2][i & 3], acc[s], 0, 0, 0);
+          acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i], x[s][i >> 2][i & 3], acc[s], 0, 0, 0);
         }
       }
     }
@@ -158,21 +186,14 @@ __global__ __launch_bounds__(512, 2) void k_up_thin_mm(const float* __restrict__
       if (x1ok[s]) { sp[1] = acc[s][1] + bv; sp[65] = acc[s][3] + bv; }
     }
     __syncthreads();                                      // the stage is complete; the tile may be overwritten
+    // ---- the next unit's tile: in flight during the second phase
+    if (unit + (int)gridDim.x < n_units) load_tile(unit + gridDim.x);
     // ---- second phase: rows of the stage, 16 bytes per access, every lane busy
-    f32x4 tg[3];
-    if (FUSE) {
+    if (FUSE) load_targets();
+    if (FUSE && sizeof(TT) != 4) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int Y = Y0 + brow[k];
-        tg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (Y >= 0 && Y < 64) {
-          if constexpr (sizeof(TT) == 4) tg[k] = *reinterpret_cast<const f32x4*>(target + img0 + bgo[k]);
-          else {
-            const uchar4 t8 = *reinterpret_cast<const uchar4*>(target + img0 + bgo[k]);
-            tg[k] = f32x4{(float)t8.x / 255.0f, (float)t8.y / 255.0f, (float)t8.z / 255.0f, (float)t8.w / 255.0f};   // ToTensor
-          }
-        }
-      }
+      for (int k = 0; k < 3; ++k)     // ToTensor
+        tg[k] = f32x4{(float)tg8[k].x / 255.0f, (float)tg8[k].y / 255.0f, (float)tg8[k].z / 255.0f, (float)tg8[k].w / 255.0f};
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -227,7 +248,7 @@ int launch_up_thin_mm(const float* small, const float* wimg, const float* bias, 
   const int n_units = 3 * N;
   static const int cap = env_int("DVAE_UP_THIN_MM_GRID", 512);         // two workgroups per CU
   const int grid = n_units < cap ? n_units : cap;
-  constexpr size_t lds = (size_t)(UTM_TILE + UTM_STAGE + 8) * sizeof(float);
+  constexpr size_t lds = (size_t)(UTM_TILE + UTM_STAGE + 8 + 32 * 64) * sizeof(float);
 #define UTM_GO(FUSE_, DIST_, TT_)                                                                                         \
   do {                                                                                                                    \
     static DeviceOnce attr;                                                                                               \

@@ -25,50 +25,32 @@
 
 namespace dvae {
 
-template <int HS, int NTHR, int NPF>
-__device__ __forceinline__ void init_small_slots_n(SlotDesc<NPF>& d, int t) {
+// Input tile of the memory waves (round 6).  Only the pixels INSIDE the image's columns are staged: HS = 16 -- 6 rows x 16
+// columns x 8 chunks of 16 bytes = 768 slots, 3 per thread; HS = 8 (a unit is a whole image) -- rows 1..8 x 8 x 8 = 512, 2 per
+// thread.  The halo columns (and for HS = 8 the halo rows) are zeroed once at kernel start and never written again.  A slot's
+// row is wave-uniform (slot s = thread + 256 k is row-major with 128 / 64 slots per row), so "this row lies outside the image"
+// (HS = 16: row 0 of an image's first unit, row 5 of its last) is a scalar condition: such a wave loads the neighbouring row
+// (same instruction count, valid address) and stores zeros.  Every unit therefore issues the SAME loads -- no per-lane
+// predicate, exec juggling or branch per slot (rounds 2-5: 70 instructions per thread and unit for 4 loads; a wave beside an
+// MFMA-streaming wave gets 130-170 instructions per unit in total, profiles/r02_run19_mfma_mix.txt) -- and the compiler can
+// count what is in flight instead of waiting for everything.
+template <int HS>
+struct UpIn {
   using G = Geo<HS>;
+  static constexpr int NPF = HS == 16 ? 3 : 2;
+  static constexpr int SPR = HS * 8;                  // slots per row: 128 / 64
+  unsigned gofs[NPF];                                 // float offset relative to row sy0 - 1 of the unit's image
+  int lds[NPF];                                       // (swizzled) float offset inside an input image
+  __device__ __forceinline__ void init(int ht) {
 #pragma unroll
-  for (int k = 0; k < NPF; ++k) {
-    const int s = t + k * NTHR;
-    d.lds[k] = -1; d.gofs[k] = 0; d.rimg[k] = 0;
-    if (s < G::SH_SLOTS) {
-      const int chunk = s & 7;
-      int q = s >> 3;
-      const int col = q % G::SCOLS; q /= G::SCOLS;
-      const int row = q;                       // IMGS == 1
-      const int sx = col - 1;
-      d.lds[k] = (row * G::SCOLS + col) * 32 + ((chunk ^ swz_small<HS>(row, col)) << 2);
-      d.gofs[k] = ((row - 1) * HS + sx) * 32 + chunk * 4;
-      d.rimg[k] = row | ((sx >= 0 && sx < HS) ? (1 << 16) : 0);
+    for (int k = 0; k < NPF; ++k) {
+      const int s = ht + 256 * k;
+      const int chunk = s & 7, col = ((s >> 3) & (HS - 1)) + 1, row = s / SPR + (HS == 16 ? 0 : 1);
+      gofs[k] = (unsigned)((row * HS + col - 1) * 32 + 4 * chunk);
+      lds[k] = (row * G::SCOLS + col) * 32 + ((chunk ^ swz_small<HS>(row, col)) << 2);
     }
   }
-}
-
-template <int HS, int NPF>
-__device__ __forceinline__ void load_small_n(f32x4 (&pf)[NPF], const SlotDesc<NPF>& d, const float* __restrict__ small,
-                                             int unit) {
-  using G = Geo<HS>;
-  const long P0 = (long)unit * G::U;
-  const int n0 = (int)(P0 / (HS * HS));
-  const int sy0 = (int)(P0 % (HS * HS)) / HS;
-  const float* base = small + ((long)n0 * HS + sy0) * HS * 32;
-#pragma unroll
-  for (int k = 0; k < NPF; ++k) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const int row = d.rimg[k] & 0xff;
-    const int sy = sy0 - 1 + row;
-    if ((d.rimg[k] >> 16) && sy >= 0 && sy < HS) v = *reinterpret_cast<const f32x4*>(base + d.gofs[k]);
-    pf[k] = v;
-  }
-}
-
-template <int NPF>
-__device__ __forceinline__ void store_small_n(const f32x4 (&pf)[NPF], const SlotDesc<NPF>& d, float* st) {
-#pragma unroll
-  for (int k = 0; k < NPF; ++k)
-    if (d.lds[k] >= 0) *reinterpret_cast<f32x4*>(st + d.lds[k]) = pf[k];
-}
+};
 
 #define UPWS_OUT_FLOATS 8192        // one unit's output block: 64 small pixels x 4 parity classes x 32 channels
 
@@ -86,7 +68,7 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
   using G = Geo<HS>;
   static_assert(G::IMGS == 1, "one image per unit");
   constexpr int HB = 2 * HS;
-  constexpr int LNPF = (G::SH_SLOTS + 255) / 256;
+  constexpr int LNPF = UpIn<HS>::NPF;
 #ifdef DVAE_DEBUG_SWITCHES
   const int abl = act >> 8;     // timing ablations (DVAE_UPWS_ABLATE, debug builds; results invalid): 1 no output stores,
   act &= 0xff;                  // 2 no mask loads
@@ -104,12 +86,42 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
   const int stride = gridDim.x;
   const int unit0 = blockIdx.x;
 
-  SlotDesc<LNPF> sd;
+  UpIn<HS> sd;
   f32x4 pf[LNPF];
   const int ht = tid - 256;
+  const int mw_ = wv - 4;                            // memory wave 0..3
+  constexpr unsigned UPI = HS * HS / G::U;           // units per image: 4 / 1
+  const unsigned last_unit = (unsigned)(n_units - 1);
+  // rows of this wave's slots that can fall outside the image (HS = 16): slot 0 of waves 0, 1 = tile row 0, slot 2 of waves
+  // 2, 3 = tile row 5
+  auto load_in = [&](int u_) {
+    const unsigned u = (unsigned)u_ < last_unit ? (unsigned)u_ : last_unit;      // (a unit index past the end: clamped, never stored)
+    const unsigned n0 = u / UPI, sy0 = (u % UPI) * G::R;
+    const float* base = small + ((size_t)n0 * HS + sy0) * (HS * 32) - HS * 32;    // row sy0 - 1 (not dereferenced outside the image)
+    const bool top = HS == 16 && sy0 == 0, bot = HS == 16 && sy0 + G::R == HS;
+#pragma unroll
+    for (int k = 0; k < LNPF; ++k) {
+      const float* src = base + sd.gofs[k];
+      if (HS == 16 && k == 0) src += (top && mw_ < 2) ? HS * 32 : 0;
+      if (HS == 16 && k == 2) src -= (bot && mw_ >= 2) ? HS * 32 : 0;
+      pf[k] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  auto store_in = [&](int u_, float* st) {
+    const unsigned sy0 = ((unsigned)u_ % UPI) * G::R;
+    const bool top = HS == 16 && sy0 == 0, bot = HS == 16 && sy0 + G::R == HS;
+#pragma unroll
+    for (int k = 0; k < LNPF; ++k) {
+      const bool outside = HS == 16 && ((k == 0 && top && mw_ < 2) || (k == 2 && bot && mw_ >= 2));   // scalar
+      *reinterpret_cast<f32x4*>(st + sd.lds[k]) = outside ? f32x4{0.f, 0.f, 0.f, 0.f} : pf[k];
+    }
+  };
+  // the halo of both input images: zero, once
+  for (int e = tid; e < 2 * G::SH_FLOATS / 4; e += 512) reinterpret_cast<f32x4*>(in0)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
   if (!is_compute) {
-    init_small_slots_n<HS, 256, LNPF>(sd, ht);
-    if (unit0 < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit0);
+    sd.init(ht);
+    load_in(unit0);
   }
   // compute-wave constants (the memory waves skip their use)
   const int cls = wv & 3;
@@ -136,8 +148,8 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
     stage_weights<false>(w, wl, tid);
   }
   if (!is_compute) {
-    if (unit0 < n_units) store_small_n<LNPF>(pf, sd, in0);
-    if (unit0 + stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit0 + stride);
+    if (unit0 < n_units) store_in(unit0, in0);
+    load_in(unit0 + stride);
   }
   __syncthreads();                                   // weight image and the first input tile are in LDS
   if (is_compute && !w_staged) {
@@ -205,10 +217,13 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
           const unsigned long long b0 = __builtin_amdgcn_ballot_w64(v0 > 0.f), b1 = __builtin_amdgcn_ballot_w64(v1 > 0.f);
           // (timing ablations, profiles/r04_v20_outbits_abl.txt, B = 1024: plain forward 75.5 us, + the 32 ballots 80.6,
           // + the 64 v_writelane 87.3 -- 90.8 with lane-0 ds_write_b32 under an exec mask instead)
-          asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)b0), "n"(e));
-          asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)(b0 >> 32)), "n"(16 + e));
-          asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)b1), "n"(32 + e));
-          asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(wordv) : "s"((uint32_t)(b1 >> 32)), "n"(48 + e));
+          // (the hazard is real: without wait states behind the v_cmp that wrote the SGPR pair the written words are wrong --
+          // tests/test_gpu_mask_bits.py, profiles/r06_v9_ab4.txt; ONE s_nop 3 in front of the four writes of a row instead of one each:
+          // 80.4 -> 75.0 us at 1024 images, profiles/r06_v11_ab5.txt)
+          asm("s_nop 3\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %6\n\tv_writelane_b32 %0, %3, %7\n\tv_writelane_b32 %0, %4, %8"
+              : "+v"(wordv)
+              : "s"((uint32_t)b0), "s"((uint32_t)(b0 >> 32)), "s"((uint32_t)b1), "s"((uint32_t)(b1 >> 32)), "n"(e), "n"(16 + e), "n"(32 + e),
+                "n"(48 + e));
         }
       }
       // the unit's 64 words of this wave: output image `ob` is out0 + b * UPWS_OUT_FLOATS, its bit image bimg + b * 256
@@ -304,8 +319,8 @@ __global__ __launch_bounds__(512) void k_up32ws(const float* __restrict__ small,
     for (;;) {
       const bool have = unit < n_units;
       if (have) {
-        if (unit + stride < n_units) store_small_n<LNPF>(pf, sd, in0 + ((k + 1) & 1) * G::SH_FLOATS);
-        if (unit + 2 * stride < n_units) load_small_n<HS, LNPF>(pf, sd, small, unit + 2 * stride);
+        if (unit + stride < n_units) store_in(unit + stride, in0 + ((k + 1) & 1) * G::SH_FLOATS);
+        load_in(unit + 2 * stride);
       }
       if (u2 >= 0) drain(u2, k & 1);
       if (MASK == 1 && u1 >= 0 && !(abl & 2)) {

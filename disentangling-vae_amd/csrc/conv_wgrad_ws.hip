@@ -33,7 +33,13 @@
 //   * channel c of a tile starts at float c * CH + 4 (c >> 2) (CH = 400 / 432 big, 80 small): the 16 lanes of a ds_read_b128
 //     group hit 16 distinct 16-byte bank slots (the stores stay 4-way conflicted -- all addresses of an instruction are
 //     congruent mod 4 dwords -- which costs LDS-array cycles nobody waits for; what the loaders are short of is issue slots) --
-//     tools/emu/wgrad_ws_lds.py checks the reads and every operand value against the direct definition.
+//     tools/emu/wgrad_ws_lds.py checks the reads and every operand value against the direct definition.  The same quads as
+//     four provably aligned ds_write_b128 (conflict-free: the 8 lanes of a store group are the 8 chunks of one quad; 16 v_mov
+//     per quad to put the transposed dwords into consecutive registers) measured 77.9 us against 76.5 at 1024 images, 27.6
+//     against 27.3 at 16 <-> 8, the same step time (profiles/r06_v11_ab5.txt): bank conflicts of the stores are not what the
+//     kernel waits for, and the form with fewer instructions wins.
+// Measured (same box, profiles/r06_v7_ab2.txt): 80.6 -> 76.4 us (+ reduce) at 1024 images, 16 <-> 8: 30.0 -> 27.2 us; the
+// 1024-image step 1.1035 -> 1.066 ms (inside the step the loaders compete with the other stream's kernels as well).
 // The MFMA stream (operands, order) is unchanged: results are bit-identical to rounds 2-5.
 #include "common.h"
 #include "conv_mfma_common.h"
