@@ -156,6 +156,30 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
   barrier_nofence();                                   // tile(unit0) is in buffer 0
   __builtin_amdgcn_s_setprio(1);
   int buf = 0;
+  f32x4 P[2][2][2];                                    // [slot][mt][h]: pixel operands of a tap
+#ifdef DVAE_DEBUG_SWITCHES
+  if (abl & 8) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) P[a >> 2][(a >> 1) & 1][a & 1] = f32x4{1.f, 2.f, 3.f, 4.f};
+  }
+#endif
+  auto rd = [&](const float* bt, int tap, int slot) {
+#ifdef DVAE_DEBUG_SWITCHES
+    if (abl & 8) return;
+#endif
+    const int kh = tap >> 2, kw = tap & 3;
+    const int tc = ((kh * 2 + (kw & 1)) * G::CW) * 32;      // row 2 sy_l + kh, parity kw & 1
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        P[slot][mt][h] = *reinterpret_cast<const f32x4*>(bt + vo[mt][h][kw >> 1][NS2 == 2 ? (kh >> 1) : 0] + tc);
+  };
+  // the first tap's operands of a unit are requested BEFORE the previous unit's epilogue (right behind the barrier that
+  // publishes its tile): the LDS round trip runs under the epilogue's arithmetic and stores instead of in front of the unit's
+  // first MFMA (round 6: 66.9 -> 66.3 us plain, 74.1 -> 70.0 us masked at 1024 images, the step 1.064 -> 1.056 ms:
+  // profiles/r06_v12_ab6.txt)
+  if (unit0 < n_units) rd(smem, 0, 0);
   for (int unit = unit0; unit < n_units; unit += stride) {
     const float* bt = smem + buf * D::BUF_FLOATS;
     const long obase = ((long)unit * 64 + 32 * ph + i16) * 32 + 16 * ch + 4 * kq;     // + mt * 16 * 32
@@ -169,31 +193,10 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 P[2][2][2];                                  // [slot][mt][h]
-#ifdef DVAE_DEBUG_SWITCHES
-    if (abl & 8) {
-#pragma unroll
-      for (int a = 0; a < 8; ++a) P[a >> 2][(a >> 1) & 1][a & 1] = f32x4{1.f, 2.f, 3.f, 4.f};
-    }
-#endif
-    auto rd = [&](int tap, int slot) {
-#ifdef DVAE_DEBUG_SWITCHES
-      if (abl & 8) return;
-#endif
-      const int kh = tap >> 2, kw = tap & 3;
-      const int tc = ((kh * 2 + (kw & 1)) * G::CW) * 32;      // row 2 sy_l + kh, parity kw & 1
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          P[slot][mt][h] = *reinterpret_cast<const f32x4*>(bt + vo[mt][h][kw >> 1][NS2 == 2 ? (kh >> 1) : 0] + tc);
-    };
-    rd(0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int cur = t & 1;
-      if (t + 1 < 16) rd(t + 1, cur ^ 1);
+      if (t + 1 < 16) rd(bt, t + 1, cur ^ 1);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -205,6 +208,8 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMAs (this tap)
     }
     if (!(abl & 16)) barrier_nofence();                // the tile is consumed (every ds_read fed an MFMA above)
+    const int nbuf = buf == 2 ? 0 : buf + 1;
+    if (unit + stride < n_units) rd(smem + nbuf * D::BUF_FLOATS, 0, 0);     // tile(unit + stride) landed before that barrier
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const f32x4 a = (acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]);
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(512) void k_down32dma(const float* __restrict__ big
       }
       if (!(abl & 1)) *reinterpret_cast<f32x4*>(out + obase + mt * 512) = o;
     }
-    buf = buf == 2 ? 0 : buf + 1;
+    buf = nbuf;
   }
 }
 
