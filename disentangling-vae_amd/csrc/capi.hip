@@ -400,6 +400,8 @@ int dvae_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, void* stream) {
   DVAE_CHECK_ARG(a->D >= 1 && a->D <= DVAE_MAX_D && a->n_enc > 0 && a->n_enc <= 8 * DVAE_KL_MAX_BLOCKS);
   DVAE_CHECK_ARG(a->n_kl >= 0 && a->n_kl <= a->n_enc && a->n_dec >= 0 && a->n_dec <= a->n_enc);
   if (a->n_dec > 0) DVAE_CHECK_ARG(a->w_d1 && a->w_d2 && a->w_d3 && a->b_d1 && a->b_d2 && a->b_d3 && a->d1 && a->d2 && a->d3);
+  if (a->conv_in) DVAE_CHECK_ARG(a->conv_w && a->conv_b && ((((uintptr_t)a->conv_in | (uintptr_t)a->conv_w) & 15) == 0));
+  if (a->convT_w) DVAE_CHECK_ARG(a->conv_in && a->convT_b && a->convT_out && a->n_dec > 0 && (((uintptr_t)a->convT_w & 15) == 0));
   return launch_fc_chain_fwd(a, (hipStream_t)stream);
 }
 
@@ -410,6 +412,8 @@ int dvae_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, void* stream) {
   DVAE_CHECK_ARG(a->d2 && a->d1 && a->h2 && a->h1 && a->a_flat && a->mu && a->logvar && a->scal && a->coef);
   DVAE_CHECK_ARG(a->gd2 && a->gd1 && a->dml && a->gh2 && a->gh1 && a->ga_flat);
   DVAE_CHECK_ARG(a->D >= 1 && a->D <= DVAE_MAX_D && a->n > 0);
+  if (a->convT_gout) DVAE_CHECK_ARG(a->convT_w && a->d3 && ((((uintptr_t)a->convT_gout | (uintptr_t)a->convT_w) & 15) == 0));
+  if (a->conv_w) DVAE_CHECK_ARG(a->convT_gout && a->conv_act && a->conv_gin && (((uintptr_t)a->conv_w & 15) == 0));
   return launch_fc_chain_bwd(a, (hipStream_t)stream);
 }
 

@@ -38,6 +38,18 @@ namespace dvae {
 
 __device__ __forceinline__ float sigmoid_hw_mm(float v) { return sigmoid_aten(v); }
 
+// experiment switches of variant builds (tools/build_variant.sh; the shipped library is built with the defaults below)
+#ifndef UTM_VARIANT      // 1: next tile requested before the matrix phase, 2: targets requested before the matrix phase,
+#define UTM_VARIANT 13   // 4: LDS-only barriers (global loads / stores stay in flight across them)
+#endif
+#ifndef UTM_ABL          // timing ablations (results invalid): 1 no MFMAs, 2 no likelihood arithmetic, 4 no target loads,
+#define UTM_ABL 0        // 8 no output stores, 16 no tile loads
+#endif
+__device__ __forceinline__ void utm_barrier() {
+  if (UTM_VARIANT & 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+
 // DIST: the reconstruction distribution (FUSE) as a compile-time constant -- with a run-time code the compiler evaluates all
 // three likelihoods per output and selects (measured: 1360 vector instructions per unit and wave instead of ~500).
 // TT: target type, float or uint8_t pixels (ToTensor's x / 255 on the fly, as the other image-reading kernels do).
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(512, 4) void k_up_thin_mm(const float* __restrict__
     for (int k = 0; k < 6; ++k) {
       const int sy = sy0 + 2 * k + rhalf;
       pf[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (sy >= 0 && sy < 32) pf[k] = *reinterpret_cast<const f32x4*>(base + 2048 * k);
+      if (sy >= 0 && sy < 32 && !((UTM_ABL & 16) && N > 0)) pf[k] = *reinterpret_cast<const f32x4*>(base + 2048 * k);
     }
   };
   if ((int)blockIdx.x < n_units) load_tile(blockIdx.x);
@@ -133,13 +145,22 @@ __global__ __launch_bounds__(512, 4) void k_up_thin_mm(const float* __restrict__
     // ---- targets of the second phase: requested now
     f32x4 tg[3];
     uchar4 tg8[3];
+    auto load_targets_k = [&](int k) {
+      const int Y = Y0 + brow[k];
+      tg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tg8[k] = make_uchar4(0, 0, 0, 0);
+      if (Y >= 0 && Y < 64) {
+        if constexpr (sizeof(TT) == 4) tg[k] = *reinterpret_cast<const f32x4*>(target + img0 + bgo[k]);
+        else tg8[k] = *reinterpret_cast<const uchar4*>(target + img0 + bgo[k]);
+      }
+    };
     auto load_targets = [&]() {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int Y = Y0 + brow[k];
         tg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         tg8[k] = make_uchar4(0, 0, 0, 0);
-        if (Y >= 0 && Y < 64) {
+        if (Y >= 0 && Y < 64 && !((UTM_ABL & 4) && N > 0)) {
           if constexpr (sizeof(TT) == 4) tg[k] = *reinterpret_cast<const f32x4*>(target + img0 + bgo[k]);
           else tg8[k] = *reinterpret_cast<const uchar4*>(target + img0 + bgo[k]);
         }
@@ -148,7 +169,10 @@ __global__ __launch_bounds__(512, 4) void k_up_thin_mm(const float* __restrict__
     // ---- tile in: registers -> swizzled LDS (rows outside the image: zeros)
 #pragma unroll
     for (int k = 0; k < 6; ++k) *reinterpret_cast<f32x4*>(tin + plo + 2 * UTM_COLS * 32 * k) = pf[k];
-    __syncthreads();                                      // the tile is complete; the stage is free (second phase of the last unit)
+    if ((UTM_VARIANT & 1) && unit + (int)gridDim.x < n_units) load_tile(unit + gridDim.x);
+    if (FUSE && (UTM_VARIANT & 2)) load_targets();
+    if (FUSE && (UTM_VARIANT & 16)) load_targets_k(0);
+    utm_barrier();                                        // the tile is complete; the stage is free (second phase of the last unit)
     // ---- matrix phase
     f32x4 acc[3];
 #pragma unroll
@@ -173,10 +197,12 @@ __global__ __launch_bounds__(512, 4) void k_up_thin_mm(const float* __restrict__
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           if (s == 2 && !tile3) continue;
-          acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i], x[s][i >> 2][i & 3], acc[s], 0, 0, 0);
+          if (!((UTM_ABL & 1) && N > 0)) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[i], x[s][i >> 2][i & 3], acc[s], 0, 0, 0);
         }
       }
     }
+    if (FUSE && (UTM_VARIANT & 8)) load_targets();        // (variant: requested behind the last MFMA, in front of the stage hand-over)
+    if (FUSE && (UTM_VARIANT & 16)) { load_targets_k(1); load_targets_k(2); }
     // ---- D fragment -> stage: lane (j, kg < 3) holds the 2 x 2 block of channel kg at its position
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -185,11 +211,11 @@ __global__ __launch_bounds__(512, 4) void k_up_thin_mm(const float* __restrict__
       if (x0ok[s]) { sp[0] = acc[s][0] + bv; sp[64] = acc[s][2] + bv; }
       if (x1ok[s]) { sp[1] = acc[s][1] + bv; sp[65] = acc[s][3] + bv; }
     }
-    __syncthreads();                                      // the stage is complete; the tile may be overwritten
+    utm_barrier();                                        // the stage is complete; the tile may be overwritten
     // ---- the next unit's tile: in flight during the second phase
-    if (unit + (int)gridDim.x < n_units) load_tile(unit + gridDim.x);
+    if (!(UTM_VARIANT & 1) && unit + (int)gridDim.x < n_units) load_tile(unit + gridDim.x);
     // ---- second phase: rows of the stage, 16 bytes per access, every lane busy
-    if (FUSE) load_targets();
+    if (FUSE && !(UTM_VARIANT & (2 | 8 | 16))) load_targets();
     if (FUSE && sizeof(TT) != 4) {
 #pragma unroll
       for (int k = 0; k < 3; ++k)     // ToTensor
@@ -203,7 +229,9 @@ __global__ __launch_bounds__(512, 4) void k_up_thin_mm(const float* __restrict__
       f32x4 gl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (FUSE && DIST == DVAE_REC_BERNOULLI) {
+        if ((UTM_ABL & 2) && N > 0) {
+          gl[q] = v[q] + tg[k][q];
+        } else if (FUSE && DIST == DVAE_REC_BERNOULLI) {
           float y, glq;
           lsum += sigmoid_bce_logit(v[q], tg[k][q], &y, &glq);
           v[q] = y;
@@ -218,6 +246,7 @@ __global__ __launch_bounds__(512, 4) void k_up_thin_mm(const float* __restrict__
           }
         }
       }
+      if ((UTM_ABL & 8) && N > 0) { lsum += v[0] + v[1] + v[2] + v[3] + gl[0] + gl[1] + gl[2] + gl[3]; continue; }
       *reinterpret_cast<f32x4*>(out + img0 + bgo[k]) = v;
       if (FUSE) *reinterpret_cast<f32x4*>(g + img0 + bgo[k]) = gl;
     }

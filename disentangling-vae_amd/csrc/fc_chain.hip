@@ -21,7 +21,17 @@
 // takes 24-28 us at any batch size up to 2048 rows (256 workgroups), against 50 / 67 us for the 7 + 7 launches it replaces
 // at 128 rows.  Fewer rows per workgroup would only move the bound from the matrix core to the weight stream.
 // Exact fp32 (k-ordered fmaf chains per accumulator; two accumulators per output, even / odd steps, summed at the end).
+//
+// Round 6, CONV = true: the 4x4 end of the conv stacks inside the same launches.  The 4 (8) batch rows of a workgroup ARE whole
+// images, and conv_64's output IS the chain's first input row (encoders.py:76-81), lin3's output IS convT_64's input
+// (decoders.py:73-75) -- and the mirror of both in the backward pass.  As launches of their own those four layers (k_down32<4> /
+// k_up32<4>, 0.5 GFLOP each) cost 8-12 us apiece at ANY batch size, 10-80 us inside a step where they queue behind the other
+// stream's chip-filling kernels (profiles/r06_final1_timeline*.md).  Here a workgroup runs conv4_end.h's unit bodies (the
+// arithmetic of those kernels, bit for bit) as prologue and epilogue of its chain: the staged 64 KB weight images arrive by
+// LDS-DMA while the chain's first ring is in flight / while the last layers multiply, and the chain's own LDS buffers overlay
+// the prologue's weight image once it is consumed (150 KB of LDS in all, one workgroup per CU as before).
 #include "common.h"
+#include "conv4_end.h"
 
 namespace dvae {
 
@@ -213,6 +223,27 @@ struct Lane {
   }
 };
 
+// LDS plan (floats inside the dynamic allocation).  Plain chain: the buffers below, one after the other.  CONV: region A =
+// [0, 16384) is the prologue's weight image and THEN the same buffers (the image is dead once the prologue's matrix phase is
+// over); region B = [16384, +20992) is the prologue's big tile + cross-wave reduction buffer and THEN the epilogue's weight
+// image + small tile; the L2 warm-up sink follows.
+template <int KS, int RG, bool CONV>
+struct ChainLds {
+  static constexpr int R = 4 * RG, NWV = 4 * KS;
+  static constexpr int TA = 0;
+  static constexpr int PART = TA + R * FCC_XS;
+  static constexpr int TB = PART + (KS == 2 ? R * FCC_HID : 4);
+  static constexpr int RED = TB + R * FCC_XS;                  // [NWV][R][64]
+  static constexpr int MLT = RED + NWV * R * 64;               // [R][64]
+  static constexpr int END = MLT + R * 64;
+  static constexpr int WL = 0;                                 // prologue: "down" image
+  static constexpr int BT = C4_WL_FLOATS, RD = BT + C4_BT_FLOATS;           // prologue: big tile, reduction buffer
+  static constexpr int WL2 = C4_WL_FLOATS, ST = WL2 + C4_WL_FLOATS;         // epilogue: "up" image, small tile
+  static constexpr int SINK = CONV ? RD + C4_RED_FLOATS : END;
+  static constexpr int TOTAL = SINK + 256;
+  static_assert(!CONV || (END <= C4_WL_FLOATS && ST + C4_ST_FLOATS <= SINK), "the chain's buffers overlay the prologue's image");
+};
+
 // 256-wide layer, contraction of NCH chunks: complete sums in v[] of the waves with kh == 0 (one workgroup barrier inside
 // when KS == 2).  wp = this layer's image + col * 4; tile = activation tile.  The next layer's first chunks are requested
 // into nring from wn (already offset for this wave) while the last DEPTH chunks are consumed.
@@ -247,19 +278,22 @@ __device__ __forceinline__ void fill256(const Lane<KS>& L, Ring<DEPTH, 1>& ring,
 }
 
 // ---------------------------------------------------------------------------------------------- forward
-template <int DEPTH, int KS, int RG>
+template <int DEPTH, int KS, int RG, bool CONV>
 __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
   const dvae_fc_chain_fwd_args& a = P.a;
   constexpr int R = 4 * RG;                         // batch rows per workgroup
   constexpr int NT = 256 * KS, NWV = 4 * KS;
   constexpr int SD = 64 / NWV;                      // chunks per wave of a layer whose contraction is split over ALL waves
   constexpr int G512 = KS == 2 ? 1 : 2;             // 256-column halves of a 512-wide layer per wave
-  __shared__ __attribute__((aligned(16))) float tA[R * FCC_XS];
-  __shared__ __attribute__((aligned(16))) float tB[R * FCC_XS];
-  __shared__ float red[NWV][R][64];
-  __shared__ float mlt[R][64];
-  __shared__ float part[KS == 2 ? R * FCC_HID : 1];
-  __shared__ __attribute__((aligned(16))) float warm_sink[256];
+  using LD = ChainLds<KS, RG, CONV>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tA = smem + LD::TA;
+  float* tB = smem + LD::TB;
+  float* red = smem + LD::RED;                      // [NWV][R][64]
+  float* mlt = smem + LD::MLT;                      // [R][64]
+  float* part = smem + LD::PART;
+  float* warm_sink = smem + LD::SINK;
+  static_assert(!CONV || KS == 2, "the conv ends are 512-thread bodies");
   const Lane<KS> L;
   const int tid = L.tid, lane = L.lane, wv = L.wv, col = L.col, xo = L.xo;
   const bool own = L.kh == 0;                       // this wave finishes the 256-wide layers (bias, activation, stores)
@@ -278,9 +312,41 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
     l2_warm(a.w_d2, FCC_HID * FCC_HID, sh, nsh, wv, NWV, lane, sink);
     l2_warm(a.w_d3, FCC_HID * FCC_FLAT, sh, nsh, wv, NWV, lane, sink);
   }
-  load_rows<FCC_FLAT, NT, R>(a.a_flat, row0, a.n_enc, tA, tid);
+  const bool dec = row0 < a.n_dec;                  // workgroup-uniform
+  if constexpr (CONV) {
+    // ---- conv_64 (encoders.py:76-80): unit u of this workgroup = images row0 + 4 u .. + 3 -> a_flat (global: the backward pass
+    // reads it) and, with one unit per workgroup, straight into the chain's input tile
+    SlotDesc<Geo<4>::BIG_NPF> sd;
+    init_big_slots<4>(sd, tid);
+    f32x4 pf[Geo<4>::BIG_NPF];
+    load_big<4>(pf, sd, a.conv_in, blockIdx.x * RG, a.n_enc);
+    c4_weight_image_issue(a.conv_w, smem + LD::WL, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the barrier inside the unit publishes the image)
+    float* a_out = const_cast<float*>(a.a_flat);
+#pragma unroll
+    for (int u = 0; u < RG; ++u) {
+      if (u > 0) load_big<4>(pf, sd, a.conv_in, blockIdx.x * RG + u, a.n_enc);
+      // (RG == 2: the tile would overlay the image the second unit still multiplies with -- its rows come back from a_flat below)
+      c4_down_unit<false, RG == 1>(a.conv_in, a.conv_b, nullptr, a_out, tA, FCC_XS, a.n_enc, DVAE_ACT_RELU, blockIdx.x * RG + u,
+                                   smem + LD::WL, smem + LD::BT, smem + LD::RD, pf, sd);
+    }
+    if (RG != 1) {
+      __syncthreads();
+      load_rows<FCC_FLAT, NT, R>(a.a_flat, row0, a.n_enc, tA, tid);
+    }
+  } else {
+    load_rows<FCC_FLAT, NT, R>(a.a_flat, row0, a.n_enc, tA, tid);
+  }
   const float be1 = a.b_e1[col], be2 = a.b_e2[col];
   __syncthreads();
+  if constexpr (CONV) {
+    // convT_64's "up" image: region B is free now (the prologue's last reads were in front of that barrier)
+    if (dec && a.convT_w) {
+      c4_weight_image_issue(a.convT_w, smem + LD::WL2, tid);
+      if (RG == 1)     // one unit per workgroup: lin3's outputs go straight into the epilogue's small tile; its halo is zero
+        for (int e = tid; e < C4_ST_FLOATS / 4; e += NT) reinterpret_cast<f32x4*>(smem + LD::ST)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 
   float v[R];
   // ---- encoder lin1: 512 -> 256, ReLU
@@ -316,26 +382,25 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
     gemm_run<SD, SD, 1, 0, 0, RG>(rml, wml, 0, D2 * 4, tA + xo + wv * SD * 4, acc, dummy_s, nullptr, 0, 0);
     acc_rows(acc[0], v);
 #pragma unroll
-    for (int r = 0; r < R; ++r) red[wv][r][lane] = v[r];
+    for (int r = 0; r < R; ++r) red[((wv) * R + (r)) * 64 + (lane)] = v[r];
   }
   // the decoder's second weight stream does not depend on anything computed here: request it now
   Ring<DEPTH, 1> rd2;
-  const bool dec = row0 < a.n_dec;                  // workgroup-uniform
   if (dec) fill256<DEPTH, KS, 64>(L, rd2, a.w_d2 + col * 4, CS);
   __syncthreads();
   for (int t = tid; t < R * D2; t += NT) {
     const int r = t / D2, j = t % D2;
-    float m = red[0][r][j];
+    float m = red[((0) * R + (r)) * 64 + (j)];
 #pragma unroll
-    for (int w = 1; w < NWV; ++w) m += red[w][r][j];
+    for (int w = 1; w < NWV; ++w) m += red[((w) * R + (r)) * 64 + (j)];
     m += a.b_ml[j];
-    mlt[r][j] = m;
+    mlt[(r) * 64 + (j)] = m;
     if (row0 + r < a.n_enc) a.ml[(long)(row0 + r) * D2 + j] = m;
   }
   __syncthreads();
   // ---- reparameterise (vae.py:66-68) + per-dim KL terms (losses.py:470); z -> tB (zero padded to a multiple of 4 columns)
   {
-    float* klt = &red[0][0][0];                     // [R][16]
+    float* klt = red;                     // [R][16]
     const int dp = (D + 3) & ~3;
     for (int t = tid; t < R * 16; t += NT) {
       const int r = t >> 4, d = t & 15;
@@ -343,7 +408,7 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
       if (d < dp) {
         float zz = 0.f;
         if (d < D) {
-          const float m = mlt[r][2 * d], lv = mlt[r][2 * d + 1];
+          const float m = mlt[(r) * 64 + (2 * d)], lv = mlt[(r) * 64 + (2 * d + 1)];
           zz = m;
           const long o = (long)(row0 + r) * D + d;
           if (row0 + r < a.n_enc) {
@@ -405,25 +470,53 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
       const float b = a.b_d3[c512];
       acc_rows(acc[g], v);
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (row0 + r < a.n_dec) a.d3[(long)(row0 + r) * FCC_FLAT + c512] = fmaxf(v[r] + b, 0.f);
+      for (int r = 0; r < R; ++r) {
+        const float y = fmaxf(v[r] + b, 0.f);
+        if (row0 + r < a.n_dec) a.d3[(long)(row0 + r) * FCC_FLAT + c512] = y;
+        if (CONV && RG == 1) smem[LD::ST + c4_st_index(r, c512 >> 4, c512 & 15)] = y;
+      }
+    }
+  }
+  if constexpr (CONV) {
+    // ---- convT_64 (decoders.py:74-76): this workgroup's rows of d3 = the 4x4x32 inputs of its images -> [n_dec][8][8][32], ReLU
+    if (!a.convT_w) return;
+    __syncthreads();                                 // d3 is visible to the workgroup; the "up" image has landed (vmcnt(0))
+    if constexpr (RG == 1) {
+      c4_up_unit<false>(smem + LD::ST, smem + LD::WL2, a.convT_b, nullptr, a.convT_out, a.n_dec, DVAE_ACT_RELU, blockIdx.x);
+      return;
+    }
+    SlotDesc<Geo<4>::SH_NPF> ss;
+    init_small_slots<4>(ss, tid, 1);
+    f32x4 ps[Geo<4>::SH_NPF];
+#pragma unroll
+    for (int u = 0; u < RG; ++u) {
+      const int unit = blockIdx.x * RG + u;
+      if (unit * 4 >= a.n_dec) break;                // (workgroup-uniform)
+      load_small_halo<4>(ps, ss, a.d3, unit, a.n_dec, 1);
+      if (u > 0) __syncthreads();                    // the previous unit's reads of the tile
+      store_small_halo<4>(ps, ss, smem + LD::ST);
+      __syncthreads();
+      c4_up_unit<false>(smem + LD::ST, smem + LD::WL2, a.convT_b, nullptr, a.convT_out, a.n_dec, DVAE_ACT_RELU, unit);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-template <int DEPTH, int KS, int RG>
+template <int DEPTH, int KS, int RG, bool CONV>
 __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   const dvae_fc_chain_bwd_args& a = P.a;
   constexpr int R = 4 * RG;
   constexpr int NT = 256 * KS, NWV = 4 * KS;
   constexpr int SD = 64 / NWV;
   constexpr int G512 = KS == 2 ? 1 : 2;
-  __shared__ __attribute__((aligned(16))) float tA[R * FCC_XS];
-  __shared__ __attribute__((aligned(16))) float tB[R * FCC_XS];
-  __shared__ float red[NWV][R][64];
-  __shared__ float part[KS == 2 ? R * FCC_HID : 1];
-  __shared__ __attribute__((aligned(16))) float warm_sink[256];
+  using LD = ChainLds<KS, RG, CONV>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tA = smem + LD::TA;
+  float* tB = smem + LD::TB;
+  float* red = smem + LD::RED;                      // [NWV][R][64]
+  float* part = smem + LD::PART;
+  float* warm_sink = smem + LD::SINK;
+  static_assert(!CONV || KS == 2, "the conv ends are 512-thread bodies");
   const Lane<KS> L;
   const int tid = L.tid, lane = L.lane, wv = L.wv, col = L.col, xo = L.xo;
   const bool own = L.kh == 0;
@@ -443,7 +536,29 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
     l2_warm(a.w_e2, FCC_HID * FCC_HID, sh, nsh, wv, NWV, lane, sink);
     l2_warm(a.w_e1, FCC_FLAT * FCC_HID, sh, nsh, wv, NWV, lane, sink);
   }
-  load_rows<FCC_FLAT, NT, R>(a.gd3, row0, n, tA, tid);
+  if constexpr (CONV) {
+    // ---- convT_64's input gradient (decoders.py:74-76 under training.py:157), masked by lin3's ReLU (d3): unit u = images
+    // row0 + 4 u .. + 3 -> gd3 (global: lin3's weight gradient reads it) and, with one unit per workgroup, the chain's input tile
+    SlotDesc<Geo<4>::BIG_NPF> sd;
+    init_big_slots<4>(sd, tid);
+    f32x4 pf[Geo<4>::BIG_NPF];
+    load_big<4>(pf, sd, a.convT_gout, blockIdx.x * RG, n);
+    c4_weight_image_issue(a.convT_w, smem + LD::WL, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* g_out = const_cast<float*>(a.gd3);
+#pragma unroll
+    for (int u = 0; u < RG; ++u) {
+      if (u > 0) load_big<4>(pf, sd, a.convT_gout, blockIdx.x * RG + u, n);
+      c4_down_unit<true, RG == 1>(a.convT_gout, nullptr, a.d3, g_out, tA, FCC_XS, n, DVAE_ACT_NONE, blockIdx.x * RG + u,
+                                  smem + LD::WL, smem + LD::BT, smem + LD::RD, pf, sd);
+    }
+    if (RG != 1) {
+      __syncthreads();
+      load_rows<FCC_FLAT, NT, R>(a.gd3, row0, n, tA, tid);
+    }
+  } else {
+    load_rows<FCC_FLAT, NT, R>(a.gd3, row0, n, tA, tid);
+  }
   float mk[R], v[R];
   // ReLU mask of a 256-wide layer = its saved post-activation output (zero rows beyond n: their gradients are not stored)
   auto load_mask = [&](const float* __restrict__ act) {
@@ -454,6 +569,13 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
   };
   load_mask(a.d2);
   __syncthreads();
+  if constexpr (CONV) {
+    if (a.conv_w) {                                   // conv_64's "up" image: region B is free now
+      c4_weight_image_issue(a.conv_w, smem + LD::WL2, tid);
+      if (RG == 1)
+        for (int e = tid; e < C4_ST_FLOATS / 4; e += NT) reinterpret_cast<f32x4*>(smem + LD::ST)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   // ---- decoder lin3 input gradient: 512 -> 256, mask d2
   layer256<DEPTH, KS, 128, 64 / KS, 1, RG>(L, r3, a.w_d3 + col * 4, CS, tA, r2, a.w_d2 + col * 4 + (long)L.kh * (64 / KS) * CS, 0, CS, part, v);
   if (own) {
@@ -488,7 +610,7 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
     gemm_run<SD, SD, 1, 0, 0, RG>(r1, w1, 0, D * 4, tA + xo + wv * SD * 4, acc, dummy_s, nullptr, 0, 0);
     acc_rows(acc[0], v);
 #pragma unroll
-    for (int r = 0; r < R; ++r) red[wv][r][lane] = v[r];
+    for (int r = 0; r < R; ++r) red[((wv) * R + (r)) * 64 + (lane)] = v[r];
   }
   fill256<DEPTH, KS, 64>(L, re2, a.w_e2 + col * 4, CS);   // encoder lin2's stream: independent of the latent glue below
   load_mask(a.h2);
@@ -503,9 +625,9 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
         float dm = 0.f, dl = 0.f;
         if (row0 + r < n) {
           const long o = (long)(row0 + r) * D + d;
-          float g = red[0][r][d];
+          float g = red[((0) * R + (r)) * 64 + (d)];
 #pragma unroll
-          for (int w = 1; w < NWV; ++w) g += red[w][r][d];
+          for (int w = 1; w < NWV; ++w) g += red[((w) * R + (r)) * 64 + (d)];
           if (a.dz) a.dz[o] = g;
           if (a.dz2) g += a.dz2[o];
           if (a.dz3) g += a.dz3[o];
@@ -575,8 +697,33 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
       const int c512 = col + (KS == 2 ? half : g) * FCC_HID;
       acc_rows(acc[g], v);
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (row0 + r < n) a.ga_flat[(long)(row0 + r) * FCC_FLAT + c512] = mk2[g][r] > 0.f ? v[r] : 0.f;
+      for (int r = 0; r < R; ++r) {
+        const float y = mk2[g][r] > 0.f ? v[r] : 0.f;
+        if (row0 + r < n) a.ga_flat[(long)(row0 + r) * FCC_FLAT + c512] = y;
+        if (CONV && RG == 1) smem[LD::ST + c4_st_index(r, c512 >> 4, c512 & 15)] = y;
+      }
+    }
+  }
+  if constexpr (CONV) {
+    // ---- conv_64's input gradient (encoders.py:76-77 under training.py:157), masked by conv3's ReLU: ga_flat rows -> [n][8][8][32]
+    if (!a.conv_w) return;
+    __syncthreads();                                 // ga_flat is visible to the workgroup; the "up" image has landed (vmcnt(0))
+    if constexpr (RG == 1) {
+      c4_up_unit<true>(smem + LD::ST, smem + LD::WL2, nullptr, a.conv_act, a.conv_gin, n, DVAE_ACT_NONE, blockIdx.x);
+      return;
+    }
+    SlotDesc<Geo<4>::SH_NPF> ss;
+    init_small_slots<4>(ss, tid, 1);
+    f32x4 ps[Geo<4>::SH_NPF];
+#pragma unroll
+    for (int u = 0; u < RG; ++u) {
+      const int unit = blockIdx.x * RG + u;
+      if (unit * 4 >= n) break;                      // (workgroup-uniform)
+      load_small_halo<4>(ps, ss, a.ga_flat, unit, n, 1);
+      if (u > 0) __syncthreads();
+      store_small_halo<4>(ps, ss, smem + LD::ST);
+      __syncthreads();
+      c4_up_unit<true>(smem + LD::ST, smem + LD::WL2, nullptr, a.conv_act, a.conv_gin, n, DVAE_ACT_NONE, unit);
     }
   }
 }
@@ -605,11 +752,35 @@ int fc_chain_rows(int n) {
 
 template <int DEPTH, int KS, int RG>
 static void launch_fwd_t(const FwdArgs& P, hipStream_t s) {
-  hipLaunchKernelGGL((k_fc_chain_fwd<DEPTH, KS, RG>), dim3((P.a.n_enc + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), 0, s, P);
+  if (P.a.conv_in) {
+    if constexpr (KS != 2) abort();                   // (debug-build variants with 256 threads: no conv ends)
+    if constexpr (KS == 2) {
+      constexpr int lds = ChainLds<KS, RG, true>::TOTAL * (int)sizeof(float);
+      static DeviceOnce attr;
+      if (attr.first())
+        (void)hipFuncSetAttribute((const void*)k_fc_chain_fwd<DEPTH, KS, RG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((k_fc_chain_fwd<DEPTH, KS, RG, true>), dim3((P.a.n_enc + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), lds, s, P);
+      return;
+    }
+  }
+  constexpr int lds = ChainLds<KS, RG, false>::TOTAL * (int)sizeof(float);
+  hipLaunchKernelGGL((k_fc_chain_fwd<DEPTH, KS, RG, false>), dim3((P.a.n_enc + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), lds, s, P);
 }
 template <int DEPTH, int KS, int RG>
 static void launch_bwd_t(const BwdArgs& P, hipStream_t s) {
-  hipLaunchKernelGGL((k_fc_chain_bwd<DEPTH, KS, RG>), dim3((P.a.n + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), 0, s, P);
+  if (P.a.convT_gout) {
+    if constexpr (KS != 2) abort();
+    if constexpr (KS == 2) {
+      constexpr int lds = ChainLds<KS, RG, true>::TOTAL * (int)sizeof(float);
+      static DeviceOnce attr;
+      if (attr.first())
+        (void)hipFuncSetAttribute((const void*)k_fc_chain_bwd<DEPTH, KS, RG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((k_fc_chain_bwd<DEPTH, KS, RG, true>), dim3((P.a.n + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), lds, s, P);
+      return;
+    }
+  }
+  constexpr int lds = ChainLds<KS, RG, false>::TOTAL * (int)sizeof(float);
+  hipLaunchKernelGGL((k_fc_chain_bwd<DEPTH, KS, RG, false>), dim3((P.a.n + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), lds, s, P);
 }
 
 int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s) {

@@ -171,14 +171,16 @@ class FcChainFwdArgs(ctypes.Structure):
     """dvae_fc_chain_fwd_args (include/dvae_hip.h)."""
     _fields_ = [(n_, _p) for n_ in ("a_flat", "w_e1", "w_e2", "w_ml", "w_d1", "w_d2", "w_d3", "b_e1", "b_e2", "b_ml",
                                     "b_d1", "b_d2", "b_d3", "eps", "h1", "h2", "ml", "mu", "logvar", "z", "kl_part",
-                                    "d1", "d2", "d3")] + [(n_, _i) for n_ in ("n_enc", "n_kl", "n_dec", "D")]
+                                    "d1", "d2", "d3")] + [(n_, _i) for n_ in ("n_enc", "n_kl", "n_dec", "D")] + \
+               [(n_, _p) for n_ in ("conv_in", "conv_w", "conv_b", "convT_w", "convT_b", "convT_out")]
 
 
 class FcChainBwdArgs(ctypes.Structure):
     """dvae_fc_chain_bwd_args (include/dvae_hip.h)."""
     _fields_ = [(n_, _p) for n_ in ("gd3", "w_d3", "w_d2", "w_d1", "w_ml", "w_e2", "w_e1", "d2", "d1", "h2", "h1",
                                     "a_flat", "mu", "logvar", "eps", "dz2", "dz3", "dmu_x", "dlv_x", "scal", "coef",
-                                    "gd2", "gd1", "dz", "dml", "gh2", "gh1", "ga_flat")] + [("n", _i), ("D", _i)]
+                                    "gd2", "gd1", "dz", "dml", "gh2", "gh1", "ga_flat")] + [("n", _i), ("D", _i)] + \
+               [(n_, _p) for n_ in ("convT_gout", "convT_w", "d3", "conv_w", "conv_act", "conv_gin")]
 
 
 def struct_of(cls, **kw):

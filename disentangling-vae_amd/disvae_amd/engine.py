@@ -264,6 +264,16 @@ class VAEEngine:
         # 64x64 images with 1 / 3 channels: the forward kernels of conv1 and convT2 also emit the sign bits of their outputs and
         # the input-gradient kernels of conv2 and convT3 read those instead of the 32x32x32 fp32 activations (dvae_*_bits)
         self.mask_bits = self.is64 and c in (1, 3) and knob("DVAE_MASK_BITS", "1") != "0"   # (A/B knob: DVAE_DEBUG=1 only)
+        # 64x64 geometry, fused FC chain: conv_64 / convT_64 and their input gradients run INSIDE the chain launches
+        # (dvae_fc_chain_fwd / _bwd, conv_in / convT_gout fields: csrc/conv4_end.h) -- four launches fewer on the critical path
+        # Up to fuse_ends_max_rows rows per launch, where the step is a chain of dependent launches and each one saved counts
+        # (same box, three alternations, profiles/r06_s2_chain3.txt: factor 64x64x1 tensor 256 0.590 -> 0.569 ms, btcvae 64x64x3 at
+        # 64 / 128 / 256 images 0.311 -> 0.302, 0.347 -> 0.344, 0.450 -> 0.447 ms); from 512 rows up the fused launches -- 150 KB
+        # of LDS, a whole CU per workgroup -- can no longer slip in beside the other stream's persistent kernels the way the
+        # small conv launches do: 0.643 -> 0.652 ms at 512 images, 1.060 -> 1.082 ms at 1024 (profiles/r06_s2_chain2.txt)
+        self.fuse_ends = self.is64 and not _lib.wide(latent_dim) and knob("DVAE_FUSE_ENDS", "1") != "0"   # (A/B knob: DVAE_DEBUG=1 only)
+        self.fuse_ends_max_rows = int(knob("DVAE_FUSE_ENDS_MAX_ROWS", "256"))
+        self._ends_on = False  # this forward pass: set by encode_convs(chain=True), read by fc_chain_fwd / decode_convs
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
         self._fc_descs = {}    # host descriptor arrays / argument structs of launches, kept alive for recorded plans
         self._images = None
@@ -426,15 +436,19 @@ class VAEEngine:
         return buf.x_f32
 
     # ------------------------------------------------------------------ forward
-    def encode_convs(self, x, buf, n=None):
+    def encode_convs(self, x, buf, n=None, chain=False):
         """x[B,C,H,W] (NCHW; fp32, or uint8 for the fused geometry: see input()) -> buf.a_flat[B,512]: the conv stack of
-        encoders.py:73-80.  The 32-channel layers read their pre-staged weight images (stage() must precede)."""
+        encoders.py:73-80.  The 32-channel layers read their pre-staged weight images (stage() must precede).
+        chain: fc_chain_fwd follows -- with fuse_ends it computes conv_64 itself, the stack stops at conv3's output."""
         s = _stream()
         B = x.shape[0] if n is None else n
         c, H, _ = self.img_size
         src, h = x, H
         last = len(self.enc_names) - 1
+        self._ends_on = chain and self._ends(B)
         for k, (name, act) in enumerate(zip(self.enc_names, buf.enc_act)):
+            if self._ends_on and k == last:
+                break
             # the last conv writes its 4x4x32 output NCHW = the (c,h,w) flatten order lin1 consumes
             # (encoders.py:80), straight into a_flat: no relayout pass; no conv kernel reads that tensor
             dst, dst_layout = (buf.a_flat, NCHW) if k == last else (act, NHWC)
@@ -494,7 +508,7 @@ class VAEEngine:
         if n_enc > _lib.FC_CHAIN_MAX_ROWS:
             raise _lib.DvaeHipError("fc_chain_fwd: at most %d rows per launch" % _lib.FC_CHAIN_MAX_ROWS)
         P, I = self.p, self._img
-        addr = self._args(("fcf", id(buf), ptr(eps), ptr(kl_dim), n_enc, n_kl, n_dec, self._images.buf.data_ptr()),
+        addr = self._args(("fcf", id(buf), ptr(eps), ptr(kl_dim), n_enc, n_kl, n_dec, self._images.buf.data_ptr(), self._ends_on),
                           _lib.FcChainFwdArgs, a_flat=ptr(buf.a_flat),
                           w_e1=I("encoder.lin1", "fwd"), w_e2=I("encoder.lin2", "fwd"), w_ml=I("encoder.mu_logvar_gen", "fwd"),
                           w_d1=I("decoder.lin1", "fwd"), w_d2=I("decoder.lin2", "fwd"), w_d3=I("decoder.lin3", "fwd"),
@@ -503,8 +517,22 @@ class VAEEngine:
                           b_d2=ptr(P("decoder.lin2.bias")), b_d3=ptr(P("decoder.lin3.bias")), eps=ptr(eps),
                           h1=ptr(buf.h1), h2=ptr(buf.h2), ml=ptr(buf.ml), mu=ptr(buf.mu), logvar=ptr(buf.logvar), z=ptr(buf.z),
                           kl_part=None if kl_dim is None else ptr(kl_dim) + 64, d1=ptr(buf.d1), d2=ptr(buf.d2), d3=ptr(buf.d3),
-                          n_enc=n_enc, n_kl=n_kl, n_dec=n_dec, D=self.latent_dim)
+                          n_enc=n_enc, n_kl=n_kl, n_dec=n_dec, D=self.latent_dim, **self._ends_fwd(buf, n_dec))
         call("dvae_fc_chain_fwd", addr, _stream())
+
+    def _ends(self, rows):
+        """Do the chain launches over `rows` rows carry the 4x4 conv ends?"""
+        return self.fuse_ends and rows <= self.fuse_ends_max_rows
+
+    def _ends_fwd(self, buf, n_dec):
+        """dvae_fc_chain_fwd_args' conv_in .. convT_out: conv_64 in front of the chain, convT_64 behind it (fuse_ends)."""
+        if not self._ends_on:
+            return {}
+        P, I = self.p, self._img
+        d = dict(conv_in=ptr(buf.enc_act[2]), conv_w=I("encoder.conv_64", "down"), conv_b=ptr(P("encoder.conv_64.bias")))
+        if n_dec > 0:
+            d.update(convT_w=I("decoder.convT_64", "up"), convT_b=ptr(P("decoder.convT_64.bias")), convT_out=ptr(buf.dec_act[0]))
+        return d
 
     def _fc_layers_fwd(self, buf, eps, kl_dim, n_enc, n_kl, n_dec, coef):
         """fc_chain_fwd for any latent dimension: dvae_linear_fwd x 3, dvae_reparam_kl_fwd (its run-time-D form), x 3."""
@@ -564,6 +592,10 @@ class VAEEngine:
         if _lib.wide(self.latent_dim):
             return self._fc_layers_bwd(buf, eps, dz2, dz3, dmu_x, dlv_x, scal, coef, n)
         I = self._img
+        ends = {}
+        if self._ends(n):      # convT_64's input gradient in front of the chain, conv_64's behind it (dvae_fc_chain_bwd_args)
+            ends = dict(convT_gout=ptr(buf.dec_gact[0]), convT_w=I("decoder.convT_64", "down"), d3=ptr(buf.d3),
+                        conv_w=I("encoder.conv_64", "up"), conv_act=ptr(buf.enc_act[2]), conv_gin=ptr(buf.enc_gact[2]))
         addr = self._args(("fcb", id(buf), ptr(eps), ptr(dz2), ptr(dz3), ptr(dmu_x), ptr(dlv_x), ptr(scal), ptr(coef), n,
                            self._images.buf.data_ptr()),
                           _lib.FcChainBwdArgs, gd3=ptr(buf.gd3),
@@ -573,13 +605,14 @@ class VAEEngine:
                           mu=ptr(buf.mu), logvar=ptr(buf.logvar), eps=ptr(eps), dz2=ptr(dz2), dz3=ptr(dz3),
                           dmu_x=ptr(dmu_x), dlv_x=ptr(dlv_x), scal=ptr(scal), coef=ptr(coef),
                           gd2=ptr(buf.gd2), gd1=ptr(buf.gd1), dz=ptr(buf.dz), dml=ptr(buf.dml), gh2=ptr(buf.gh2),
-                          gh1=ptr(buf.gh1), ga_flat=ptr(buf.ga_flat), n=n, D=self.latent_dim)
+                          gh1=ptr(buf.gh1), ga_flat=ptr(buf.ga_flat), n=n, D=self.latent_dim, **ends)
         call("dvae_fc_chain_bwd", addr, _stream())
 
-    def decode_convs(self, buf, n, fuse_loss=None):
+    def decode_convs(self, buf, n, fuse_loss=None, chain=False):
         """buf.d3[B,512] -> buf.recon[B,C,H,W] (NCHW, post-sigmoid): the convT stack of decoders.py:74-82.
         fuse_loss = (target, dist_code, coef, partials): the last layer also evaluates the reconstruction likelihood
-        against `target` (partial sums -> partials) and writes dLoss/dlogit into buf.g_logit in the same pass."""
+        against `target` (partial sums -> partials) and writes dLoss/dlogit into buf.g_logit in the same pass.
+        chain: fc_chain_fwd preceded -- with fuse_ends it has computed convT_64 already (buf.dec_act[0])."""
         s = _stream()
         B = n
         # lin3's output [B, 32*4*4] in (c,h,w) order IS the NCHW 4x4x32 input of the first convT
@@ -587,6 +620,9 @@ class VAEEngine:
         src, src_layout, h = buf.d3, NCHW, 4
         for name, act in zip(self.dec_names, buf.dec_act):
             lname = "decoder.%s" % name
+            if chain and self._ends_on and h == 4:
+                src, src_layout, h = act, NHWC, 8
+                continue
             if self.mask_bits and h == 16:          # convT2: also emits the sign bits of its output (convT3's backward mask)
                 call("dvae_conv32_up_bits", ptr(src), self._img(lname, "up"), ptr(self.p(lname + ".bias")), None, ptr(act),
                      ptr(buf.bits_convT2), B, ACT_RELU, s)
@@ -670,7 +706,9 @@ class VAEEngine:
             # the first decoder layer's input gradient leaves NCHW = (c,h,w) order, straight into gd3 (the
             # gradient of lin3's output; ReLU mask = lin3's output d3 in the same order): no relayout pass
             out_layout = NCHW if k == 0 else NHWC
-            if couts[k] == HID:
+            if k == 0 and fc_chain is not None and self._ends(B):
+                pass                                 # convT_64's input gradient: the prologue of fc_chain_bwd
+            elif couts[k] == HID:
                 call("dvae_conv32_down", ptr(dy), self._img(lname, "down"), None, ptr(x_in), ptr(gx), out_layout, B, h,
                      ACT_NONE, s)
             elif self.mask_bits:
@@ -749,6 +787,7 @@ class VAEEngine:
               + [(buf.h2, buf.dml, self.g("encoder.mu_logvar_gen.weight"), self.g("encoder.mu_logvar_gen.bias"),
                   B, HIDDEN_DIM, 2 * self.latent_dim)])
         eager = self.eager_wgrad and not self.single_stream
+        fused_end = bool(fc_chain) and self._ends(B)        # conv_64's input gradient: fc_chain_bwd's epilogue wrote enc_gact[2]
         deferred = [lambda fc=fc: self._side_wgrad_grouped(fc)]
         tail_main = []                      # weight gradients the main stream computes after conv1's (load balance of the tail)
         last = len(self.enc_names) - 1
@@ -774,7 +813,8 @@ class VAEEngine:
                         self._conv_wgrad(*wargs, fork=False, main=True)
                     break
                 self._conv_wgrad(*wargs, fork=k < last)      # (k == last: the fork above covers it)
-                self._conv_dgrad(dy, dy_layout, lname, x_in, buf, k, B, h_in, s)
+                if not (k == last and fused_end):
+                    self._conv_dgrad(dy, dy_layout, lname, x_in, buf, k, B, h_in, s)
             self._join_side()
             return
         for k in range(last, -1, -1):
@@ -813,7 +853,7 @@ class VAEEngine:
                 side, deferred = deferred + [lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False)], []
             else:
                 deferred.append(lambda wargs=wargs: self._conv_wgrad(*wargs, fork=False))
-            if k > 0:                            # this stream's next kernel first, then the side launches
+            if k > 0 and not (k == last and fused_end):   # this stream's next kernel first, then the side launches
                 self._conv_dgrad(dy, dy_layout, lname, x_in, buf, k, B, h_in, s)
             for launch in side:
                 launch()

@@ -452,7 +452,7 @@ class _SingleOptimizerLoss(BaseLoss):
             record_py(eps.normal_)             # = torch.randn_like (vae.py:67): same Philox consumption
         if not is_train:
             eps = None
-        eng.encode_convs(data, buf)
+        eng.encode_convs(data, buf, chain=True)
         # the FC core in one launch: lin1 -> lin2 -> mu_logvar -> reparameterise (+ KL partial blocks) -> lin1 -> lin2 -> lin3
         # (latent dimensions above 16: one launch per layer, kl_dim final at once and klb = 0 -- engine.fc_chain_fwd)
         eng.fc_chain_fwd(buf, eps, sc.kl_dim, B, coef=sc.coef)
@@ -502,7 +502,7 @@ class _SingleOptimizerLoss(BaseLoss):
             # the iteration, nothing may queue in front of its weight gradients)
             call("dvae_stream_order", s, eng._aux_raw())
         # decoder convT stack; its last layer also evaluates the reconstruction likelihood and dL/dlogit
-        eng.decode_convs(buf, B, fuse_loss=fuse)
+        eng.decode_convs(buf, B, fuse_loss=fuse, chain=True)
         if btc and world > 1:
             # sharded: this stream's launches are issued FIRST -- the exchanges make the side stream's part long to issue, and
             # at a hundred images per GPU the host is what the critical path would wait for
@@ -745,12 +745,12 @@ class FactorKLoss(BaseLoss):
         eps1 = eps12[:Bh]
         buf = eng.buffers(B)
         data = eng.input(data, buf)
-        eng.encode_convs(data, buf, n=2 * Bh)                         # data1 and data2 in one pass
+        eng.encode_convs(data, buf, n=2 * Bh, chain=True)                         # data1 and data2 in one pass
         # FC core of both halves in one launch; KL only over data1 with the half batch as denominator (losses.py:255-259),
         # decoder only for data1
         eng.fc_chain_fwd(buf, eps12, sc.kl_dim, 2 * Bh, n_kl=Bh, n_dec=Bh, coef=sc.coef)
         klb = eng.kl_blocks(2 * Bh)
-        eng.decode_convs(buf, Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
+        eng.decode_convs(buf, Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials), chain=True)
         off = Bh
         # z_perm: permute across the (global) half batch, losses.py:287
         zin = sc.latent("disc_in", 2 * Bh, D)
@@ -896,12 +896,12 @@ class FactorKLoss(BaseLoss):
         else:
             buf = eng.buffers(B)
             data = eng.input(data, buf)
-            eng.encode_convs(data, buf, n=Bh)
+            eng.encode_convs(data, buf, n=Bh, chain=True)
             # z = mean; KL over data1 with the half batch as denominator (losses.py:255-259)
             eng.fc_chain_fwd(buf, None, sc.kl_dim, Bh, coef=sc.coef)
             if eng.kl_blocks(Bh):
                 call("dvae_kl_finish", ptr(sc.kl_dim), eng.kl_blocks(Bh), ptr(sc.coef), D, s)
-            eng.decode_convs(buf, Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials))
+            eng.decode_convs(buf, Bh, fuse_loss=(data, self._rec_code(), sc.coef, sc.partials), chain=True)
             # evaluation: vae_loss only (losses.py:276-278); discriminator on z1
             logits = disc.forward_raw(buf.z, Bh)
             g_dtc = sc.latent("g_dtc", 2 * Bh, 2)

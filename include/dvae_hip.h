@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DVAE_VERSION 108
+#define DVAE_VERSION 109
 
 /* Latent dimensions.  The reference's --latent-dim is any integer (main.py:81); every experiment of hyperparam.ini uses 10.
  * The FUSED kernels (the FC chain, the register-resident beta-TCVAE estimator, the 16-wide KL / scalar records) cover
@@ -244,6 +244,15 @@ typedef struct {
   float* kl_part;                                           /* [ceil(n_enc/dvae_fc_chain_rows(n_enc)),16] partial blocks (= kl_dim + 16) or NULL */
   float *d1, *d2, *d3;                                      /* [n_dec,256] x2, [n_dec,512] */
   int n_enc, n_kl, n_dec, D;
+  /* The 4x4 end of the conv stacks in the same launch (version >= 109; 64x64 geometry; all NULL: the plain chain).
+   * conv_in != NULL: the launch FIRST computes a_flat = ReLU(conv_64(conv_in) + conv_b) (encoders.py:76-80) -- a_flat is then an
+   * OUTPUT -- bit-identical to dvae_conv32_down(conv_in, conv_w, conv_b, NULL, a_flat, DVAE_NCHW, n_enc, 4, DVAE_ACT_RELU).
+   * convT_w != NULL (needs conv_in): it ENDS with convT_out = ReLU(convT_64(d3) + convT_b) (decoders.py:74-76) for the rows
+   * < n_dec, bit-identical to dvae_conv32_up(d3, DVAE_NCHW, convT_w, convT_b, NULL, convT_out, n_dec, 4, DVAE_ACT_RELU).      */
+  const float* conv_in;                                     /* [n_enc,8,8,32] NHWC: conv3's post-ReLU output */
+  const float *conv_w, *conv_b;                             /* img_down of encoder.conv_64 (dvae_stage_weights), its bias */
+  const float *convT_w, *convT_b;                           /* img_up of decoder.convT_64, its bias */
+  float* convT_out;                                         /* [n_dec,8,8,32] NHWC */
 } dvae_fc_chain_fwd_args;
 typedef struct {
   const float* gd3;                                         /* [n,512] gradient w.r.t. decoder.lin3's pre-activation output */
@@ -254,6 +263,15 @@ typedef struct {
   const float *scal, *coef;
   float *gd2, *gd1, *dz /* may be NULL */, *dml, *gh2, *gh1, *ga_flat;   /* [n,256] x2, [n,D], [n,2D], [n,256] x2, [n,512] */
   int n, D;
+  /* The 4x4 end in the same launch (version >= 109; all NULL: the plain chain).  convT_gout != NULL: the launch FIRST computes
+   * gd3 = [d3 > 0] * (convT_64's input gradient of convT_gout) -- gd3 is then an OUTPUT -- bit-identical to
+   * dvae_conv32_down(convT_gout, convT_w, NULL, d3, gd3, DVAE_NCHW, n, 4, DVAE_ACT_NONE).  conv_w != NULL (needs convT_gout): it
+   * ENDS with conv_gin = [conv_act > 0] * (conv_64's input gradient of ga_flat), bit-identical to
+   * dvae_conv32_up(ga_flat, DVAE_NCHW, conv_w, NULL, conv_act, conv_gin, n, 4, DVAE_ACT_NONE).                                */
+  const float* convT_gout;                                  /* [n,8,8,32] NHWC: gradient w.r.t. convT_64's output (already masked) */
+  const float *convT_w, *d3;                                /* img_down of decoder.convT_64; [n,512] lin3's post-ReLU output */
+  const float *conv_w, *conv_act;                           /* img_up of encoder.conv_64; [n,8,8,32] conv3's post-ReLU output */
+  float* conv_gin;                                          /* [n,8,8,32] NHWC: gradient w.r.t. conv3's output */
 } dvae_fc_chain_bwd_args;
 int dvae_fc_chain_fwd(const dvae_fc_chain_fwd_args* args, void* stream);
 int dvae_fc_chain_bwd(const dvae_fc_chain_bwd_args* args, void* stream);

@@ -26,7 +26,7 @@ def test_header_symbols_exported():
 def test_ctypes_table_matches_header():
     assert sorted(_lib.SIGNATURES) == _declared()
     h = _lib.lib()
-    assert h.dvae_version() == 108
+    assert h.dvae_version() == 109
     assert h.dvae_conv_wgrad_ws_floats() > 4_000_000
 
 

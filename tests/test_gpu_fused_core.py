@@ -534,3 +534,92 @@ def test_event_slots_order_a_late_consumer_after_marked_work():
         assert torch.equal(out, torch.full_like(out, 21.0)), (rep, out[:4], out[-4:])
     with pytest.raises(_lib.DvaeHipError):
         call("dvae_event_record", 99, stream())
+
+
+@pytest.mark.parametrize("n_enc,n_dec,D", [(1, 1, 10), (4, 4, 10), (7, 7, 6), (128, 128, 10), (1024, 1024, 10), (1030, 1030, 10),
+                                          (262, 131, 10), (2048, 1024, 10), (50, 0, 10)])
+def test_fc_chain_with_conv_ends(n_enc, n_dec, D):
+    """dvae_fc_chain_fwd / dvae_fc_chain_bwd with the 4x4 end of the conv stacks in the same launch (conv_in / convT_w,
+    convT_gout / conv_w: encoders.py:76-81, decoders.py:73-76 and their input gradients) == the three-launch sequences
+    dvae_conv32_down -> chain -> dvae_conv32_up they replace in the training step, bit for bit, every output."""
+    shapes, W, Bv = _fc_params(D, seed=7)
+    ent = _fc_stage(shapes, W)
+    wc, wt = dev(_rand(32, 32, 4, 4, seed=31, scale=0.2)), dev(_rand(32, 32, 4, 4, seed=32, scale=0.2))
+    bc, bt_ = dev(_rand(32, seed=33, scale=0.1)), dev(_rand(32, seed=34, scale=0.1))
+    f = lambda *s: torch.full(s, 7.0, device=DEV)
+    img = {k: f(16384) for k in ("c_down", "c_up", "t_down", "t_up")}
+    _stage([(wc, img["c_down"], img["c_up"]), (wt, img["t_down"], img["t_up"])])
+    bd = {k: dev(v) for k, v in Bv.items()}
+    eps = dev(torch.randn(n_enc, D, generator=torch.Generator().manual_seed(2)))
+    conv_in = dev(torch.relu(_rand(n_enc, 8, 8, 32, seed=41)))
+    nd = max(n_dec, 1)
+
+    def fwd(fused):
+        out = dict(h1=f(n_enc, 256), h2=f(n_enc, 256), ml=f(n_enc, 2 * D), mu=f(n_enc, D), logvar=f(n_enc, D), z=f(n_enc, D),
+                   d1=f(nd, 256), d2=f(nd, 256), d3=f(nd, 512))
+        a_flat, up = f(n_enc, 512), f(nd, 8, 8, 32)
+        kl = torch.full((_lib.KL_FLOATS,), 7.0, device=DEV)
+        extra = {}
+        if fused:
+            extra = dict(conv_in=ptr(conv_in), conv_w=ptr(img["c_down"]), conv_b=ptr(bc))
+            if n_dec:
+                extra.update(convT_w=ptr(img["t_up"]), convT_b=ptr(bt_), convT_out=ptr(up))
+        else:
+            call("dvae_conv32_down", ptr(conv_in), ptr(img["c_down"]), ptr(bc), None, ptr(a_flat), _lib.NCHW, n_enc, 4,
+                 _lib.ACT_RELU, stream())
+        st, addr = _lib.struct_of(_lib.FcChainFwdArgs, a_flat=ptr(a_flat), eps=ptr(eps), kl_part=ptr(kl) + 64,
+                                  n_enc=n_enc, n_kl=n_enc, n_dec=n_dec, D=D,
+                                  **{"w_" + k: ptr(ent[k][1]) for k in shapes}, **{"b_" + k: ptr(bd[k]) for k in shapes},
+                                  **{k: ptr(v) for k, v in out.items()}, **extra)
+        call("dvae_fc_chain_fwd", addr, stream())
+        if not fused and n_dec:
+            call("dvae_conv32_up", ptr(out["d3"]), _lib.NCHW, ptr(img["t_up"]), ptr(bt_), None, ptr(up), n_dec, 4, _lib.ACT_RELU,
+                 stream())
+        torch.cuda.synchronize()
+        out.update(a_flat=a_flat, up=up, kl=kl)
+        return out
+
+    ref, got = fwd(False), fwd(True)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), "forward %s" % k
+    assert float(ref["a_flat"].abs().max()) > 0 and (n_dec == 0 or float(ref["up"][:n_dec].abs().max()) > 0)
+    if n_dec == 0:
+        return
+    # ---- backward over n = n_dec rows
+    n = n_dec
+    gout = dev(_rand(n, 8, 8, 32, seed=51))
+    acts = {k: dev(torch.relu(_rand(n, w, seed=60 + i))) for i, (k, w) in enumerate(
+        [("d2", 256), ("d1", 256), ("h2", 256), ("h1", 256), ("a_flat", 512), ("d3", 512)])}
+    conv_act = dev(torch.relu(_rand(n, 8, 8, 32, seed=71)))
+    mu, lv = dev(_rand(n, D, seed=20)), dev(_rand(n, D, seed=21, scale=0.7))
+    dz2 = dev(_rand(n, D, seed=22))
+    scal = torch.zeros(_lib.NSCAL); scal[_lib.S_KLW] = 1.7
+    coef = torch.zeros(_lib.NCOEF); coef[_lib.C_INV_B] = 1.0 / n
+    scal, coef = dev(scal), dev(coef)
+
+    def bwd(fused):
+        out = dict(gd2=f(n, 256), gd1=f(n, 256), dz=f(n, D), dml=f(n, 2 * D), gh2=f(n, 256), gh1=f(n, 256), ga_flat=f(n, 512))
+        gd3, gin = f(n, 512), f(n, 8, 8, 32)
+        extra = {}
+        if fused:
+            extra = dict(convT_gout=ptr(gout), convT_w=ptr(img["t_down"]), d3=ptr(acts["d3"]), conv_w=ptr(img["c_up"]),
+                         conv_act=ptr(conv_act), conv_gin=ptr(gin))
+        else:
+            call("dvae_conv32_down", ptr(gout), ptr(img["t_down"]), None, ptr(acts["d3"]), ptr(gd3), _lib.NCHW, n, 4,
+                 _lib.ACT_NONE, stream())
+        ins = dict(gd3=gd3, mu=mu, logvar=lv, eps=eps[:n].contiguous(), dz2=dz2, scal=scal, coef=coef,
+                   **{k: v for k, v in acts.items() if k != "d3"})
+        st, addr = _lib.struct_of(_lib.FcChainBwdArgs, n=n, D=D, **{"w_" + k: ptr(ent[k][2]) for k in shapes},
+                                  **{k: ptr(v) for k, v in ins.items()}, **{k: ptr(v) for k, v in out.items()}, **extra)
+        call("dvae_fc_chain_bwd", addr, stream())
+        if not fused:
+            call("dvae_conv32_up", ptr(out["ga_flat"]), _lib.NCHW, ptr(img["c_up"]), None, ptr(conv_act), ptr(gin), n, 4,
+                 _lib.ACT_NONE, stream())
+        torch.cuda.synchronize()
+        out.update(gd3=gd3, gin=gin)
+        return out
+
+    ref, got = bwd(False), bwd(True)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), "backward %s" % k
+    assert float(ref["gd3"].abs().max()) > 0 and float(ref["gin"].abs().max()) > 0
