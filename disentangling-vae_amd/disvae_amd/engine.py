@@ -264,14 +264,15 @@ class VAEEngine:
         # 64x64 images with 1 / 3 channels: the forward kernels of conv1 and convT2 also emit the sign bits of their outputs and
         # the input-gradient kernels of conv2 and convT3 read those instead of the 32x32x32 fp32 activations (dvae_*_bits)
         self.mask_bits = self.is64 and c in (1, 3) and knob("DVAE_MASK_BITS", "1") != "0"   # (A/B knob: DVAE_DEBUG=1 only)
-        # 64x64 geometry, fused FC chain: conv_64 / convT_64 and their input gradients run INSIDE the chain launches
-        # (dvae_fc_chain_fwd / _bwd, conv_in / convT_gout fields: csrc/conv4_end.h) -- four launches fewer on the critical path
+        # fused FC chain: the 8x8 <-> 4x4 layers (conv_64 / convT_64 at 64x64, conv3 / convT1 at 32x32) and their input
+        # gradients run INSIDE the chain launches (dvae_fc_chain_fwd / _bwd, conv_in / convT_gout fields: csrc/conv4_end.h) --
+        # four launches fewer on the critical path
         # Up to fuse_ends_max_rows rows per launch, where the step is a chain of dependent launches and each one saved counts
         # (same box, three alternations, profiles/r06_s2_chain3.txt: factor 64x64x1 tensor 256 0.590 -> 0.569 ms, btcvae 64x64x3 at
         # 64 / 128 / 256 images 0.311 -> 0.302, 0.347 -> 0.344, 0.450 -> 0.447 ms); from 512 rows up the fused launches -- 150 KB
         # of LDS, a whole CU per workgroup -- can no longer slip in beside the other stream's persistent kernels the way the
         # small conv launches do: 0.643 -> 0.652 ms at 512 images, 1.060 -> 1.082 ms at 1024 (profiles/r06_s2_chain2.txt)
-        self.fuse_ends = self.is64 and not _lib.wide(latent_dim) and knob("DVAE_FUSE_ENDS", "1") != "0"   # (A/B knob: DVAE_DEBUG=1 only)
+        self.fuse_ends = not _lib.wide(latent_dim) and knob("DVAE_FUSE_ENDS", "1") != "0"   # (A/B knob: DVAE_DEBUG=1 only)
         self.fuse_ends_max_rows = int(knob("DVAE_FUSE_ENDS_MAX_ROWS", "256"))
         self._ends_on = False  # this forward pass: set by encode_convs(chain=True), read by fc_chain_fwd / decode_convs
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
@@ -529,9 +530,10 @@ class VAEEngine:
         if not self._ends_on:
             return {}
         P, I = self.p, self._img
-        d = dict(conv_in=ptr(buf.enc_act[2]), conv_w=I("encoder.conv_64", "down"), conv_b=ptr(P("encoder.conv_64.bias")))
+        enc, dec = "encoder." + self.enc_names[-1], "decoder." + self.dec_names[0]
+        d = dict(conv_in=ptr(buf.enc_act[-2]), conv_w=I(enc, "down"), conv_b=ptr(P(enc + ".bias")))
         if n_dec > 0:
-            d.update(convT_w=I("decoder.convT_64", "up"), convT_b=ptr(P("decoder.convT_64.bias")), convT_out=ptr(buf.dec_act[0]))
+            d.update(convT_w=I(dec, "up"), convT_b=ptr(P(dec + ".bias")), convT_out=ptr(buf.dec_act[0]))
         return d
 
     def _fc_layers_fwd(self, buf, eps, kl_dim, n_enc, n_kl, n_dec, coef):
@@ -594,8 +596,9 @@ class VAEEngine:
         I = self._img
         ends = {}
         if self._ends(n):      # convT_64's input gradient in front of the chain, conv_64's behind it (dvae_fc_chain_bwd_args)
-            ends = dict(convT_gout=ptr(buf.dec_gact[0]), convT_w=I("decoder.convT_64", "down"), d3=ptr(buf.d3),
-                        conv_w=I("encoder.conv_64", "up"), conv_act=ptr(buf.enc_act[2]), conv_gin=ptr(buf.enc_gact[2]))
+            ends = dict(convT_gout=ptr(buf.dec_gact[0]), convT_w=I("decoder." + self.dec_names[0], "down"), d3=ptr(buf.d3),
+                        conv_w=I("encoder." + self.enc_names[-1], "up"), conv_act=ptr(buf.enc_act[-2]),
+                        conv_gin=ptr(buf.enc_gact[-2]))
         addr = self._args(("fcb", id(buf), ptr(eps), ptr(dz2), ptr(dz3), ptr(dmu_x), ptr(dlv_x), ptr(scal), ptr(coef), n,
                            self._images.buf.data_ptr()),
                           _lib.FcChainBwdArgs, gd3=ptr(buf.gd3),

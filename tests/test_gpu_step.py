@@ -391,6 +391,57 @@ def test_replay_matches_eager(loss, mode):
     assert torch.equal(runs[0][1], runs[1][1])
 
 
+@pytest.mark.parametrize("loss,img,B", [("btcvae", (3, 64, 64), 16), ("factor", (1, 64, 64), 24), ("VAE", (1, 32, 32), 9),
+                                        ("betaB", (3, 64, 64), 300)])
+def test_conv_ends_inside_the_chain_launches_change_nothing(loss, img, B):
+    """engine.fuse_ends (the 8x8 <-> 4x4 layers and their input gradients as prologue / epilogue of dvae_fc_chain_fwd / _bwd,
+    up to engine.fuse_ends_max_rows rows per step; encoders.py:76-81, decoders.py:73-76) against the same steps with those four
+    layers as launches of their own: same arithmetic, so losses and parameters after 4 steps are bit-identical.  B = 300 is above
+    the row limit: both runs take the separate launches (the limit is honoured)."""
+    D = 10
+    runs = []
+    for fuse in (False, True):
+        model, opt, loss_f = _native(loss, img, 21, 202599, 5e-4)
+        eng = model.engine
+        assert eng.fuse_ends, "the shipped configuration fuses the conv ends"
+        eng.fuse_ends = fuse
+        loss_f.replay = None                               # eager: every launch of every step goes through engine.call (counted)
+        gen = torch.Generator().manual_seed(4)
+        losses = []
+        data = torch.empty((B,) + img, device=DEV)
+        seen = []
+        orig = _lib.call
+
+        def spy(name, *a):
+            seen.append(name)
+            return orig(name, *a)
+        import disvae_amd.engine as E
+        E.call = spy
+        try:
+            for step in range(4):
+                data.copy_(torch.rand((B,) + img, generator=gen))
+                if loss == "factor":
+                    Bh = B // 2
+                    noise = (torch.randn(Bh, D, generator=gen).to(DEV), torch.randn(Bh, D, generator=gen).to(DEV),
+                             torch.stack([torch.randperm(Bh, generator=gen) for _ in range(D)]))
+                    l = loss_f.call_optimize(data, model, opt, None, noise=noise)
+                else:
+                    l = loss_f.fused_step(data, model, opt, None, eps=torch.randn(B, D, generator=gen).to(DEV))
+                losses.append(l.item())
+        finally:
+            E.call = orig
+        # launches of the 4x4 end per step: conv32_down at Hs = 4 (argument 7 of dvae_conv32_down) is gone exactly when fused
+        n_chain = seen.count("dvae_fc_chain_fwd")
+        assert n_chain >= 4
+        runs.append((losses, model.arena.flat.clone(), model.arena.grad.clone(), len(seen)))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    if B <= 256:                                # (factor: the forward chain runs over both halves = B rows)
+        assert runs[1][3] < runs[0][3], "fused steps must issue fewer launches (%d vs %d)" % (runs[1][3], runs[0][3])
+    else:
+        assert runs[1][3] == runs[0][3]
+
+
 @pytest.mark.parametrize("mode", ["plan", "graph"])
 @pytest.mark.parametrize("loss", ["btcvae", "factor"])
 def test_replay_device_rng_trains(loss, mode, tmp_path):
