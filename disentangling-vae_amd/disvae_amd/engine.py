@@ -274,6 +274,13 @@ class VAEEngine:
         # small conv launches do: 0.643 -> 0.652 ms at 512 images, 1.060 -> 1.082 ms at 1024 (profiles/r06_s2_chain2.txt)
         self.fuse_ends = not _lib.wide(latent_dim) and knob("DVAE_FUSE_ENDS", "1") != "0"   # (A/B knob: DVAE_DEBUG=1 only)
         self.fuse_ends_max_rows = int(knob("DVAE_FUSE_ENDS_MAX_ROWS", "256"))
+        # Round 6: convT3's weight gradient (bandwidth-bound) is forked one kernel earlier -- behind convT3's input gradient, beside
+        # the matrix-bound input gradient of convT2 -- instead of behind both.  The side stream's serial chain of weight gradients
+        # is what small steps end on, and it now starts ~15 us sooner: 128 / 256 images 0.341 -> 0.330, 0.443 -> 0.431 ms,
+        # btcvae 64x64x1 B = 256 0.412 -> 0.398, 1024 images 1.054 -> 1.048 ms (profiles/r06_s2_sched2.txt).  Mode 2 (in FRONT of
+        # convT3's input gradient) wins another 1 % at 128 images and loses 1.6 % at 256, 0.7 % at 1024 (r06_s2_sched3.txt): not used.
+        # Moving the main stream's tail (tail_main) to the side stream loses 2-8 % at every small batch (same file).
+        self.early_thin_wgrad = int(knob("DVAE_EARLY_THIN", "1"))     # (A/B knob: DVAE_DEBUG=1 only)
         self._ends_on = False  # this forward pass: set by encode_convs(chain=True), read by fc_chain_fwd / decode_convs
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
         self._fc_descs = {}    # host descriptor arrays / argument structs of launches, kept alive for recorded plans
@@ -704,6 +711,9 @@ class VAEEngine:
                 # both operands of this layer's weight gradient exist (dy: the previous input gradient or g_logit): side
                 # stream, now, beside this layer's input gradient
                 self._conv_wgrad(*wargs, fork=True)
+            elif self.early_thin_wgrad == 2 and h == 32 and not self.single_stream:
+                self.fork_side()                 # (its launch follows this stream's next kernel, like every side launch)
+                queued.append(wargs)
             else:
                 (pending if h >= 16 else deferred).append(wargs)
             # the first decoder layer's input gradient leaves NCHW = (c,h,w) order, straight into gd3 (the
@@ -726,7 +736,8 @@ class VAEEngine:
             for w_ in queued:                    # side launches of the previous fork, issued AFTER this stream's next kernel
                 self._conv_wgrad(*w_, fork=False)
             queued = []
-            if h == 16 or (k == 0 and pending):  # last big dgrad is enqueued: its inputs and those of `pending` are final
+            early = self.early_thin_wgrad == 1 and h == 32 and pending and not self.single_stream
+            if h == 16 or (k == 0 and pending) or early:  # last big dgrad is enqueued: its inputs and those of `pending` are final
                 self.fork_side()
                 queued, pending = pending, []
         for w_ in queued:
