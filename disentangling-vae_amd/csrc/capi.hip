@@ -433,6 +433,8 @@ int dvae_set_coef(float* coef, float c0, float c1, float c2, float c3, float c4,
 int dvae_stream_create(void** stream) {
   DVAE_CHECK_ARG(stream);
   hipStream_t s = nullptr;
+  // (lowest-priority streams for the engine -- the caller's kernels first -- measured the same or 0.5-1.5 % slower at 64 .. 1024
+  // images: profiles/r06_s2_prio1.txt; round 4 measured a HIGH-priority side stream: the same)
   if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
     set_error("dvae_stream_create: %s", hipGetErrorString(hipGetLastError()));
     return -2;

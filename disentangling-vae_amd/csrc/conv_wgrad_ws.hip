@@ -290,7 +290,21 @@ static int launch_wgrad_ws_t(const float* big, const float* small, float* dw, fl
                              float* ws, hipStream_t s) {
   using W = WGeo<HS>;
   const int n_units = (int)(((long)N * HS * HS) / 64);
-  int grid = n_units < WGW_MAX_BLOCKS ? n_units : WGW_MAX_BLOCKS;
+  // Persistent grid.  One workgroup per CU fills the chip -- which is what a step of 129 .. 320 images must NOT do: there the
+  // other stream's kernels are the chain of small dependent launches the iteration waits for (8x8 / 4x4 layers, the FC chain),
+  // and with every CU taken by a 512-thread, 130 KB workgroup that runs 3-5 units they queue for ~20 us each.  192 workgroups
+  // leave a quarter of the chip to them: 192 / 256 images 0.384 -> 0.368, 0.432 -> 0.416 ms, btcvae 64x64x1 B = 256 0.400 ->
+  // 0.382 (profiles/r06_s2_cap3.txt: the shipped library against a WGW_FULL_GRID build, same box, three alternations; the
+  // sweep over grid sizes: r06_s2_cap1.txt, r06_s2_cap2.txt).  At 128 images and below a workgroup runs one or two units and is
+  // gone before anything queues (256: 0.331, 192: 0.335 ms); at 384 images the two are level, at 512 the full grid wins
+  // (0.634 vs 0.645 ms) and from 1024 images the main stream's kernels fill the chip themselves: a smaller grid only delays
+  // the weight gradients (round 5 measured the same at 1024: profiles/r05_v23_side_cap_ab.txt).
+#ifdef WGW_FULL_GRID                 // (variant builds, tools/build_variant.sh: the A/B partner)
+  const int full = WGW_MAX_BLOCKS;
+#else
+  const int full = (N > 128 && N <= 320) ? 192 : WGW_MAX_BLOCKS;
+#endif
+  int grid = n_units < full ? n_units : full;
   {
     static const int cap = env_int("DVAE_WGRAD_GRID", WGW_MAX_BLOCKS);   // debug builds: A/B of the persistent grid size
     if (cap > 0 && cap < grid) grid = cap;

@@ -113,6 +113,16 @@ _TAIL_MAIN = ("conv3", "conv_64")
 
 
 _DEVICE_STREAMS = {}
+_WG2_STREAMS = {}
+
+
+def wg2_stream(device):
+    """Second weight-gradient stream of `device` (the three-queue schedule of small steps), one per process like device_streams."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _WG2_STREAMS.get(key)
+    if st is None:
+        st = _WG2_STREAMS[key] = _lib.new_stream(device)
+    return st
 
 
 def device_streams(device):
@@ -240,6 +250,8 @@ class VAEEngine:
         self._bufs = {}
         self._ws = None
         self._ws_side = None
+        self._ws_wg2 = None    # partial-sum workspace of the second weight-gradient stream (three_streams)
+        self._wg2 = None
         self._side = None      # side HIP stream: the weight-gradient kernels run beside the dgrad chain
         self._aux = None       # exchange stream of sharded steps (see buffers())
         # small batches: everything on the caller's stream.  Below ~256 images the iteration is bound by the latency of
@@ -281,6 +293,9 @@ class VAEEngine:
         # convT3's input gradient) wins another 1 % at 128 images and loses 1.6 % at 256, 0.7 % at 1024 (r06_s2_sched3.txt): not used.
         # Moving the main stream's tail (tail_main) to the side stream loses 2-8 % at every small batch (same file).
         self.early_thin_wgrad = int(knob("DVAE_EARLY_THIN", "1"))     # (A/B knob: DVAE_DEBUG=1 only)
+        # small steps: the weight gradients on TWO side streams, each launched at the first fork behind the kernel that produces
+        # its last operand (_decode_backward_3s / _encode_backward_3s).  Set per step by the loss plugins (BaseLoss._streams).
+        self.three_streams = False
         self._ends_on = False  # this forward pass: set by encode_convs(chain=True), read by fc_chain_fwd / decode_convs
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
         self._fc_descs = {}    # host descriptor arrays / argument structs of launches, kept alive for recorded plans
@@ -308,6 +323,8 @@ class VAEEngine:
             _lib.note_alloc()
             self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
             self._ws_side = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._ws_wg2 = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._wg2 = wg2_stream(self.device)
             # (a high-priority side stream measured the same step time: profiles/r04_v45_side_priority.txt)
             # third stream (sharded batches): the exchange-bound part of a step -- latent all-gather, the estimator over the
             # global batch, column-gradient reduce-scatter, the all-reduce of the loss sums -- must not sit in front of the
@@ -392,7 +409,7 @@ class VAEEngine:
     def _aux_raw(self):
         return _stream() if self.single_stream else self._aux.cuda_stream
 
-    def _side_wgrad_grouped(self, problems):
+    def _side_wgrad_grouped(self, problems, stream=None):
         """All FC weight gradients of `problems` = [(x, dy, dw, db, M, K, N)] (tensors) in ONE launch on the side stream
         (dvae_linear_wgrad_grouped): ~400 short-lived workgroups instead of six launches that each leave most of
         the chip idle and delay the conv weight gradients queued behind them."""
@@ -403,7 +420,7 @@ class VAEEngine:
                 self._fc_descs.clear()
                 _lib.note_alloc()
             ent = self._fc_descs[key] = _lib.wgrad_descs(key)
-        call("dvae_linear_wgrad_grouped", ent[1], len(problems), self._side_raw())
+        call("dvae_linear_wgrad_grouped", ent[1], len(problems), self._side_raw() if stream is None else stream)
 
     def _conv_wgrad(self, fn, *args, fork=True, main=False):
         """Conv / convT weight gradient `fn(*args, ws, stream)`: off the dgrad critical path, so it
@@ -677,6 +694,23 @@ class VAEEngine:
              ptr(buf.d3), B, HIDDEN_DIM, HID * 16, ACT_RELU, ws, s)
         self.decode_convs(buf, B, fuse_loss)
 
+    # ---- three-queue schedule of small steps ----------------------------------------------------------------------------
+    def _three(self, chain):
+        """The backward pass of this step puts its weight gradients on two side streams (64x64 geometry, native step)."""
+        return bool(self.three_streams and chain and self.is64 and not self.single_stream and not self.eager_wgrad)
+
+    def _fork_q(self, *qs):
+        """Order side stream 1 (side) and / or 2 (wg2) behind everything enqueued so far on the current stream."""
+        for q in qs:
+            if q == 1:
+                self.fork_side()
+            else:
+                call("dvae_stream_order", _stream(), self._wg2.cuda_stream)
+
+    def _wgrad_q(self, q, fn, *args):
+        """Conv / convT weight gradient (+ its fixed-order reduction) on side stream q, with that stream's partial-sum workspace."""
+        call(fn, *args, ptr(self._ws_side if q == 1 else self._ws_wg2), (self._side if q == 1 else self._wg2).cuda_stream)
+
     # ------------------------------------------------------------------ backward
     def decode_backward(self, z, buf, n=None, join=True, defer_fc_wgrad=False, fc_chain=None):
         """buf.g_logit (grad w.r.t. the pre-sigmoid output) -> decoder weight grads, buf.dz.
@@ -701,13 +735,17 @@ class VAEEngine:
         # and leaves most CUs idle -- so the big weight gradients are forked THERE (fork 1, after the last
         # big dgrad), and the rest after the FC dgrads (fork 2).  Every fork costs this stream ~6 us.
         eager = self.eager_wgrad and not self.single_stream
+        three = self._three(fc_chain is not None) and defer_fc_wgrad and not join
         pending, deferred, queued = [], [], []
+        W3 = {}                                  # three-queue schedule: every layer's weight-gradient launch, by layer
         for k in range(len(names) - 1, -1, -1):
             name, x_in, gx, h = names[k], acts[k], gacts[k], hs[k]
             lname = "decoder.%s" % name
             wargs = ("dvae_convT4s2_wgrad", ptr(x_in), NCHW if k == 0 else NHWC, ptr(dy), dy_layout,
                      ptr(self.g(lname + ".weight")), ptr(self.g(lname + ".bias")), B, HID, h, h, couts[k])
-            if eager:
+            if three:
+                W3[k] = wargs
+            elif eager:
                 # both operands of this layer's weight gradient exist (dy: the previous input gradient or g_logit): side
                 # stream, now, beside this layer's input gradient
                 self._conv_wgrad(*wargs, fork=True)
@@ -731,6 +769,22 @@ class VAEEngine:
                 call("dvae_convT4s2_dgrad", ptr(dy), dy_layout, ptr(self.p(lname + ".weight")), ptr(x_in), ptr(gx),
                      out_layout, B, HID, h, h, couts[k], s)
             dy, dy_layout = gx, NHWC
+            if three:
+                # a weight gradient needs its layer's OUTPUT gradient, i.e. the input gradient of the layer above: behind convT3's
+                # input gradient both convT3's and convT2's are due (one per side stream), behind convT2's convT1's
+                last = len(names) - 1
+                for q, w_ in queued:
+                    self._wgrad_q(q, *w_)
+                queued = []
+                if k == last:
+                    self._fork_q(1, 2)
+                    queued = [(1, wargs)]        # (W3[last - 1] does not exist yet: built at the head of the next iteration)
+                elif k == last - 1:
+                    self._wgrad_q(2, *wargs)     # convT2's: forked behind convT3's input gradient, its operands were final there
+                    self._fork_q(1)
+                elif k == last - 2:
+                    self._wgrad_q(1, *wargs)     # convT1's: forked behind convT2's input gradient
+                continue
             if eager:
                 continue
             for w_ in queued:                    # side launches of the previous fork, issued AFTER this stream's next kernel
@@ -740,6 +794,19 @@ class VAEEngine:
             if h == 16 or (k == 0 and pending) or early:  # last big dgrad is enqueued: its inputs and those of `pending` are final
                 self.fork_side()
                 queued, pending = pending, []
+        if three:
+            for q, w_ in queued:
+                self._wgrad_q(q, *w_)
+            fc_chain()
+            # behind the chain of FC input gradients: convT_64's weight gradient here, the FC layers' and the encoder's 4x4 end
+            # in _encode_backward_3s (same fork)
+            self._fork_q(1, 2)
+            if len(names) == 4:
+                self._wgrad_q(1, *W3[0])
+            self._fc_pending = [(buf.d2, buf.gd3, self.g("decoder.lin3.weight"), self.g("decoder.lin3.bias"), B, HIDDEN_DIM, HID * 16),
+                                (buf.d1, buf.gd2, self.g("decoder.lin2.weight"), self.g("decoder.lin2.bias"), B, HIDDEN_DIM, HIDDEN_DIM),
+                                (z, buf.gd1, self.g("decoder.lin1.weight"), self.g("decoder.lin1.bias"), B, D, HIDDEN_DIM)]
+            return
         for w_ in queued:
             self._conv_wgrad(*w_, fork=False)
         if fc_chain is not None:
@@ -765,6 +832,43 @@ class VAEEngine:
             self._side_wgrad_grouped(fc)
         if join:
             self._join_side()
+
+    def _encode_backward_3s(self, x, buf, B, fc, fused_end):
+        """encode_backward of the three-queue schedule; _decode_backward's fork behind the FC chain covers the first launches."""
+        s = _stream()
+        c, H, _ = self.img_size
+        last = len(self.enc_names) - 1
+        W = {}
+        for k in range(last, -1, -1):
+            lname = "encoder.%s" % self.enc_names[k]
+            h_in = self.enc_sizes[k] * 2
+            x_in, x_layout, cin = (buf.enc_act[k - 1], NHWC, HID) if k > 0 else (x, NCHW, c)
+            dy, dy_layout = (buf.ga_flat, NCHW) if k == last else (buf.enc_gact[k], NHWC)
+            W[k] = (("dvae_conv4s2_wgrad", ptr(x_in), x_layout, ptr(dy), dy_layout, ptr(self.g(lname + ".weight")),
+                     ptr(self.g(lname + ".bias")), B, cin, h_in, h_in, HID), dy, dy_layout, lname, x_in, h_in)
+        # all six FC weight gradients + conv_64's (ga_flat is final): second side stream
+        self._side_wgrad_grouped(fc, stream=self._wg2.cuda_stream)
+        self._wgrad_q(2, *W[last][0])
+        if not fused_end:                        # conv_64's input gradient as a launch of its own: conv3's weight gradient waits for it
+            _, dy, dyl, lname, x_in, h_in = W[last]
+            self._conv_dgrad(dy, dyl, lname, x_in, buf, last, B, h_in, s)
+            self._fork_q(1)
+        for k in range(last - 1, 0, -1):
+            _, dy, dyl, lname, x_in, h_in = W[k]
+            self._conv_dgrad(dy, dyl, lname, x_in, buf, k, B, h_in, s)     # this stream's next kernel first, then the side launch
+            if k == last - 1:
+                self._wgrad_q(1, *W[k][0])       # conv3's (operand: fc_chain_bwd's epilogue / the launch above)
+                self._fork_q(2)                  # behind conv3's input gradient: conv2's weight gradient
+            else:
+                self._wgrad_q(2, *W[k][0])
+        if x.dtype == torch.uint8:
+            lname = "encoder.%s" % self.enc_names[0]
+            call("dvae_conv4s2_wgrad_u8", ptr(x), ptr(buf.enc_gact[0]), ptr(self.g(lname + ".weight")),
+                 ptr(self.g(lname + ".bias")), B, c, H, H, HID, ptr(self._ws), s)
+        else:
+            self._conv_wgrad(*W[0][0], fork=False, main=True)
+        self._join_side()
+        call("dvae_stream_order", self._wg2.cuda_stream, s)
 
     def _conv_dgrad(self, dy, dy_layout, lname, x_in, buf, k, B, h_in, s):
         """Input gradient of encoder conv layer k (> 0) into buf.enc_gact[k - 1], masked by the ReLU of layer k - 1: by the
@@ -802,6 +906,8 @@ class VAEEngine:
                   B, HIDDEN_DIM, 2 * self.latent_dim)])
         eager = self.eager_wgrad and not self.single_stream
         fused_end = bool(fc_chain) and self._ends(B)        # conv_64's input gradient: fc_chain_bwd's epilogue wrote enc_gact[2]
+        if self._three(bool(fc_chain)) and len(pend) == 3:
+            return self._encode_backward_3s(x, buf, B, fc, fused_end)
         deferred = [lambda fc=fc: self._side_wgrad_grouped(fc)]
         tail_main = []                      # weight gradients the main stream computes after conv1's (load balance of the tail)
         last = len(self.enc_names) - 1

@@ -172,6 +172,12 @@ class BaseLoss(abc.ABC):
     # images: 0.349 vs 0.359 ms, btcvae_dsprites 0.421 vs 0.433 ms: profiles/r05_v25_schedule_ab.txt) -- each fork costs the
     # critical path an event and the small weight gradients it frees early are not what the iteration waits for
     EAGER_WGRAD_ELEMS = int(knob("DVAE_EAGER_WGRAD_ELEMS", 0))
+    # weight gradients on TWO side streams (engine.three_streams) from this many batch rows per step (single process).  Measured
+    # (profiles/r06_s2_three1.txt, same box, three alternations): SLOWER for every beta-TCVAE step -- 64 / 128 / 256 / 512 / 1024
+    # images 0.288 -> 0.300, 0.328 -> 0.347, 0.435 -> 0.441, 0.634 -> 0.648, 1.050 -> 1.060 ms: whatever runs beside the main
+    # stream's chain of small kernels slows that chain by more than the side streams gain -- and faster only where the side
+    # stream also carries the discriminator's chain: factor 64x64x3 tensor 2048 1.853 -> 1.832 ms (FactorKLoss below)
+    THREE_STREAM_MIN_ROWS = 1 << 30
     # sharded batches up to this many input elements per rank: ONE all-reduce of the whole gradient arena at the end instead of
     # two overlapped spans (the step is a latency chain; every collective costs the host and both streams more than the
     # overlap of 1 MB buys)
@@ -182,6 +188,8 @@ class BaseLoss(abc.ABC):
         single = mode == "1" or (mode == "auto" and data.numel() <= self.SINGLE_STREAM_ELEMS)
         model.engine.single_stream = bool(single) and self._world()[0] == 1
         model.engine.eager_wgrad = data.numel() <= int(knob("DVAE_EAGER_WGRAD_ELEMS", self.EAGER_WGRAD_ELEMS))
+        model.engine.three_streams = (not single and self._world()[0] == 1
+                                      and data.shape[0] >= int(knob("DVAE_THREE_STREAM_MIN_ROWS", self.THREE_STREAM_MIN_ROWS)))
         tm = knob("DVAE_TAIL_MAIN", "default")      # A/B (DVAE_DEBUG=1): which encoder weight gradients end the main stream
         if tm != "default":
             model.engine.tail_main = tuple(v for v in tm.split(",") if v)
@@ -201,7 +209,8 @@ class BaseLoss(abc.ABC):
         batch pointer, the stream, and the few Python-side switches passed as scalars."""
         return (id(model), data.shape, data.data_ptr(), injected, _stream(), model.arena.flat.data_ptr(),
                 model.arena.grad.data_ptr(), _lib.ALLOC_GEN[0], self.rec_dist, getattr(self, "is_mss", None),
-                model.engine.single_stream, model.engine.eager_wgrad, model.engine.tail_main, id(self.comm), self.estimator)
+                model.engine.single_stream, model.engine.eager_wgrad, model.engine.tail_main, id(self.comm), self.estimator,
+                model.engine.three_streams)
 
     @abc.abstractmethod
     def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):
@@ -687,6 +696,10 @@ class FactorKLoss(BaseLoss):
     """losses.py:205-313.  ``call_optimize`` runs the whole two-optimizer iteration on the HIP
     kernels, including quirk Q1 (the encoder also receives d[0.5 CE(D(z1),0)]/dz1 because the
     reference does not detach d_z and steps the VAE optimizer after d_tc_loss.backward())."""
+
+    # the side stream carries the discriminator's chain as well: from 2048 rows per step the VAE's weight gradients go to two
+    # side streams (BaseLoss.THREE_STREAM_MIN_ROWS: tensor 2048 1.853 -> 1.832 ms, tensor 256 0.561 -> 0.592)
+    THREE_STREAM_MIN_ROWS = 2048
 
     def __init__(self, device, gamma=10., disc_kwargs={}, optim_kwargs=dict(lr=5e-5, betas=(0.5, 0.9)), **kwargs):
         super().__init__(**kwargs)
