@@ -33,12 +33,13 @@ __device__ __forceinline__ int c4_st_index(int img_l, int c, int pos) {
   return ((img_l * 6 + row) * 6 + col) * 32 + (((c >> 2) ^ swz_small<4>(row, col)) << 2) + (c & 3);
 }
 
-// "down" (Conv2d forward / ConvTranspose2d input gradient), unit `unit` of big[N][8][8][32] (NHWC) -> out[N][512] ((c,h,w)
+// "down" (Conv2d forward / ConvTranspose2d input gradient), unit `unit` of big[N][8][8][32] (NHWC; its tile is in pf, loaded by the
+// caller with load_big<4>) -> out[N][512] ((c,h,w)
 // order) AND rows 0..3 of `tile` (LDS, row stride `ts`; images beyond N: zero rows).  512 threads; wl = the layer's "down"
 // image (complete and published by a barrier before the call), bt / red = scratch.  Two workgroup barriers inside; the caller
 // adds the one that publishes `tile` (TILE = false: no tile, out only).  mask (MASK): [N][512], same order as out.
 template <bool MASK, bool TILE>
-__device__ __forceinline__ void c4_down_unit(const float* __restrict__ big, const float* __restrict__ bias,
+__device__ __forceinline__ void c4_down_unit(const float* __restrict__ bias,
                                              const float* __restrict__ mask, float* __restrict__ out, float* tile, int ts,
                                              int N, int act, int unit, const float* wl, float* bt, float* red,
                                              const f32x4 (&pf)[Geo<4>::BIG_NPF], const SlotDesc<Geo<4>::BIG_NPF>& sd) {

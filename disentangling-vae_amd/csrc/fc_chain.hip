@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_fwd(const FwdArgs P) {
     for (int u = 0; u < RG; ++u) {
       if (u > 0) load_big<4>(pf, sd, a.conv_in, blockIdx.x * RG + u, a.n_enc);
       // (RG == 2: the tile would overlay the image the second unit still multiplies with -- its rows come back from a_flat below)
-      c4_down_unit<false, RG == 1>(a.conv_in, a.conv_b, nullptr, a_out, tA, FCC_XS, a.n_enc, DVAE_ACT_RELU, blockIdx.x * RG + u,
+      c4_down_unit<false, RG == 1>(a.conv_b, nullptr, a_out, tA, FCC_XS, a.n_enc, DVAE_ACT_RELU, blockIdx.x * RG + u,
                                    smem + LD::WL, smem + LD::BT, smem + LD::RD, pf, sd);
     }
     if (RG != 1) {
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256 * KS) void k_fc_chain_bwd(const BwdArgs P) {
 #pragma unroll
     for (int u = 0; u < RG; ++u) {
       if (u > 0) load_big<4>(pf, sd, a.convT_gout, blockIdx.x * RG + u, n);
-      c4_down_unit<true, RG == 1>(a.convT_gout, nullptr, a.d3, g_out, tA, FCC_XS, n, DVAE_ACT_NONE, blockIdx.x * RG + u,
+      c4_down_unit<true, RG == 1>(nullptr, a.d3, g_out, tA, FCC_XS, n, DVAE_ACT_NONE, blockIdx.x * RG + u,
                                   smem + LD::WL, smem + LD::BT, smem + LD::RD, pf, sd);
     }
     if (RG != 1) {
@@ -751,36 +751,44 @@ int fc_chain_rows(int n) {
 }
 
 template <int DEPTH, int KS, int RG>
-static void launch_fwd_t(const FwdArgs& P, hipStream_t s) {
+static int launch_fwd_t(const FwdArgs& P, hipStream_t s) {
   if (P.a.conv_in) {
-    if constexpr (KS != 2) abort();                   // (debug-build variants with 256 threads: no conv ends)
+    if constexpr (KS != 2) {                          // (debug-build variants with 256 threads)
+      set_error("dvae_fc_chain_fwd: the conv ends need the 512-thread variants");
+      return -1;
+    }
     if constexpr (KS == 2) {
       constexpr int lds = ChainLds<KS, RG, true>::TOTAL * (int)sizeof(float);
       static DeviceOnce attr;
       if (attr.first())
         (void)hipFuncSetAttribute((const void*)k_fc_chain_fwd<DEPTH, KS, RG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL((k_fc_chain_fwd<DEPTH, KS, RG, true>), dim3((P.a.n_enc + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), lds, s, P);
-      return;
+      return 0;
     }
   }
   constexpr int lds = ChainLds<KS, RG, false>::TOTAL * (int)sizeof(float);
   hipLaunchKernelGGL((k_fc_chain_fwd<DEPTH, KS, RG, false>), dim3((P.a.n_enc + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), lds, s, P);
+  return 0;
 }
 template <int DEPTH, int KS, int RG>
-static void launch_bwd_t(const BwdArgs& P, hipStream_t s) {
+static int launch_bwd_t(const BwdArgs& P, hipStream_t s) {
   if (P.a.convT_gout) {
-    if constexpr (KS != 2) abort();
+    if constexpr (KS != 2) {
+      set_error("dvae_fc_chain_bwd: the conv ends need the 512-thread variants");
+      return -1;
+    }
     if constexpr (KS == 2) {
       constexpr int lds = ChainLds<KS, RG, true>::TOTAL * (int)sizeof(float);
       static DeviceOnce attr;
       if (attr.first())
         (void)hipFuncSetAttribute((const void*)k_fc_chain_bwd<DEPTH, KS, RG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL((k_fc_chain_bwd<DEPTH, KS, RG, true>), dim3((P.a.n + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), lds, s, P);
-      return;
+      return 0;
     }
   }
   constexpr int lds = ChainLds<KS, RG, false>::TOTAL * (int)sizeof(float);
   hipLaunchKernelGGL((k_fc_chain_bwd<DEPTH, KS, RG, false>), dim3((P.a.n + 4 * RG - 1) / (4 * RG)), dim3(256 * KS), lds, s, P);
+  return 0;
 }
 
 int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s) {
@@ -788,18 +796,19 @@ int launch_fc_chain_fwd(const dvae_fc_chain_fwd_args* a, hipStream_t s) {
   P.a = *a;
   static const int variant = env_int("DVAE_FCC_VARIANT", 0) % 100;
   const bool r4 = fc_chain_rows(a->n_enc) == 4;
+  int rc = 0;
   switch (variant) {
 #ifdef DVAE_DEBUG_SWITCHES
-    case 81: if (r4) launch_fwd_t<8, 1, 1>(P, s); else launch_fwd_t<8, 1, 2>(P, s); break;
-    case 82: if (r4) launch_fwd_t<8, 2, 1>(P, s); else launch_fwd_t<8, 2, 2>(P, s); break;
-    case 161: if (r4) launch_fwd_t<16, 1, 1>(P, s); else launch_fwd_t<16, 1, 2>(P, s); break;
-    case 162: if (r4) launch_fwd_t<16, 2, 1>(P, s); else launch_fwd_t<16, 2, 2>(P, s); break;
+    case 81: rc = r4 ? launch_fwd_t<8, 1, 1>(P, s) : launch_fwd_t<8, 1, 2>(P, s); break;
+    case 82: rc = r4 ? launch_fwd_t<8, 2, 1>(P, s) : launch_fwd_t<8, 2, 2>(P, s); break;
+    case 161: rc = r4 ? launch_fwd_t<16, 1, 1>(P, s) : launch_fwd_t<16, 1, 2>(P, s); break;
+    case 162: rc = r4 ? launch_fwd_t<16, 2, 1>(P, s) : launch_fwd_t<16, 2, 2>(P, s); break;
 #endif
     default:
-      if (r4) launch_fwd_t<FCC_R4_DEPTH, 2, 1>(P, s);
-      else launch_fwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10, 2>(P, s);
+      rc = r4 ? launch_fwd_t<FCC_R4_DEPTH, 2, 1>(P, s) : launch_fwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10, 2>(P, s);
       break;
   }
+  if (rc != 0) return rc;
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -809,18 +818,19 @@ int launch_fc_chain_bwd(const dvae_fc_chain_bwd_args* a, hipStream_t s) {
   P.a = *a;
   static const int variant = env_int("DVAE_FCC_VARIANT", 0) % 100;
   const bool r4 = fc_chain_rows(a->n) == 4;
+  int rc = 0;
   switch (variant) {
 #ifdef DVAE_DEBUG_SWITCHES
-    case 81: if (r4) launch_bwd_t<8, 1, 1>(P, s); else launch_bwd_t<8, 1, 2>(P, s); break;
-    case 82: if (r4) launch_bwd_t<8, 2, 1>(P, s); else launch_bwd_t<8, 2, 2>(P, s); break;
-    case 161: if (r4) launch_bwd_t<16, 1, 1>(P, s); else launch_bwd_t<16, 1, 2>(P, s); break;
-    case 162: if (r4) launch_bwd_t<16, 2, 1>(P, s); else launch_bwd_t<16, 2, 2>(P, s); break;
+    case 81: rc = r4 ? launch_bwd_t<8, 1, 1>(P, s) : launch_bwd_t<8, 1, 2>(P, s); break;
+    case 82: rc = r4 ? launch_bwd_t<8, 2, 1>(P, s) : launch_bwd_t<8, 2, 2>(P, s); break;
+    case 161: rc = r4 ? launch_bwd_t<16, 1, 1>(P, s) : launch_bwd_t<16, 1, 2>(P, s); break;
+    case 162: rc = r4 ? launch_bwd_t<16, 2, 1>(P, s) : launch_bwd_t<16, 2, 2>(P, s); break;
 #endif
     default:
-      if (r4) launch_bwd_t<FCC_R4_DEPTH, 2, 1>(P, s);
-      else launch_bwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10, 2>(P, s);
+      rc = r4 ? launch_bwd_t<FCC_R4_DEPTH, 2, 1>(P, s) : launch_bwd_t<FCC_DEFAULT_VARIANT / 10, FCC_DEFAULT_VARIANT % 10, 2>(P, s);
       break;
   }
+  if (rc != 0) return rc;
   DVAE_CHECK_LAUNCH();
   return 0;
 }

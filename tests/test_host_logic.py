@@ -482,3 +482,30 @@ def test_any_latent_dim_is_accepted_for_every_loss(loss):
     st = defaultdict(list)
     type(loss_f)._store_kl(st, vals, 10)
     assert st["kl_loss_0"] == [_lib.S_KL0] and st["kl_loss_9"] == [_lib.S_KL0 + 9]
+
+
+def test_round6_schedule_policies():
+    """Host-side decisions of round 6, no kernels: which steps carry the 8x8 <-> 4x4 conv layers inside the FC-chain launches
+    (engine.fuse_ends, up to fuse_ends_max_rows rows; never above 16 latents, where there is no chain launch), which steps put
+    their weight gradients on two side streams (FactorVAE from 2048 rows, the other losses never) and where convT3's weight
+    gradient is forked; the dvae_fc_chain_*_args structs carry the conv-end fields behind the version-108 ones."""
+    from disvae_amd import _lib
+    from disvae_amd.engine import VAEEngine
+
+    def engine(img, D):          # (model.engine refuses on a CPU model: the engine object itself is host-side state only)
+        m = init_specific_model("Burgess", img, D)
+        return VAEEngine(m.img_size, m.latent_dim, m.arena)
+    eng = engine((3, 64, 64), 10)
+    assert eng.fuse_ends and eng.fuse_ends_max_rows == 256 and eng.early_thin_wgrad == 1 and not eng.three_streams
+    assert eng._ends(1) and eng._ends(256) and not eng._ends(257) and not eng._ends(1024)
+    assert engine((1, 32, 32), 10).fuse_ends          # conv3 / convT1 are that geometry's 4x4 end
+    assert not engine((3, 64, 64), 17).fuse_ends      # per-layer FC launches above 16 latents
+    eng.three_streams = True
+    assert eng._three(True) and not eng._three(False)
+    eng.single_stream = True
+    assert not eng._three(True)
+    assert L.BaseLoss.THREE_STREAM_MIN_ROWS > 1 << 20 and L.FactorKLoss.THREE_STREAM_MIN_ROWS == 2048
+    f = [n for n, _ in _lib.FcChainFwdArgs._fields_]
+    b = [n for n, _ in _lib.FcChainBwdArgs._fields_]
+    assert f[-6:] == ["conv_in", "conv_w", "conv_b", "convT_w", "convT_b", "convT_out"] and f[-7] == "D"
+    assert b[-6:] == ["convT_gout", "convT_w", "d3", "conv_w", "conv_act", "conv_gin"] and b[-7] == "D"
