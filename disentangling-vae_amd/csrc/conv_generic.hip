@@ -89,6 +89,112 @@ __global__ void k_up_generic(const float* __restrict__ small, Strides ss, const 
   }
 }
 
+// ---- the thin ends at ANY spatial size (round 6) -------------------------------------------------------------------------
+// conv1 (Cb -> 32), convT3's input gradient (the same product with a mask) and convT3 forward (32 -> Cb) of images the tuned
+// 64x64 kernels do not cover -- the 32x32 geometry of BASELINE configs[0] -- took 21 / 21 / 44 us per launch at 64 images on
+// the kernels above: one thread per output ELEMENT, every operand a strided scalar load from global memory
+// (profiles/r05_v33_mnist_generic_wgrad.txt).  Here the weights sit in LDS, a thread of the down kernel owns 4 consecutive output
+// channels of a pixel (its 16 Cb input values loaded once, one 16-byte store) and a thread of the up kernel reads its <= 4
+// contributing pixels as 16-byte chunks.  Every output is the SAME fmaf chain as in k_down_generic / k_up_generic (bias, then
+// cb / kh / kw resp. kh / kw / cs ascending): results are bit-identical (DVAE_FORCE_GENERIC=1 still selects the plain kernels:
+// tests/test_gpu_kernels.py::test_thin_ends_at_any_size_match_the_plain_generic_kernels).
+template <int CB>
+__global__ __launch_bounds__(256) void k_down_thin_px(const float* __restrict__ big, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, const float* __restrict__ mask,
+                                                      float* __restrict__ out, int N, int Hs, int Ws, int act) {
+  __shared__ float wl[32 * CB * 16];               // w[cs][cb][kh][kw] as it is
+  for (int e = threadIdx.x; e < 32 * CB * 16; e += 256) wl[e] = w[e];
+  __syncthreads();
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  const long total = (long)N * Hs * Ws * 8;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int q = idx & 7;
+    long r = idx >> 3;
+    const int sx = r % Ws; r /= Ws;
+    const int sy = r % Hs;
+    const int n = r / Hs;
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = bias ? bias[4 * q + j] : 0.f;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const float* bp = big + ((long)n * CB + cb) * Hb * Wb;
+#pragma unroll
+      for (int kh = 0; kh < 4; ++kh) {
+        const int by = 2 * sy - 1 + kh;
+        if (by < 0 || by >= Hb) continue;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          const int bx = 2 * sx - 1 + kw;
+          if (bx < 0 || bx >= Wb) continue;
+          const float v = bp[by * Wb + bx];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, wl[((4 * q + j) * CB + cb) * 16 + kh * 4 + kw], acc[j]);
+        }
+      }
+    }
+    const long o = (((long)n * Hs + sy) * Ws + sx) * 32 + 4 * q;
+    f32x4 res;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) res[j] = act == DVAE_ACT_SIGMOID ? sigmoid_exact(acc[j]) : apply_act(acc[j], act);
+    if (mask) {
+      const f32x4 m = *reinterpret_cast<const f32x4*>(mask + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) res[j] = m[j] > 0.f ? res[j] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(out + o) = res;
+  }
+}
+
+template <int CB>
+__global__ __launch_bounds__(256) void k_up_thin_px(const float* __restrict__ small, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, const float* __restrict__ mask,
+                                                    float* __restrict__ out, Strides so, int out_nhwc, int N, int Hs, int Ws,
+                                                    int act) {
+  __shared__ __attribute__((aligned(16))) float wl[CB * 16 * 32];   // [cb][tap][cs]
+  for (int e = threadIdx.x; e < 32 * CB * 16; e += 256) {
+    const int cs = e / (CB * 16), rem = e % (CB * 16);              // w[cs][cb][tap]: rem = cb * 16 + tap
+    wl[rem * 32 + cs] = w[e];
+  }
+  __syncthreads();
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  const long total = (long)N * CB * Hb * Wb;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    int n, cb, by, bx;
+    long r = idx;
+    if (out_nhwc) { cb = r % CB; r /= CB; bx = r % Wb; r /= Wb; by = r % Hb; n = r / Hb; }
+    else { bx = r % Wb; r /= Wb; by = r % Hb; r /= Hb; cb = r % CB; n = r / CB; }
+    float acc = bias ? bias[cb] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+      const int t = by + 1 - kh;
+      if (t < 0 || (t & 1)) continue;
+      const int sy = t >> 1;
+      if (sy >= Hs) continue;
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw) {
+        const int u = bx + 1 - kw;
+        if (u < 0 || (u & 1)) continue;
+        const int sx = u >> 1;
+        if (sx >= Ws) continue;
+        const float* sp = small + (((long)n * Hs + sy) * Ws + sx) * 32;
+        const float* wp = wl + (cb * 16 + kh * 4 + kw) * 32;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 4 * c4);
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + 4 * c4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = fmaf(sv[j], wv[j], acc);
+        }
+      }
+    }
+    const long o = n * so.n + cb * so.c + by * so.h + bx * so.w;
+    if (act == DVAE_ACT_SIGMOID) acc = sigmoid_exact(acc); else acc = apply_act(acc, act);
+    if (mask) acc = mask[o] > 0.f ? acc : 0.f;
+    out[o] = acc;
+  }
+}
+
 // one block per (cs, cb): 16 taps reduced over all (n, sy, sx)
 __global__ __launch_bounds__(256) void k_wgrad_generic(const float* __restrict__ big, Strides sb,
                                                        const float* __restrict__ small, Strides ss,
@@ -232,6 +338,16 @@ int launch_down_generic(const ConvArgs& a, hipStream_t s) {
   Strides sb = make_strides(a.big_layout, a.Cb, 2 * a.Hs, 2 * a.Ws);
   Strides so = make_strides(a.out_layout, a.Cs, a.Hs, a.Ws);
   long total = (long)a.N * a.Cs * a.Hs * a.Ws;
+#ifndef THIN_PX_OFF   // (variant builds: the A/B partner)
+  if (!use_generic_only() && a.Cs == 32 && (a.Cb == 1 || a.Cb == 3) && a.big_layout == DVAE_NCHW && a.out_layout == DVAE_NHWC &&
+      (((uintptr_t)a.out | (uintptr_t)a.mask) & 15) == 0) {
+    const int grid = grid_for((long)a.N * a.Hs * a.Ws * 8, 256);
+    if (a.Cb == 1) hipLaunchKernelGGL(k_down_thin_px<1>, dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.Hs, a.Ws, a.act);
+    else hipLaunchKernelGGL(k_down_thin_px<3>, dim3(grid), dim3(256), 0, s, a.big, a.w, a.bias, a.mask, a.out, a.N, a.Hs, a.Ws, a.act);
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   hipLaunchKernelGGL(k_down_generic, dim3(grid_for(total, 256)), dim3(256), 0, s, a.big, sb, a.w, a.bias,
                      a.mask, a.out, so, a.out_layout == DVAE_NHWC, a.N, a.Cb, a.Cs, a.Hs, a.Ws, a.act);
   DVAE_CHECK_LAUNCH();
@@ -242,6 +358,15 @@ int launch_up_generic(const ConvArgs& a, hipStream_t s) {
   Strides ss = make_strides(a.small_layout, a.Cs, a.Hs, a.Ws);
   Strides so = make_strides(a.out_layout, a.Cb, 2 * a.Hs, 2 * a.Ws);
   long total = (long)a.N * a.Cb * 4 * a.Hs * a.Ws;
+#ifndef THIN_PX_OFF
+  if (!use_generic_only() && a.Cs == 32 && (a.Cb == 1 || a.Cb == 3) && a.small_layout == DVAE_NHWC && ((uintptr_t)a.small & 15) == 0) {
+    const int grid = grid_for(total, 256);
+    if (a.Cb == 1) hipLaunchKernelGGL(k_up_thin_px<1>, dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.mask, a.out, so, a.out_layout == DVAE_NHWC, a.N, a.Hs, a.Ws, a.act);
+    else hipLaunchKernelGGL(k_up_thin_px<3>, dim3(grid), dim3(256), 0, s, a.small, a.w, a.bias, a.mask, a.out, so, a.out_layout == DVAE_NHWC, a.N, a.Hs, a.Ws, a.act);
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
   hipLaunchKernelGGL(k_up_generic, dim3(grid_for(total, 256)), dim3(256), 0, s, a.small, ss, a.w, a.bias,
                      a.mask, a.out, so, a.out_layout == DVAE_NHWC, a.N, a.Cb, a.Cs, a.Hs, a.Ws, a.act);
   DVAE_CHECK_LAUNCH();

@@ -493,3 +493,35 @@ def test_data_parallel_glue_kernels():
         sd, dd = dev(src), dev(torch.zeros(Bn, A, inner))
         call("dvae_swap_outer", ptr(sd), ptr(dd), A, Bn, inner, stream())
         assert torch.equal(dd.cpu(), src.permute(1, 0, 2).contiguous()), (A, Bn, inner)
+
+
+@pytest.mark.parametrize("N,C,H", [(3, 1, 32), (64, 1, 32), (5, 3, 32), (9, 1, 16), (2, 3, 24), (70, 3, 32)])
+def test_thin_ends_at_any_size_match_the_plain_generic_kernels(N, C, H):
+    """The thin ends of images the tuned 64x64 kernels do not cover (BASELINE configs[0]: 32x32) run on k_down_thin_px /
+    k_up_thin_px (conv_generic.hip, round 6: weights in LDS, 16-byte accesses); every output is the same fmaf chain as in the
+    plain shape-generic kernels (DVAE_FORCE_GENERIC=1 selects those): conv1 forward (encoders.py:54,73), convT3's input
+    gradient and convT3 forward + sigmoid (decoders.py:65,82) bit for bit."""
+    Hs = H // 2
+    w1, b1 = dev(_rand(32, C, 4, 4, seed=1, scale=0.3)), dev(_rand(32, seed=2, scale=0.1))
+    wt, bt = dev(_rand(32, C, 4, 4, seed=3, scale=0.3)), dev(_rand(C, seed=4, scale=0.1))
+    x = dev(torch.rand(N, C, H, H, generator=torch.Generator().manual_seed(5)))
+    a = dev(torch.relu(_rand(N, Hs, Hs, 32, seed=6)))            # NHWC 32-channel activation (input of convT3 / mask of its dgrad)
+    dy = dev(_rand(N, C, H, H, seed=7))
+    outs = []
+    for generic in (True, False):
+        y = torch.full((N, Hs, Hs, 32), 7.0, device=DEV)
+        dx = torch.full((N, Hs, Hs, 32), 7.0, device=DEV)
+        rec = torch.full((N, C, H, H), 7.0, device=DEV)
+        with force_generic(generic):
+            call("dvae_conv4s2_fwd", ptr(x), _lib.NCHW, ptr(w1), ptr(b1), ptr(y), _lib.NHWC, N, C, H, H, 32, _lib.ACT_RELU, stream())
+            call("dvae_convT4s2_dgrad", ptr(dy), _lib.NCHW, ptr(wt), ptr(a), ptr(dx), _lib.NHWC, N, 32, Hs, Hs, C, stream())
+            call("dvae_convT4s2_fwd", ptr(a), _lib.NHWC, ptr(wt), ptr(bt), ptr(rec), _lib.NCHW, N, 32, Hs, Hs, C, _lib.ACT_SIGMOID,
+                 stream())
+            torch.cuda.synchronize()
+        outs.append((y, dx, rec))
+    for g, t, what in zip(outs[0], outs[1], ("conv1 forward", "convT3 input gradient", "convT3 forward + sigmoid")):
+        assert torch.equal(g, t), what
+    assert float(outs[0][0].abs().max()) > 0 and float(outs[0][1].abs().max()) > 0
+    ref = torch.sigmoid(torch.nn.functional.conv_transpose2d(a.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), bt.double().cpu(),
+                                                             stride=2, padding=1))
+    check(outs[1][2], ref, rtol=1e-5, atol_rel=2e-6, what="convT3 forward vs fp64")
