@@ -163,8 +163,10 @@ class BaseLoss(abc.ABC):
     AUTO_PLAN_ELEMS = 256 * 3 * 64 * 64
     # one HIP stream instead of two below this many input elements per step (engine.single_stream); DVAE_STREAMS=1|2 forces
     # (round 2 measured the cross-over at 64 images, profiles/r02_run10_streams.txt; with the round-5 schedule two streams win at
-    # 32 and 64 images as well: 0.291 / 0.301 against 0.338 / 0.346 ms, profiles/r05_v26_sweep.txt)
-    SINGLE_STREAM_ELEMS = int(knob("DVAE_SINGLE_STREAM_ELEMS", 16 * 3 * 64 * 64))
+    # 32 and 64 images as well: 0.291 / 0.301 against 0.338 / 0.346 ms, profiles/r05_v26_sweep.txt; round 6: at 4 / 8 / 16 images
+    # too -- 0.306 -> 0.267, 0.312 -> 0.271, 0.315 -> 0.277 ms -- and at the 32x32 geometry level at 16 / 64 images, -3 % at 128:
+    # profiles/r06_s2_streams_small.txt.  Two streams at every size.)
+    SINGLE_STREAM_ELEMS = int(knob("DVAE_SINGLE_STREAM_ELEMS", 0))
 
     # dependency-driven weight-gradient schedule (engine.eager_wgrad: a fork per layer) up to this many input elements per
     # step; above, the batch-sized schedule (two forks per half of the backward pass).  Round 3 measured the two within noise
