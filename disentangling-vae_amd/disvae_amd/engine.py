@@ -283,9 +283,14 @@ class VAEEngine:
         # (same box, three alternations, profiles/r06_s2_chain3.txt: factor 64x64x1 tensor 256 0.590 -> 0.569 ms, btcvae 64x64x3 at
         # 64 / 128 / 256 images 0.311 -> 0.302, 0.347 -> 0.344, 0.450 -> 0.447 ms); from 512 rows up the fused launches -- 150 KB
         # of LDS, a whole CU per workgroup -- can no longer slip in beside the other stream's persistent kernels the way the
-        # small conv launches do: 0.643 -> 0.652 ms at 512 images, 1.060 -> 1.082 ms at 1024 (profiles/r06_s2_chain2.txt)
+        # small conv launches do: 0.643 -> 0.652 ms at 512 images, 1.060 -> 1.082 ms at 1024 (profiles/r06_s2_chain2.txt) -- in
+        # the BACKWARD pass, that is (fuse_ends_max_rows); the forward chain has its own limit below
         self.fuse_ends = not _lib.wide(latent_dim) and knob("DVAE_FUSE_ENDS", "1") != "0"   # (A/B knob: DVAE_DEBUG=1 only)
         self.fuse_ends_max_rows = int(knob("DVAE_FUSE_ENDS_MAX_ROWS", "256"))
+        # the FORWARD chain's own limit: beside it the other stream carries only the estimator's small kernels, nothing a 150 KB
+        # workgroup could block -- 384 / 512 / 1024 images 0.545 -> 0.543, 0.631 -> 0.629, 1.039 -> 1.030 ms; level at 2048 rows,
+        # where the 8-row variant runs (profiles/r06_s2_fwd_ends.txt)
+        self.fuse_ends_max_rows_fwd = int(knob("DVAE_FUSE_ENDS_MAX_ROWS_FWD", "1024"))
         # Round 6: convT3's weight gradient (bandwidth-bound) is forked one kernel earlier -- behind convT3's input gradient, beside
         # the matrix-bound input gradient of convT2 -- instead of behind both.  The side stream's serial chain of weight gradients
         # is what small steps end on, and it now starts ~15 us sooner: 128 / 256 images 0.341 -> 0.330, 0.443 -> 0.431 ms,
@@ -470,7 +475,7 @@ class VAEEngine:
         c, H, _ = self.img_size
         src, h = x, H
         last = len(self.enc_names) - 1
-        self._ends_on = chain and self._ends(B)
+        self._ends_on = chain and self.fuse_ends and B <= self.fuse_ends_max_rows_fwd
         for k, (name, act) in enumerate(zip(self.enc_names, buf.enc_act)):
             if self._ends_on and k == last:
                 break

@@ -392,12 +392,13 @@ def test_replay_matches_eager(loss, mode):
 
 
 @pytest.mark.parametrize("loss,img,B", [("btcvae", (3, 64, 64), 16), ("factor", (1, 64, 64), 24), ("VAE", (1, 32, 32), 9),
-                                        ("betaB", (3, 64, 64), 300)])
+                                        ("betaB", (3, 64, 64), 300), ("betaH", (1, 64, 64), 1100)])
 def test_conv_ends_inside_the_chain_launches_change_nothing(loss, img, B):
     """engine.fuse_ends (the 8x8 <-> 4x4 layers and their input gradients as prologue / epilogue of dvae_fc_chain_fwd / _bwd,
     up to engine.fuse_ends_max_rows rows per step; encoders.py:76-81, decoders.py:73-76) against the same steps with those four
-    layers as launches of their own: same arithmetic, so losses and parameters after 4 steps are bit-identical.  B = 300 is above
-    the row limit: both runs take the separate launches (the limit is honoured)."""
+    layers as launches of their own: same arithmetic, so losses and parameters after 4 steps are bit-identical.  The row limits
+    are honoured: up to 256 rows both directions carry the conv ends (4 launches fewer per step), up to 1024 rows the forward
+    chain only (2 fewer), above that none."""
     D = 10
     runs = []
     for fuse in (False, True):
@@ -436,10 +437,10 @@ def test_conv_ends_inside_the_chain_launches_change_nothing(loss, img, B):
         runs.append((losses, model.arena.flat.clone(), model.arena.grad.clone(), len(seen)))
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
-    if B <= 256:                                # (factor: the forward chain runs over both halves = B rows)
-        assert runs[1][3] < runs[0][3], "fused steps must issue fewer launches (%d vs %d)" % (runs[1][3], runs[0][3])
-    else:
-        assert runs[1][3] == runs[0][3]
+    # (factor: the forward chain runs over both halves = B rows, the backward chain over B / 2)
+    fwd = 2 if B <= 1024 else 0
+    bwd = 2 if (B // 2 if loss == "factor" else B) <= 256 else 0
+    assert runs[0][3] - runs[1][3] == 4 * (fwd + bwd), (runs[0][3], runs[1][3])
 
 
 @pytest.mark.parametrize("mode", ["plan", "graph"])
