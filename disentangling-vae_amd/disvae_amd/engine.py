@@ -301,6 +301,12 @@ class VAEEngine:
         # small steps: the weight gradients on TWO side streams, each launched at the first fork behind the kernel that produces
         # its last operand (_decode_backward_3s / _encode_backward_3s).  Set per step by the loss plugins (BaseLoss._streams).
         self.three_streams = False
+        # steps of 129-320 images end on the side stream (its weight-gradient grid is the smaller one there, conv_wgrad_ws.hip): the
+        # grouped FC weight gradients become the LAST launch of the main stream's tail instead -- 256 images 0.425 -> 0.415 ms,
+        # btcvae 64x64x1 B = 256 0.386 -> 0.375; outside that band the main stream is the tail already: 64 / 128 / 512 / 1024
+        # images +1.3 / +1.4 / +2.1 / +0.6 % (profiles/r06_s2_fcw_main.txt)
+        self.fcw_main = knob("DVAE_FCW_MAIN", "1") == "1"
+        self.fcw_main_rows = (129, 320)
         self._ends_on = False  # this forward pass: set by encode_convs(chain=True), read by fc_chain_fwd / decode_convs
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
         self._fc_descs = {}    # host descriptor arrays / argument structs of launches, kept alive for recorded plans
@@ -913,7 +919,11 @@ class VAEEngine:
         fused_end = bool(fc_chain) and self._ends(B)        # conv_64's input gradient: fc_chain_bwd's epilogue wrote enc_gact[2]
         if self._three(bool(fc_chain)) and len(pend) == 3:
             return self._encode_backward_3s(x, buf, B, fc, fused_end)
-        deferred = [lambda fc=fc: self._side_wgrad_grouped(fc)]
+        # the grouped FC weight gradients: side stream (in front of conv2's weight gradient) -- or, fcw_main, the LAST launch of the
+        # main stream's tail (a step of a few hundred images ends on the side stream: profiles/r06_final4_dsprites_timeline.md)
+        fcw_main = (self.fcw_main and self.is64 and not self.single_stream
+                    and self.fcw_main_rows[0] <= B <= self.fcw_main_rows[1])
+        deferred = [] if fcw_main else [lambda fc=fc: self._side_wgrad_grouped(fc)]
         tail_main = []                      # weight gradients the main stream computes after conv1's (load balance of the tail)
         last = len(self.enc_names) - 1
         if eager:
@@ -971,6 +981,8 @@ class VAEEngine:
                     self._conv_wgrad(*wargs, fork=False, main=True)
                 for w_ in tail_main:
                     self._conv_wgrad(*w_, fork=False, main=True)
+                if fcw_main:
+                    self._side_wgrad_grouped(fc, stream=s)
             elif name in self.tail_main and self.is64 and not self.single_stream:
                 tail_main.append(wargs)
             elif big:
