@@ -746,6 +746,10 @@ class VAEEngine:
         # and leaves most CUs idle -- so the big weight gradients are forked THERE (fork 1, after the last
         # big dgrad), and the rest after the FC dgrads (fork 2).  Every fork costs this stream ~6 us.
         eager = self.eager_wgrad and not self.single_stream
+        # where convT3's weight gradient is forked (early_thin_wgrad): behind its input gradient -- or, at the 128 images of one
+        # rank of the 8-GPU headline configuration, in FRONT of it (beside it): 0.332 -> 0.325 ms there, level at 32 / 64, +1.3 %
+        # at 96, +1.6 % at 256 images (profiles/r06_s2_sched3.txt, r06_s2_sched4.txt)
+        early_mode = 2 if (self.early_thin_wgrad == 1 and 112 <= B <= 128) else self.early_thin_wgrad
         three = self._three(fc_chain is not None) and defer_fc_wgrad and not join
         pending, deferred, queued = [], [], []
         W3 = {}                                  # three-queue schedule: every layer's weight-gradient launch, by layer
@@ -760,7 +764,7 @@ class VAEEngine:
                 # both operands of this layer's weight gradient exist (dy: the previous input gradient or g_logit): side
                 # stream, now, beside this layer's input gradient
                 self._conv_wgrad(*wargs, fork=True)
-            elif self.early_thin_wgrad == 2 and h == 32 and not self.single_stream:
+            elif early_mode == 2 and h == 32 and not self.single_stream:
                 self.fork_side()                 # (its launch follows this stream's next kernel, like every side launch)
                 queued.append(wargs)
             else:
@@ -801,7 +805,7 @@ class VAEEngine:
             for w_ in queued:                    # side launches of the previous fork, issued AFTER this stream's next kernel
                 self._conv_wgrad(*w_, fork=False)
             queued = []
-            early = self.early_thin_wgrad == 1 and h == 32 and pending and not self.single_stream
+            early = early_mode == 1 and h == 32 and pending and not self.single_stream
             if h == 16 or (k == 0 and pending) or early:  # last big dgrad is enqueued: its inputs and those of `pending` are final
                 self.fork_side()
                 queued, pending = pending, []
