@@ -295,11 +295,13 @@ class VAEEngine:
         # the matrix-bound input gradient of convT2 -- instead of behind both.  The side stream's serial chain of weight gradients
         # is what small steps end on, and it now starts ~15 us sooner: 128 / 256 images 0.341 -> 0.330, 0.443 -> 0.431 ms,
         # btcvae 64x64x1 B = 256 0.412 -> 0.398, 1024 images 1.054 -> 1.048 ms (profiles/r06_s2_sched2.txt).  Mode 2 (in FRONT of
-        # convT3's input gradient) wins another 1 % at 128 images and loses 1.6 % at 256, 0.7 % at 1024 (r06_s2_sched3.txt): not used.
+        # convT3's input gradient) wins another 1-2 % at 128 images and loses 1.6 % at 256, 0.7 % at 1024 (r06_s2_sched3.txt): used at
+        # 112-128 images only (decode_backward).
         # Moving the main stream's tail (tail_main) to the side stream loses 2-8 % at every small batch (same file).
         self.early_thin_wgrad = int(knob("DVAE_EARLY_THIN", "1"))     # (A/B knob: DVAE_DEBUG=1 only)
-        # small steps: the weight gradients on TWO side streams, each launched at the first fork behind the kernel that produces
-        # its last operand (_decode_backward_3s / _encode_backward_3s).  Set per step by the loss plugins (BaseLoss._streams).
+        # the weight gradients on TWO side streams, each launched at the first fork behind the kernel that produces its last operand
+        # (decode_backward's `three` branch / _encode_backward_3s).  Set per step by the loss plugins (BaseLoss._streams: FactorVAE
+        # from 2048 rows; slower for every other step measured).
         self.three_streams = False
         # steps of 129-320 images end on the side stream (its weight-gradient grid is the smaller one there, conv_wgrad_ws.hip): the
         # grouped FC weight gradients become the LAST launch of the main stream's tail instead -- 256 images 0.425 -> 0.415 ms,
