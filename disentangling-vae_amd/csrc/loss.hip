@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void k_recon_loss(const float* __restrict__ re
 }
 
 // ---- beta-TCVAE ------------------------------------------------------------------------------
+#define BTC_WG_MAX_ROWS 512      // local rows up to which the backward passes run a workgroup per row / column
 __device__ __forceinline__ float log_w_ij(int i, int j, int Bg, float lN, float lS, float lM) {
   // math.py:66-72 with M+1 == B: column 0 <- 1/N, column 1 <- strat, then W[M-1,0] <- strat
   if (j == 0) return (i == Bg - 2) ? lS : lN;
@@ -357,6 +358,136 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_cols(const float* __restrict
       dmu[(long)j * D + d] = a;
       dlv[(long)j * D + d] = b;
     }
+  }
+}
+
+// row pass with one WORKGROUP (4 waves) per local row i (round 6; up to BTC_WG_MAX_ROWS local rows): the columns j are split over
+// 256 lanes, so a lane walks Bg / 256 columns instead of Bg / 64 -- the kernel is a chain of dependent L2 round trips, not
+// arithmetic -- and the four waves' sums are added in a fixed order through LDS.  One rank of eight of the headline configuration
+// (128 local rows x 1024 columns): 0.372 -> 0.365 ms per sharded step; 256 x 256: 0.375 -> 0.373; 1024 x 1024 level, 2048 x 2048
+// 1 % slower (four times the workgroups beside the decoder's kernels): profiles/r06_s2_est1.txt.
+template <int DT>
+__global__ __launch_bounds__(256) void k_btcvae_bwd_rows_wg(const float* __restrict__ z, const float* __restrict__ mu,
+                                                         const float* __restrict__ lv, const float* __restrict__ tmp,
+                                                         const float* __restrict__ rowstats,
+                                                         int Bg, int row0, int Bl, int is_mss,
+                                                         const float* __restrict__ log_w, const float* __restrict__ coef,
+                                                         float* __restrict__ dz, int Drt) {
+  constexpr int DM = DT ? DT : 16;          // DT = 0: latent dimension given at run time (<= 16)
+  const int D = DT ? DT : Drt;
+  __shared__ float red[4][DM];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int il = blockIdx.x;
+  const int i = row0 + il;
+  const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
+  const float alpha = coef[DVAE_C_ALPHA], beta = coef[DVAE_C_BETA], gam = coef[DVAE_C_GAMMA] * coef[DVAE_C_ANNEAL];
+  const float invB = 1.f / (float)Bg;
+  const float cP = (beta - alpha) * invB, cQ = (gam - beta) * invB;
+  const float* muT = tmp; const float* cT = tmp + (long)D * Bg; const float* ivT = tmp + (long)2 * D * Bg;
+  const float* rs = rowstats + (long)il * DVAE_ROWSTATS;
+  const float lqz = rs[1];
+  float zi[DM], lse[DM], g[DM];
+#pragma unroll
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) { zi[d] = z[(long)i * D + d]; lse[d] = rs[4 + d]; g[d] = 0.f; }
+#pragma unroll 2
+  for (int j = threadIdx.x; j < Bg; j += 256) {
+    const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
+    float ld[DM], r[DM];
+    float S = 0.f;
+#pragma unroll
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
+      const float iv = ivT[(long)d * Bg + j];
+      const float diff = zi[d] - muT[(long)d * Bg + j];
+      r[d] = diff * iv;
+      ld[d] = (cT[(long)d * Bg + j] - 0.5f * (diff * diff * iv)) + lw;
+      S += ld[d];
+    }
+    const float P = __expf(S - lqz);
+#pragma unroll
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
+      const float G = cP * P + cQ * __expf(ld[d] - lse[d]);
+      g[d] -= G * r[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
+    const float v = wave_sum(g[d]);
+    if (lane == 0) red[wv][d] = v;
+  }
+  __syncthreads();
+  const int d = threadIdx.x;
+  if (d < D) {
+    // diagonal terms: alpha * log q(z_i|x_i) / B  and  -gamma' * log p(z_i) / B
+    const float gs = (red[0][d] + red[1][d]) + (red[2][d] + red[3][d]);
+    const float zd = z[(long)i * D + d];
+    const float m = mu[(long)i * D + d], l = lv[(long)i * D + d];
+    const float r = (zd - m) * expf(-l);
+    dz[(long)il * D + d] = gs - alpha * invB * r + gam * invB * zd;
+  }
+}
+
+// column pass with one WORKGROUP per column j (the rows are split over 256 lanes), fixed-order sum of the four waves through LDS
+template <int DT>
+__global__ __launch_bounds__(256) void k_btcvae_bwd_cols_wg(const float* __restrict__ z, const float* __restrict__ mu,
+                                                         const float* __restrict__ lv, const float* __restrict__ rowstats,
+                                                         int Bg, int row0, int Bl, int is_mss,
+                                                         const float* __restrict__ log_w, const float* __restrict__ coef,
+                                                         float* __restrict__ dmu, float* __restrict__ dlv, int Drt) {
+  constexpr int DM = DT ? DT : 16;          // DT = 0: latent dimension given at run time (<= 16)
+  const int D = DT ? DT : Drt;
+  __shared__ float red[4][2 * DM];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = blockIdx.x;
+  const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
+  const float alpha = coef[DVAE_C_ALPHA], beta = coef[DVAE_C_BETA], gam = coef[DVAE_C_GAMMA] * coef[DVAE_C_ANNEAL];
+  const float invB = 1.f / (float)Bg;
+  const float cP = (beta - alpha) * invB, cQ = (gam - beta) * invB;
+  float mj[DM], lj[DM], ivj[DM], gm[DM], gl[DM];
+#pragma unroll
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
+    mj[d] = mu[(long)j * D + d]; lj[d] = lv[(long)j * D + d]; ivj[d] = expf(-lj[d]); gm[d] = 0.f; gl[d] = 0.f;
+  }
+#pragma unroll 2
+  for (int il = threadIdx.x; il < Bl; il += 256) {
+    const int i = row0 + il;
+    const float* rs = rowstats + (long)il * DVAE_ROWSTATS;
+    const float lw = log_w_ij(i, j, Bg, lN, lS, lM);
+    float ld[DM], r[DM], diff[DM];
+    float S = 0.f;
+#pragma unroll
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
+      diff[d] = z[(long)i * D + d] - mj[d];
+      r[d] = diff[d] * ivj[d];
+      ld[d] = (-0.5f * (LOG2PI + lj[d]) - 0.5f * (diff[d] * diff[d] * ivj[d])) + lw;
+      S += ld[d];
+    }
+    const float P = __expf(S - rs[1]);
+#pragma unroll
+    for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
+      const float G = cP * P + cQ * __expf(ld[d] - rs[4 + d]);
+      gm[d] += G * r[d];
+      gl[d] += G * (-0.5f + 0.5f * r[d] * diff[d]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DM; ++d) if (DT != 0 || d < D) {
+    const float a = wave_sum(gm[d]), b = wave_sum(gl[d]);
+    if (lane == 0) { red[wv][2 * d] = a; red[wv][2 * d + 1] = b; }
+  }
+  __syncthreads();
+  const int d = threadIdx.x;
+  if (d < D) {
+    float a = (red[0][2 * d] + red[1][2 * d]) + (red[2][2 * d] + red[3][2 * d]);
+    float b = (red[0][2 * d + 1] + red[1][2 * d + 1]) + (red[2][2 * d + 1] + red[3][2 * d + 1]);
+    if (j >= row0 && j < row0 + Bl) {  // diagonal term alpha * log q(z_j|x_j) / B
+      const float m = mu[(long)j * D + d], iv = expf(-lv[(long)j * D + d]);
+      const float diff = z[(long)j * D + d] - m;
+      const float r = diff * iv;
+      a += alpha * invB * r;
+      b += alpha * invB * (-0.5f + 0.5f * r * diff);
+    }
+    dmu[(long)j * D + d] = a;
+    dlv[(long)j * D + d] = b;
   }
 }
 
@@ -644,12 +775,22 @@ int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const fl
   if (D < 1) return 1;
   if (D > DVAE_MAX_D)
     return launch_btcvae_bwd_wide(z, mu, lv, rowstats, Bg, D, row0, Bl, is_mss, log_w, coef, tmp, dz, dmu, dlv, s);
-  if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
+  // (a workgroup per row / column up to BTC_WG_MAX_ROWS local rows, a wave per row / column above: see k_btcvae_bwd_rows_wg)
+  const bool wg = Bl <= BTC_WG_MAX_ROWS;
+  if (wg && D == 10) hipLaunchKernelGGL(k_btcvae_bwd_rows_wg<10>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
+                                        is_mss, log_w, coef, dz, D);
+  else if (wg) hipLaunchKernelGGL(k_btcvae_bwd_rows_wg<0>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
+                                  is_mss, log_w, coef, dz, D);
+  else if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
                                   is_mss, log_w, coef, dz, D);
   else hipLaunchKernelGGL(k_btcvae_bwd_rows<0>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
                           is_mss, log_w, coef, dz, D);
   DVAE_CHECK_LAUNCH();
-  if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_cols<10>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
+  if (wg && D == 10) hipLaunchKernelGGL(k_btcvae_bwd_cols_wg<10>, dim3(Bg), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
+                                        is_mss, log_w, coef, dmu, dlv, D);
+  else if (wg) hipLaunchKernelGGL(k_btcvae_bwd_cols_wg<0>, dim3(Bg), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
+                                  is_mss, log_w, coef, dmu, dlv, D);
+  else if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_cols<10>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
                                   is_mss, log_w, coef, dmu, dlv, D);
   else hipLaunchKernelGGL(k_btcvae_bwd_cols<0>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
                           is_mss, log_w, coef, dmu, dlv, D);
