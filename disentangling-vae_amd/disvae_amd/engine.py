@@ -298,7 +298,10 @@ class VAEEngine:
         # convT3's input gradient) wins another 1-2 % at 128 images and loses 1.6 % at 256, 0.7 % at 1024 (r06_s2_sched3.txt): used at
         # 112-128 images only (decode_backward).
         # Moving the main stream's tail (tail_main) to the side stream loses 2-8 % at every small batch (same file).
-        self.early_thin_wgrad = int(knob("DVAE_EARLY_THIN", "1"))     # (A/B knob: DVAE_DEBUG=1 only)
+        _et = knob("DVAE_EARLY_THIN", "auto")                          # (A/B knob: DVAE_DEBUG=1 only: 0 / 1 / 2 force a mode)
+        self.early_thin_wgrad = 1 if _et == "auto" else int(_et)
+        self.early_thin_auto = _et == "auto"
+        self.sharded = False   # this step runs under data parallelism (set per step by the loss plugins, BaseLoss._streams)
         # the weight gradients on TWO side streams, each launched at the first fork behind the kernel that produces its last operand
         # (decode_backward's `three` branch / _encode_backward_3s).  Set per step by the loss plugins (BaseLoss._streams: FactorVAE
         # from 2048 rows; slower for every other step measured).
@@ -750,8 +753,9 @@ class VAEEngine:
         eager = self.eager_wgrad and not self.single_stream
         # where convT3's weight gradient is forked (early_thin_wgrad): behind its input gradient -- or, at the 128 images of one
         # rank of the 8-GPU headline configuration, in FRONT of it (beside it): 0.332 -> 0.325 ms there, level at 32 / 64, +1.3 %
-        # at 96, +1.6 % at 256 images (profiles/r06_s2_sched3.txt, r06_s2_sched4.txt)
-        early_mode = 2 if (self.early_thin_wgrad == 1 and 112 <= B <= 128) else self.early_thin_wgrad
+        # at 96, +1.6 % at 256 images (profiles/r06_s2_sched3.txt, r06_s2_sched4.txt).  Not under data parallelism: the fork carries the
+        # late epilogue with its collectives, whose host-side issue would then stand in front of convT3's input gradient
+        early_mode = 2 if (self.early_thin_auto and 112 <= B <= 128 and not self.sharded) else self.early_thin_wgrad
         three = self._three(fc_chain is not None) and defer_fc_wgrad and not join
         pending, deferred, queued = [], [], []
         W3 = {}                                  # three-queue schedule: every layer's weight-gradient launch, by layer

@@ -190,6 +190,7 @@ class BaseLoss(abc.ABC):
         single = mode == "1" or (mode == "auto" and data.numel() <= self.SINGLE_STREAM_ELEMS)
         model.engine.single_stream = bool(single) and self._world()[0] == 1
         model.engine.eager_wgrad = data.numel() <= int(knob("DVAE_EAGER_WGRAD_ELEMS", self.EAGER_WGRAD_ELEMS))
+        model.engine.sharded = self._world()[0] > 1
         model.engine.three_streams = (not single and self._world()[0] == 1
                                       and data.shape[0] >= int(knob("DVAE_THREE_STREAM_MIN_ROWS", self.THREE_STREAM_MIN_ROWS)))
         tm = knob("DVAE_TAIL_MAIN", "default")      # A/B (DVAE_DEBUG=1): which encoder weight gradients end the main stream
@@ -212,7 +213,7 @@ class BaseLoss(abc.ABC):
         return (id(model), data.shape, data.data_ptr(), injected, _stream(), model.arena.flat.data_ptr(),
                 model.arena.grad.data_ptr(), _lib.ALLOC_GEN[0], self.rec_dist, getattr(self, "is_mss", None),
                 model.engine.single_stream, model.engine.eager_wgrad, model.engine.tail_main, id(self.comm), self.estimator,
-                model.engine.three_streams)
+                model.engine.three_streams, model.engine.sharded)
 
     @abc.abstractmethod
     def __call__(self, data, recon_data, latent_dist, is_train, storer, **kwargs):

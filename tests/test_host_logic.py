@@ -497,7 +497,7 @@ def test_round6_schedule_policies():
         return VAEEngine(m.img_size, m.latent_dim, m.arena)
     eng = engine((3, 64, 64), 10)
     assert eng.fuse_ends and eng.fuse_ends_max_rows == 256 and eng.fuse_ends_max_rows_fwd == 1024
-    assert eng.early_thin_wgrad == 1 and not eng.three_streams
+    assert eng.early_thin_wgrad == 1 and eng.early_thin_auto and not eng.sharded and not eng.three_streams
     assert eng._ends(1) and eng._ends(256) and not eng._ends(257) and not eng._ends(1024)
     assert engine((1, 32, 32), 10).fuse_ends          # conv3 / convT1 are that geometry's 4x4 end
     assert not engine((3, 64, 64), 17).fuse_ends      # per-layer FC launches above 16 latents
