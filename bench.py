@@ -906,6 +906,8 @@ def main():
     ap.add_argument("--no-drop-in", action="store_true", help="skip the drop-in leg (Adam(model.parameters()) + a host "
                     "sync per iteration)")
     ap.add_argument("--shard-which", default="single,torch,rccl", help="subset of the shard legs (profiling)")
+    ap.add_argument("--shard-world", type=int, default=None, help="with --shard-legs: one rank of THIS many instead of eight "
+                    "(profiling the 2- and 4-GPU shards: 512 / 256 images per rank)")
     ap.add_argument("--shard-legs", action="store_true", help="only the shard legs of --config (btcvae_celeba, default, or "
                     "factor_celeba: one rank of eight -- single process, torch transport, rccl transport), print them, exit")
     ap.add_argument("--cpu-reference", action="store_true", help="no GPU needed: time the unmodified reference Trainer "
@@ -938,6 +940,9 @@ def main():
     device = torch.device("cuda", local_rank)
 
     if args.shard_legs:
+        if args.shard_world:
+            global SHARD_WORLD
+            SHARD_WORLD = int(args.shard_world)
         res = shard_legs(device, steps=args.steps, warmup=args.warmup, with_parity=not args.no_parity_check,
                          with_roofline=not args.no_roofline, which=tuple(args.shard_which.split(",")),
                          name=args.config or "btcvae_celeba")

@@ -182,8 +182,11 @@ class BaseLoss(abc.ABC):
     THREE_STREAM_MIN_ROWS = 1 << 30
     # sharded batches up to this many input elements per rank: ONE all-reduce of the whole gradient arena at the end instead of
     # two overlapped spans (the step is a latency chain; every collective costs the host and both streams more than the
-    # overlap of 1 MB buys)
-    SMALL_SHARD_ELEMS = 384 * 3 * 64 * 64
+    # overlap of 1 MB buys).  Round 6: at EVERY size -- as one rank of two (512 images) the two-span path takes 1.06-1.16 ms
+    # against 0.63 with one all-reduce (single process: 0.63), FactorVAE tensor 1024 / 512 per rank 1.31 / 0.93 against 1.18 / 0.83
+    # (profiles/r06_s2_shard_world.txt: mirrored world, C-ABI transport); the 2 MB arena is ~20 us of xGMI time, there is
+    # nothing worth overlapping.  (The spans stay reachable for A/B: DVAE_DEBUG=1 DVAE_SMALL_SHARD_ELEMS=<elements>.)
+    SMALL_SHARD_ELEMS = int(knob("DVAE_SMALL_SHARD_ELEMS", 1 << 40))
 
     def _streams(self, model, data):
         mode = knob("DVAE_STREAMS", "auto")
