@@ -1102,10 +1102,16 @@ def main():
         nimg = B if loss_name != "factor" else B // 2
         fams = kernel_rooflines(nimg, device)
         thin = thin_kernel_rooflines(nimg, C, device)
-        if not ddp and loss_name != "factor" and loss_f._replay_mode(True, data) is None:
-            # the durations the launches get INSIDE the timed step (eager issue) are what `achieved` / `frac` are computed from
-            # (FactorVAE: the encoder launches run over both halves, the decoder's over one -- its entries stay kernel-alone)
-            ins = in_step_durations(lambda: trainer._train_iteration_async(data, storer))
+        if not ddp and loss_name != "factor":
+            # the durations the launches get INSIDE the timed step are what `achieved` / `frac` are computed from (FactorVAE: the
+            # encoder launches run over both halves, the decoder's over one -- its entries stay kernel-alone).  The brackets sit
+            # in the host-side call path, so these iterations are issued eagerly (the same launches on the same streams as the
+            # recorded plan the timed loop replays up to 1024 images)
+            saved_replay, loss_f.replay = loss_f.replay, None
+            try:
+                ins = in_step_durations(lambda: trainer._train_iteration_async(data, storer))
+            finally:
+                loss_f.replay = saved_replay
             apply_in_step(fams, ins)
             apply_in_step(thin, ins)
             fams.sort(key=lambda r: -r["us_per_launch"] * len(r.get("launches", [1, 1])))

@@ -160,7 +160,10 @@ class BaseLoss(abc.ABC):
             t.copy_(like, non_blocking=True)
         return t
 
-    AUTO_PLAN_ELEMS = 256 * 3 * 64 * 64
+    # (round 6: up to 1024 images -- the same step time at 512 / 1024 images single process, 0.23-0.27 instead of 0.36 ms of host
+    # time per step; one rank of two of configs[3] (512 images through the sharded path) spends 0.55 ms of host per 0.63 ms step
+    # when it is issued eagerly: profiles/r06_s2_shard_world.txt)
+    AUTO_PLAN_ELEMS = 1024 * 3 * 64 * 64
     # one HIP stream instead of two below this many input elements per step (engine.single_stream); DVAE_STREAMS=1|2 forces
     # (round 2 measured the cross-over at 64 images, profiles/r02_run10_streams.txt; with the round-5 schedule two streams win at
     # 32 and 64 images as well: 0.291 / 0.301 against 0.338 / 0.346 ms, profiles/r05_v26_sweep.txt; round 6: at 4 / 8 / 16 images
