@@ -367,17 +367,16 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_cols(const float* __restrict
 // (128 local rows x 1024 columns): 0.372 -> 0.365 ms per sharded step; 256 x 256: 0.375 -> 0.373; 1024 x 1024 level, 2048 x 2048
 // 1 % slower (four times the workgroups beside the decoder's kernels): profiles/r06_s2_est1.txt.
 template <int DT>
-__global__ __launch_bounds__(256) void k_btcvae_bwd_rows_wg(const float* __restrict__ z, const float* __restrict__ mu,
-                                                         const float* __restrict__ lv, const float* __restrict__ tmp,
-                                                         const float* __restrict__ rowstats,
-                                                         int Bg, int row0, int Bl, int is_mss,
-                                                         const float* __restrict__ log_w, const float* __restrict__ coef,
-                                                         float* __restrict__ dz, int Drt) {
+__device__ __forceinline__ void btcvae_bwd_rows_wg_body(int il, const float* __restrict__ z, const float* __restrict__ mu,
+                                                        const float* __restrict__ lv, const float* __restrict__ tmp,
+                                                        const float* __restrict__ rowstats,
+                                                        int Bg, int row0, int Bl, int is_mss,
+                                                        const float* __restrict__ log_w, const float* __restrict__ coef,
+                                                        float* __restrict__ dz, int Drt) {
   constexpr int DM = DT ? DT : 16;          // DT = 0: latent dimension given at run time (<= 16)
   const int D = DT ? DT : Drt;
   __shared__ float red[4][DM];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int il = blockIdx.x;
   const int i = row0 + il;
   const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
   const float alpha = coef[DVAE_C_ALPHA], beta = coef[DVAE_C_BETA], gam = coef[DVAE_C_GAMMA] * coef[DVAE_C_ANNEAL];
@@ -428,16 +427,15 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_rows_wg(const float* __restr
 
 // column pass with one WORKGROUP per column j (the rows are split over 256 lanes), fixed-order sum of the four waves through LDS
 template <int DT>
-__global__ __launch_bounds__(256) void k_btcvae_bwd_cols_wg(const float* __restrict__ z, const float* __restrict__ mu,
-                                                         const float* __restrict__ lv, const float* __restrict__ rowstats,
-                                                         int Bg, int row0, int Bl, int is_mss,
-                                                         const float* __restrict__ log_w, const float* __restrict__ coef,
-                                                         float* __restrict__ dmu, float* __restrict__ dlv, int Drt) {
+__device__ __forceinline__ void btcvae_bwd_cols_wg_body(int j, const float* __restrict__ z, const float* __restrict__ mu,
+                                                        const float* __restrict__ lv, const float* __restrict__ rowstats,
+                                                        int Bg, int row0, int Bl, int is_mss,
+                                                        const float* __restrict__ log_w, const float* __restrict__ coef,
+                                                        float* __restrict__ dmu, float* __restrict__ dlv, int Drt) {
   constexpr int DM = DT ? DT : 16;          // DT = 0: latent dimension given at run time (<= 16)
   const int D = DT ? DT : Drt;
   __shared__ float red[4][2 * DM];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = blockIdx.x;
   const float lN = is_mss ? log_w[0] : 0.f, lS = is_mss ? log_w[1] : 0.f, lM = is_mss ? log_w[2] : 0.f;
   const float alpha = coef[DVAE_C_ALPHA], beta = coef[DVAE_C_BETA], gam = coef[DVAE_C_GAMMA] * coef[DVAE_C_ANNEAL];
   const float invB = 1.f / (float)Bg;
@@ -489,6 +487,18 @@ __global__ __launch_bounds__(256) void k_btcvae_bwd_cols_wg(const float* __restr
     dmu[(long)j * D + d] = a;
     dlv[(long)j * D + d] = b;
   }
+}
+
+// both passes in ONE launch: workgroups [0, Bl) take a row each, [Bl, Bl + Bg) a column each (they are independent; on the
+// exchange stream of a sharded step every launch is ~6 us of the chain the FC input gradients wait for)
+template <int DT>
+__global__ __launch_bounds__(256) void k_btcvae_bwd_wg(const float* __restrict__ z, const float* __restrict__ mu,
+                                                       const float* __restrict__ lv, const float* __restrict__ tmp,
+                                                       const float* __restrict__ rowstats, int Bg, int row0, int Bl, int is_mss,
+                                                       const float* __restrict__ log_w, const float* __restrict__ coef,
+                                                       float* __restrict__ dz, float* __restrict__ dmu, float* __restrict__ dlv, int Drt) {
+  if ((int)blockIdx.x < Bl) btcvae_bwd_rows_wg_body<DT>(blockIdx.x, z, mu, lv, tmp, rowstats, Bg, row0, Bl, is_mss, log_w, coef, dz, Drt);
+  else btcvae_bwd_cols_wg_body<DT>(blockIdx.x - Bl, z, mu, lv, rowstats, Bg, row0, Bl, is_mss, log_w, coef, dmu, dlv, Drt);
 }
 
 // ---- FactorVAE pieces ----------------------------------------------------------------------
@@ -775,22 +785,22 @@ int launch_btcvae_bwd(const float* z, const float* mu, const float* lv, const fl
   if (D < 1) return 1;
   if (D > DVAE_MAX_D)
     return launch_btcvae_bwd_wide(z, mu, lv, rowstats, Bg, D, row0, Bl, is_mss, log_w, coef, tmp, dz, dmu, dlv, s);
-  // (a workgroup per row / column up to BTC_WG_MAX_ROWS local rows, a wave per row / column above: see k_btcvae_bwd_rows_wg)
-  const bool wg = Bl <= BTC_WG_MAX_ROWS;
-  if (wg && D == 10) hipLaunchKernelGGL(k_btcvae_bwd_rows_wg<10>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
-                                        is_mss, log_w, coef, dz, D);
-  else if (wg) hipLaunchKernelGGL(k_btcvae_bwd_rows_wg<0>, dim3(Bl), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
-                                  is_mss, log_w, coef, dz, D);
-  else if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
+  // a workgroup per row / column up to BTC_WG_MAX_ROWS local rows (both passes in one launch), a wave per row / column above:
+  // see k_btcvae_bwd_wg
+  if (Bl <= BTC_WG_MAX_ROWS) {
+    if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_wg<10>, dim3(Bl + Bg), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl, is_mss,
+                                    log_w, coef, dz, dmu, dlv, D);
+    else hipLaunchKernelGGL(k_btcvae_bwd_wg<0>, dim3(Bl + Bg), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl, is_mss, log_w,
+                            coef, dz, dmu, dlv, D);
+    DVAE_CHECK_LAUNCH();
+    return 0;
+  }
+  if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_rows<10>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
                                   is_mss, log_w, coef, dz, D);
   else hipLaunchKernelGGL(k_btcvae_bwd_rows<0>, dim3((Bl + 3) / 4), dim3(256), 0, s, z, mu, lv, tmp, rowstats, Bg, row0, Bl,
                           is_mss, log_w, coef, dz, D);
   DVAE_CHECK_LAUNCH();
-  if (wg && D == 10) hipLaunchKernelGGL(k_btcvae_bwd_cols_wg<10>, dim3(Bg), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
-                                        is_mss, log_w, coef, dmu, dlv, D);
-  else if (wg) hipLaunchKernelGGL(k_btcvae_bwd_cols_wg<0>, dim3(Bg), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
-                                  is_mss, log_w, coef, dmu, dlv, D);
-  else if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_cols<10>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
+  if (D == 10) hipLaunchKernelGGL(k_btcvae_bwd_cols<10>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
                                   is_mss, log_w, coef, dmu, dlv, D);
   else hipLaunchKernelGGL(k_btcvae_bwd_cols<0>, dim3((Bg + 3) / 4), dim3(256), 0, s, z, mu, lv, rowstats, Bg, row0, Bl,
                           is_mss, log_w, coef, dmu, dlv, D);
