@@ -176,7 +176,7 @@ int launch_up_mfma32(const ConvArgs& a, hipStream_t s);
 int launch_down_mfma32_dma(const ConvArgs& a, hipStream_t s);  // conv_down_dma.hip: Hs in {8,16}, NHWC -> NHWC
 int launch_wgrad_mfma32_ws(const float* big, const float* small, float* dw, float* db, int bias_from_big, int N, int Hs,
                            float* ws, hipStream_t s);    // wave-specialised, transposed LDS tiles (conv_wgrad_ws.hip): Hs in {8,16}
-int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_big, int nblk, hipStream_t s);
+int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_big, int nblk, hipStream_t s, int N);
 int launch_up_mfma32_ws(const ConvArgs& a, hipStream_t s);      // wave-specialised (conv_up_ws.hip): Hs in {8,16}, NHWC
 int launch_wgrad_mfma32(const float* big, const float* small, float* dw, float* db, int bias_from_big,
                         int N, int Hs, float* ws, hipStream_t s, int small_nchw = 0);

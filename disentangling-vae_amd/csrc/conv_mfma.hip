@@ -358,16 +358,21 @@ __global__ __launch_bounds__(512) void k_wgrad32(const float* __restrict__ big, 
   }
 }
 
+template <bool LEAN>
 __global__ __launch_bounds__(256) void k_wgrad32_reduce(const float* __restrict__ ws, float* __restrict__ dw,
                                                         float* __restrict__ db, int bias_from_big, int nblk) {
-  wgrad32_reduce_body(blockIdx.x, ws, dw, db, bias_from_big, nblk);
+  wgrad32_reduce_body<LEAN>(blockIdx.x, ws, dw, db, bias_from_big, nblk);
 }
 
 size_t wgrad32_ws_floats() { return (size_t)WG_MAX_BLOCKS * WG_STRIDE; }
 
 // fixed-order reduction of `nblk` per-workgroup partials (also used by conv_wgrad_ws.hip, which writes the same format)
-int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_big, int nblk, hipStream_t s) {
-  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(WG_REDUCE_BLOCKS), dim3(256), 0, s, ws, dw, db, bias_from_big, nblk);
+// (N = images of the step: from WGR_LEAN_MIN_IMAGES the low-register form, wgrad_reduce.h)
+int launch_wgrad32_reduce(const float* ws, float* dw, float* db, int bias_from_big, int nblk, hipStream_t s, int N) {
+  if (N >= WGR_LEAN_MIN_IMAGES)
+    hipLaunchKernelGGL(k_wgrad32_reduce<true>, dim3(WG_REDUCE_BLOCKS), dim3(256), 0, s, ws, dw, db, bias_from_big, nblk);
+  else
+    hipLaunchKernelGGL(k_wgrad32_reduce<false>, dim3(WG_REDUCE_BLOCKS), dim3(256), 0, s, ws, dw, db, bias_from_big, nblk);
   DVAE_CHECK_LAUNCH();
   return 0;
 }
@@ -427,9 +432,7 @@ static int launch_wgrad_t(const float* big, const float* small, float* dw, float
   if (attr.first()) { (void)hipFuncSetAttribute((const void*)k_wgrad32<HS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
   hipLaunchKernelGGL(k_wgrad32<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, N, n_units, small_nchw);
   DVAE_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_wgrad32_reduce, dim3(WG_REDUCE_BLOCKS), dim3(256), 0, s, ws, dw, db, bias_from_big, grid);
-  DVAE_CHECK_LAUNCH();
-  return 0;
+  return launch_wgrad32_reduce(ws, dw, db, bias_from_big, grid, s, N);
 }
 
 static bool mfma32_applicable(int Cb, int Cs, int Hs, int Ws, int l0, int l1, int l2) {

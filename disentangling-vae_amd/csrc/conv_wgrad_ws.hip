@@ -319,7 +319,7 @@ static int launch_wgrad_ws_t(const float* big, const float* small, float* dw, fl
   hipLaunchKernelGGL(k_wgrad32ws<HS>, dim3(grid), dim3(512), lds, s, big, small, ws, n_units);
 #endif
   DVAE_CHECK_LAUNCH();
-  return launch_wgrad32_reduce(ws, dw, db, bias_from_big, grid, s);
+  return launch_wgrad32_reduce(ws, dw, db, bias_from_big, grid, s, N);
 }
 
 // NHWC on both sides, Hs in {8, 16}; returns 1 if not applicable

@@ -18,6 +18,7 @@ namespace dvae {
 
 // bias gradient: 4 workgroups x (8 channels x 32 partial-groups); every lane has its 8 partials (x 4 slots when the
 // bias comes from the big side) in flight at once
+template <bool LEAN>
 __device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws, float* __restrict__ db,
                                                     int bias_from_big, int nblk, int blk) {
   __shared__ float redb[32][8];
@@ -25,7 +26,21 @@ __device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws
   const int c = blk * 8 + o;
   const float* wsb = ws + 16384 + c;
   float v[8];
-  if (bias_from_big) {
+  if (bias_from_big && LEAN) {
+#pragma unroll
+    for (int u2 = 0; u2 < 8; u2 += 2) {              // (two partials = 8 loads in flight at a time; the same sums)
+      float a[2][4];
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        const int g = gq + 32 * (u2 + uu);
+        const float* q = wsb + (long)(g < nblk ? g : nblk - 1) * WG_STRIDE;
+        a[uu][0] = q[32]; a[uu][1] = q[64]; a[uu][2] = q[96]; a[uu][3] = q[128];
+      }
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) v[u2 + uu] = (a[uu][0] + a[uu][1]) + (a[uu][2] + a[uu][3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if (bias_from_big) {
     float a[8][4];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {                    // partial gq + 32 u, clamped (zeroed below)
@@ -58,15 +73,47 @@ __device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws
 // 256 workgroups x (16 positions of 16 bytes = 64 outputs) x 16 partial-groups.  Every lane has ALL its partials in flight
 // at once (16 x 16-byte loads, a wave instruction covers 4 partials x 256 contiguous bytes): the reduction is one round trip
 // to L2 / HBM instead of two rounds of 4-byte loads.  Fixed summation order: tree over u per lane, then groups 0..15.
+// LEAN (steps of >= WGR_LEAN_MIN_IMAGES images): the four quarters of the summation tree one after the other -- 4 loads in flight
+// instead of 16, 42 VGPRs instead of 74 -- so that a reduction workgroup FITS beside the other stream's persistent kernels
+// (k_up32ws<8>: 48 free VGPRs per SIMD, k_down32dma: 64-80) instead of waiting for their workgroups to leave: inside the
+// 1024-image step these launches took 22 us on average, one of them 75 (profiles/r06_final4_b1024_timeline.md), alone 6.  The
+// same tree, bit-identical sums.  1024 images 1.0405 -> 1.0288 ms; at 256 / 512 images, where nothing blocks the launch and its
+// own four round trips count, +2.4 / +0.8 %: not used there (profiles/r06_s2_lean.txt).
+#define WGR_LEAN_MIN_IMAGES 768
+template <bool LEAN>
 __device__ __forceinline__ void wgrad32_reduce_body(int blk_x, const float* __restrict__ ws, float* __restrict__ dw,
                                                     float* __restrict__ db, int bias_from_big, int nblk) {
   if (blk_x >= 256) {                                // the last four workgroups reduce the bias gradient
-    if (db) wgrad32_bias_reduce(ws, db, bias_from_big, nblk, blk_x - 256);
+    if (db) wgrad32_bias_reduce<LEAN>(ws, db, bias_from_big, nblk, blk_x - 256);
     return;
   }
   __shared__ __attribute__((aligned(16))) float red[16][64];
   const int p = threadIdx.x & 15, gq = threadIdx.x >> 4;
   const float* src = ws + (blk_x * 16 + p) * 4;
+  if constexpr (LEAN) {
+  f32x4 pair[2];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    f32x4 qa;
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+      const int hh = 2 * pp + hq;
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int g = gq + 16 * (4 * hh + u);
+        v[u] = *reinterpret_cast<const f32x4*>(src + (long)(g < nblk ? g : nblk - 1) * WG_STRIDE);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (gq + 16 * (4 * hh + u) >= nblk) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 q = (v[0] + v[1]) + (v[2] + v[3]);
+      if (hq == 0) qa = q; else pair[pp] = qa + q;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  *reinterpret_cast<f32x4*>(&red[gq][p * 4]) = pair[0] + pair[1];
+  } else {
   f32x4 v[16];
   // unconditional loads from a clamped partial index, zeroed afterwards: a branch per load would serialise them
 #pragma unroll
@@ -82,6 +129,7 @@ __device__ __forceinline__ void wgrad32_reduce_body(int blk_x, const float* __re
 #pragma unroll
     for (int u = 0; u < 16; u += 2 * w) v[u] += v[u + w];
   *reinterpret_cast<f32x4*>(&red[gq][p * 4]) = v[0];
+  }
   __syncthreads();
   if (threadIdx.x < 64) {
     const int o = threadIdx.x;
