@@ -26,20 +26,23 @@ __device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws
   const int c = blk * 8 + o;
   const float* wsb = ws + 16384 + c;
   float v[8];
-  if (bias_from_big && LEAN) {
+  if (LEAN) {
+    // one partial at a time, the same tree ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)): a handful of registers
+    float e = 0.f, pr = 0.f, pp = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
-    for (int u2 = 0; u2 < 8; u2 += 2) {              // (two partials = 8 loads in flight at a time; the same sums)
-      float a[2][4];
-#pragma unroll
-      for (int uu = 0; uu < 2; ++uu) {
-        const int g = gq + 32 * (u2 + uu);
-        const float* q = wsb + (long)(g < nblk ? g : nblk - 1) * WG_STRIDE;
-        a[uu][0] = q[32]; a[uu][1] = q[64]; a[uu][2] = q[96]; a[uu][3] = q[128];
-      }
-#pragma unroll
-      for (int uu = 0; uu < 2; ++uu) v[u2 + uu] = (a[uu][0] + a[uu][1]) + (a[uu][2] + a[uu][3]);
+    for (int u = 0; u < 8; ++u) {
+      const int g = gq + 32 * u;
+      const float* q = wsb + (long)(g < nblk ? g : nblk - 1) * WG_STRIDE;
+      float t;
+      if (bias_from_big) t = (q[32] + q[64]) + (q[96] + q[128]);
+      else t = q[0];
+      if (g >= nblk) t = 0.f;
+      if ((u & 1) == 0) e = t; else pr = e + t;
+      if ((u & 3) == 1) pp = pr;
+      if ((u & 3) == 3) { if (u == 3) q0 = pp + pr; else q1 = pp + pr; }
       __builtin_amdgcn_sched_barrier(0);
     }
+    redb[gq][o] = q0 + q1;
   } else if (bias_from_big) {
     float a[8][4];
 #pragma unroll
@@ -57,15 +60,22 @@ __device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws
       v[u] = wsb[(long)(g < nblk ? g : nblk - 1) * WG_STRIDE];
     }
   }
+  if (!LEAN) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
-    if (gq + 32 * u >= nblk) v[u] = 0.f;
-  redb[gq][o] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    for (int u = 0; u < 8; ++u)
+      if (gq + 32 * u >= nblk) v[u] = 0.f;
+    redb[gq][o] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
   __syncthreads();
   if (threadIdx.x < 8) {
     float t = 0.f;
+    if (LEAN) {
+#pragma unroll 4
+      for (int k = 0; k < 32; ++k) t += redb[k][o];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 32; ++k) t += redb[k][o];
+      for (int k = 0; k < 32; ++k) t += redb[k][o];
+    }
     db[c] = t;
   }
 }
@@ -74,11 +84,12 @@ __device__ __forceinline__ void wgrad32_bias_reduce(const float* __restrict__ ws
 // at once (16 x 16-byte loads, a wave instruction covers 4 partials x 256 contiguous bytes): the reduction is one round trip
 // to L2 / HBM instead of two rounds of 4-byte loads.  Fixed summation order: tree over u per lane, then groups 0..15.
 // LEAN (steps of >= WGR_LEAN_MIN_IMAGES images): the four quarters of the summation tree one after the other -- 4 loads in flight
-// instead of 16, 42 VGPRs instead of 74 -- so that a reduction workgroup FITS beside the other stream's persistent kernels
+// instead of 16, 34 VGPRs instead of 74 (the bias sums one partial at a time) -- so that a reduction workgroup FITS beside the other stream's persistent kernels
 // (k_up32ws<8>: 48 free VGPRs per SIMD, k_down32dma: 64-80) instead of waiting for their workgroups to leave: inside the
 // 1024-image step these launches took 22 us on average, one of them 75 (profiles/r06_final4_b1024_timeline.md), alone 6.  The
 // same tree, bit-identical sums.  1024 images 1.0405 -> 1.0288 ms; at 256 / 512 images, where nothing blocks the launch and its
-// own four round trips count, +2.4 / +0.8 %: not used there (profiles/r06_s2_lean.txt).
+// own four round trips count, +2.4 / +0.8 %: not used there (profiles/r06_s2_lean.txt).  Two loads in flight (28 VGPRs: fits beside
+// k_up32ws<16> as well): 1.0364 against 1.0306 ms (profiles/r06_s2_lean2.txt): not used.
 #define WGR_LEAN_MIN_IMAGES 768
 template <bool LEAN>
 __device__ __forceinline__ void wgrad32_reduce_body(int blk_x, const float* __restrict__ ws, float* __restrict__ dw,
@@ -134,8 +145,13 @@ __device__ __forceinline__ void wgrad32_reduce_body(int blk_x, const float* __re
   if (threadIdx.x < 64) {
     const int o = threadIdx.x;
     float t = 0.f;
+    if (LEAN) {
+#pragma unroll 4
+      for (int k = 0; k < 16; ++k) t += red[k][o];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][o];
+      for (int k = 0; k < 16; ++k) t += red[k][o];
+    }
     const int idx = blk_x * 64 + o;                  // (tap, cs, cb)
     const int tap = idx >> 10, cs = (idx >> 5) & 31, cb = idx & 31;
     dw[(cs * 32 + cb) * 16 + tap] = t;
