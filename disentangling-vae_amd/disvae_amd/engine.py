@@ -311,7 +311,7 @@ class VAEEngine:
         # btcvae 64x64x1 B = 256 0.386 -> 0.375; outside that band the main stream is the tail already: 64 / 128 / 512 / 1024
         # images +1.3 / +1.4 / +2.1 / +0.6 % (profiles/r06_s2_fcw_main.txt)
         self.fcw_main = knob("DVAE_FCW_MAIN", "1") == "1"
-        self.fcw_main_rows = (129, 320)
+        self.fcw_main_rows = tuple(int(v) for v in knob("DVAE_FCW_MAIN_ROWS", "129,320").split(","))
         self._ends_on = False  # this forward pass: set by encode_convs(chain=True), read by fc_chain_fwd / decode_convs
         self._fc_pending = []  # FC weight-gradient problems waiting for the grouped launch (decoder's, deferred)
         self._fc_descs = {}    # host descriptor arrays / argument structs of launches, kept alive for recorded plans
